@@ -1,0 +1,180 @@
+/*
+ * mcl_hip_engine.h — C ABI of the MI355X particle-filter update engine (libmcl_hip_engine.so).
+ *
+ * Drop-in boundary for the hot path of AE-HYU/monte_carlo_localization: the bodies of
+ *     void ParticleFilter::MCL(const Eigen::Vector3d&, const std::vector<float>&)   src/particle_filter.cpp:652-694
+ *     Eigen::Vector3d ParticleFilter::expected_pose()                               src/particle_filter.cpp:696-716
+ * plus the state hand-over points that surround them (get_omap cpp:190-224, lidarCB cpp:297-313,
+ * initialize_particles_pose cpp:388-398, initialize_global cpp:433-443, visualize cpp:946-958).
+ * The reference has no FFI of its own (the functions are private members, hpp:39-43,74-75); the
+ * entry points below are what a binding for this path has to offer, one per hand-over point, and
+ * INTEGRATION.md shows the ~40-line patch that wires them into the unchanged class.
+ *
+ * Conventions
+ *   - plain C, no C++/Eigen/ROS/torch types; the caller owns every host buffer, the engine owns
+ *     all device memory behind the opaque handle and copies in/out synchronously;
+ *   - particle matrices use the memory layout of Eigen::MatrixXd(N,3): column-major, i.e. N x's,
+ *     then N y's, then N thetas (hpp:102); weights are std::vector<double> (hpp:103);
+ *   - every function returns MCL_OK (0) or a negative mcl_status; nothing throws across the ABI.
+ *     On failure the engine state is left as it was (the host patch then skips the tick exactly
+ *     like a failed state_lock_.try_lock(), cpp:756);
+ *   - calls on one handle must be serialised by the caller (they are: single-threaded executor
+ *     cpp:1022 + state_lock_ cpp:756/387/408).  mcl_update() is synchronous: when it returns the
+ *     new particle set, weights and pose are final (its wall time feeds delay compensation,
+ *     cpp:792-796).
+ */
+#ifndef MCL_HIP_ENGINE_H
+#define MCL_HIP_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCL_ABI_VERSION 1
+
+typedef struct mcl_engine mcl_engine_t;
+
+typedef enum {
+    MCL_OK = 0,
+    MCL_ERR_INVALID_ARG = -1,   /* null pointer, size mismatch, bad enum            */
+    MCL_ERR_NOT_READY = -2,     /* map / beam angles / particles not set yet        */
+    MCL_ERR_HIP = -3,           /* a HIP runtime call failed; see mcl_last_error()  */
+    MCL_ERR_NO_DEVICE = -4,     /* no gfx950 device visible                         */
+    MCL_ERR_UNSUPPORTED = -5    /* e.g. ray steps requested but not kept            */
+} mcl_status;
+
+typedef enum {
+    MCL_RESAMPLE_MULTINOMIAL = 0, /* what the reference does: std::discrete_distribution, cpp:658-665 */
+    MCL_RESAMPLE_SYSTEMATIC = 1   /* one offset per update, u_m = (m + u0)/N                           */
+} mcl_resample_mode;
+
+typedef enum {
+    MCL_WEIGHT_LOG = 0,           /* sum of log table entries, max-subtracted (default; no underflow)  */
+    MCL_WEIGHT_PRODUCT = 1        /* sequential double product + pow, bit-for-bit cpp:566-578 incl.
+                                     its underflow at >~200 beams; needs keep_ray_steps                */
+} mcl_weight_mode;
+
+typedef enum {
+    MCL_RAYS_AUTO = 0,            /* = MCL_RAYS_SKIP                                                  */
+    MCL_RAYS_MARCH = 1,           /* literal fixed-step fp64 march on the int8 grid (cpp:611-650)      */
+    MCL_RAYS_SKIP = 2             /* same sample lattice, empty-space skipping on an LDS-resident
+                                     distance-to-obstacle window; exactness guard falls back to MARCH  */
+} mcl_ray_kernel;
+
+/* Numeric subset of the node's parameters (cpp:23-78) + engine knobs. */
+typedef struct {
+    int64_t max_particles;          /* MAX_PARTICLES, cpp:51                                   */
+    int32_t device;                 /* HIP device ordinal                                      */
+    uint64_t seed;                  /* Philox key; the reference seeds from random_device cpp:20 */
+    double max_range_m;             /* cpp:54                                                  */
+    double z_hit, z_short, z_max, z_rand, sigma_hit;   /* cpp:64-68                            */
+    double squash_factor;           /* cpp:53 (INV_SQUASH_FACTOR = 1/squash_factor)            */
+    double motion_dispersion_x, motion_dispersion_y, motion_dispersion_theta; /* cpp:71-73      */
+    int32_t resample_mode;          /* mcl_resample_mode                                       */
+    int32_t weight_mode;            /* mcl_weight_mode                                         */
+    int32_t ray_kernel;             /* mcl_ray_kernel                                          */
+    int32_t keep_ray_steps;         /* !=0: keep the N*B uint8 step indices of the last update */
+    int32_t debug_force_exact;      /* !=0: treat every ray as "ambiguous" (tests the fallback)*/
+    int32_t reserved[7];
+} mcl_config_t;
+
+/* Fills *cfg with the reference's defaults (config/mcl_config.yaml:6-40, cpp:23-47). */
+void mcl_default_config(mcl_config_t *cfg);
+
+int mcl_abi_version(void);
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out);
+void mcl_destroy(mcl_engine_t *h);
+/* Message of the last failing call on this handle ("" if none).  h may be NULL for mcl_create. */
+const char *mcl_last_error(const mcl_engine_t *h);
+
+/* ---- map + sensor table: replaces what get_omap() keeps (cpp:190-195) and
+ *      precompute_sensor_model() builds (cpp:233-292) ------------------------------------- */
+/* data: nav_msgs/OccupancyGrid.data, row-major H x W int8; resolution: MapMetaData.resolution
+ * (float32); origin: info.origin.position.{x,y} (map yaw is ignored, cpp:628-629). */
+int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t height,
+                float resolution, double origin_x, double origin_y);
+/* MAX_RANGE_PX (cpp:195) for the current map. */
+int mcl_get_max_range_px(const mcl_engine_t *h, int32_t *out);
+/* The engine's sensor_model_table_: (P+1)^2 doubles, Eigen column-major (index d*(P+1)+r). */
+int mcl_get_sensor_table(const mcl_engine_t *h, double *out, size_t n);
+
+/* ---- beam geometry: downsampled_angles_ (cpp:306-310, hpp:117) ---------------------------- */
+int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams);
+
+/* ---- particle state: particles_ / weights_ (hpp:102-103) ---------------------------------- */
+/* After initialize_particles_pose / initialize_global rewrote the host copies (cpp:388-398,
+ * 433-443).  n must be <= max_particles and becomes the active particle count. */
+int mcl_set_particles(mcl_engine_t *h, const double *xyz_colmajor, const double *weights, int64_t n);
+int mcl_get_particles(mcl_engine_t *h, double *xyz_colmajor, int64_t n);
+int mcl_get_weights(mcl_engine_t *h, double *weights, int64_t n);
+/* visualize()'s weighted sample of k rows (cpp:949-956): k draws from the current weights.
+ * uniforms: k doubles in [0,1) (e.g. from the host's rng_) or NULL for Philox draws.
+ * out: k x 3 column-major. */
+int mcl_sample_particles(mcl_engine_t *h, int32_t k, const double *uniforms, double *out_colmajor);
+/* get_current_pose()'s particles_.colwise().mean() (cpp:903-908). */
+int mcl_particle_mean(mcl_engine_t *h, double out[3]);
+
+/* ---- the update: body of MCL(action, observation) (cpp:652-694) --------------------------- */
+/* action = (forward displacement m, unused, yaw displacement rad) (cpp:761-772);
+ * obs = n_beams downsampled ranges in metres (cpp:316-320).
+ * Injection hooks for reference-exact parity: normals = N x 3 ROW-major doubles in
+ * the reference's draw order (n_x, n_y, n_theta per particle, cpp:496-498), uniforms = N doubles
+ * in [0,1) as discrete_distribution would draw them (cpp:663).  Either may be NULL -> Philox. */
+int mcl_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams,
+               const double *normals_nx3, const double *uniforms_n);
+/* sensor_model() + normalisation only, on the current particles (cpp:676-686): no resample, no
+ * motion.  Used by parity tests of the ray-cast / likelihood stage. */
+int mcl_sensor_update(mcl_engine_t *h, const float *obs, int32_t n_beams);
+
+/* ---- expected_pose() (cpp:696-716) --------------------------------------------------------- */
+int mcl_expected_pose(mcl_engine_t *h, double out[3]);
+
+/* ---- TimingStats mirror (utils.hpp:51-57): resampling, motion_model, query_prep, ray_casting,
+ *      sensor_model (table eval + normalise), total — milliseconds of the LAST update -------- */
+int mcl_get_stage_timings(const mcl_engine_t *h, double ms[6]);
+
+/* ---- parity / diagnostics ------------------------------------------------------------------ */
+int mcl_get_resample_indices(mcl_engine_t *h, int32_t *idx, int64_t n);      /* parents of last update */
+int mcl_get_ray_steps(mcl_engine_t *h, uint8_t *steps, size_t n);            /* N*B, needs keep_ray_steps */
+int mcl_get_log_weights(mcl_engine_t *h, double *logw, int64_t n);           /* un-normalised log w   */
+/* counters of the last update: [0] rays resolved by the exact fallback, [1] particles that did
+ * not fit the LDS window (global-memory path), [2] grid probes examined, [3] reserved */
+int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
+/* duration (ms) of the dominant kernel (ray cast + likelihood) in the last update, measured
+ * with HIP events on the engine's own stream */
+int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
+
+/* ---- multi-GPU staging (one engine per rank; collectives are the host's) -- */
+/* Device pointers of engine-owned buffers so the host can hand them to RCCL without copies. */
+typedef enum {
+    MCL_BUF_X = 0, MCL_BUF_Y = 1, MCL_BUF_THETA = 2,  /* current particle columns, double[N]      */
+    MCL_BUF_QWEIGHT = 3,                               /* uint64[N] fixed-point weights (2^-36)    */
+    MCL_BUF_LOGW = 4,                                  /* double[N]                                */
+    MCL_BUF_SCALARS = 5                                /* double[8]: max logw, sum w, sum q (as
+                                                          u64 bits), sum wx, wy, wsin, wcos, -    */
+} mcl_buffer_id;
+int mcl_device_ptr(mcl_engine_t *h, int32_t which, void **dev_ptr);
+/* Stage 1: resample this rank's n children [child_first, child_first+n) out of the GLOBAL parent
+ * set (device pointers, n_parents entries each: columns + inclusive global CDF of q with total
+ * q_total), apply motion, cast rays, leave log-weights and the local max in SCALARS[0]. */
+int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth,
+                        const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
+                        int64_t child_first, int64_t n_children_total,
+                        const double action[3], const float *obs, int32_t n_beams);
+/* Stage 2: given the GLOBAL max log-weight, compute w, q and the local partial sums (SCALARS). */
+int mcl_stage_weights(mcl_engine_t *h, double global_max_logw);
+/* Stage 3: install the GLOBAL sums (sum w, wx, wy, wsin, wcos) so that get_weights /
+ * expected_pose report globally normalised values. */
+int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5]);
+/* Inclusive scan of q (uint64) on the engine's stream: cdf[i] = offset + q[0] + ... + q[i]. */
+int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCL_HIP_ENGINE_H */

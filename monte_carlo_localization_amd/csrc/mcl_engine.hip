@@ -1,0 +1,856 @@
+// mcl_engine.hip — C-ABI shim (include/mcl_hip_engine.h) over the HIP kernels in mcl_kernels.h.
+//
+// Host-side work done here, all of it init-time or O(beams) per update:
+//   * sensor table (cpp:233-292) in double, its fp32 log form, the padded distance field;
+//   * motion scalars (cpp:452-471), obs_idx (cpp:549-554,570,573);
+//   * kernel launches on the engine's own stream + HIP-event stage timings (utils.hpp:51-57).
+// There is NO CPU fallback: without a gfx950 device mcl_create fails with MCL_ERR_NO_DEVICE.
+#include "../../include/mcl_hip_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcl_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_COUNT };
+
+}  // namespace
+
+struct mcl_engine {
+    mcl_config_t cfg{};
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT]{};
+    std::string err;
+
+    // map
+    bool have_map = false;
+    int W = 0, H = 0, P = 0, Wp = 0, Hp = 0, Wps = 0, tw_cells = 0;
+    double res = 0, ox = 0, oy = 0;
+    std::vector<double> table;          // (P+1)^2 column-major (d*(P+1)+r)
+    int8_t *d_grid = nullptr;
+    uint8_t *d_dist = nullptr;
+    float *d_L = nullptr;               // [r_obs][d]
+    double *d_table = nullptr;          // double table (product mode)
+
+    // beams
+    int B = 0, bpad = 0;
+    std::vector<float> angles;
+    float *d_angle = nullptr;
+    double2 *d_beam_cs = nullptr;
+    int32_t *d_obs_idx = nullptr;
+    float *d_Lt = nullptr;
+    size_t lt_capacity = 0;
+
+    // particles
+    int64_t cap = 0, N = 0;
+    bool have_particles = false;
+    double *d_x[2]{}, *d_y[2]{}, *d_th[2]{};
+    int cur = 0;
+    double *d_w = nullptr, *d_logw = nullptr, *d_tmp = nullptr;   // tmp: cap*3 doubles
+    uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
+    int32_t *d_idx = nullptr;
+    uint8_t *d_steps = nullptr;
+    size_t steps_capacity = 0, blocktot_capacity = 0;
+    double *d_part = nullptr;           // kRedBlocks * 8
+    double *d_scalars = nullptr;        // 8
+    unsigned long long *d_counters = nullptr;  // 4
+    double *d_inject = nullptr;         // cap*4 (normals + uniforms)
+    double h_scalars[8]{};
+    uint64_t q_total = 0;
+    double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
+    bool have_idx = false, have_steps = false, have_logw = false;
+    uint32_t update_idx = 0;
+    double timings[6]{};
+    double ray_ms = 0;
+    unsigned long long h_counters[4]{};
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return MCL_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+int fail(mcl_engine *h, int code, const char *msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+template <class T>
+void dfree(T *&p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+// cpp:233-292, restated; column-major (d*(tw)+r).
+void build_sensor_table(const mcl_config_t &c, int P, std::vector<double> &t)
+{
+    const int tw = P + 1;
+    t.assign((size_t)tw * tw, 0.0);
+    for (int d = 0; d < tw; ++d) {
+        double norm = 0.0;
+        for (int r = 0; r < tw; ++r) {
+            double prob = 0.0;
+            double z = (double)(r - d);
+            prob += c.z_hit * std::exp(-(z * z) / (2.0 * c.sigma_hit * c.sigma_hit)) / (c.sigma_hit * std::sqrt(2.0 * M_PI));
+            if (r < d) prob += 2.0 * c.z_short * (d - r) / (double)d;
+            if (r == P) prob += c.z_max;
+            if (r < P) prob += c.z_rand * 1.0 / (double)P;
+            norm += prob;
+            t[(size_t)d * tw + r] = prob;
+        }
+        if (norm > 0)
+            for (int r = 0; r < tw; ++r) t[(size_t)d * tw + r] /= norm;
+    }
+}
+
+// Padded stop grid + exact Chebyshev distance (two-pass 8-neighbour chamfer), capped at 255.
+// Padded cell (xp,yp), xp in [0,W], yp in [0,H], stands for reference cell (max(xp-1,0), max(yp-1,0)):
+// the reference truncates toward zero (cpp:628-629), so pixel coordinates in (-1,0) read cell 0.
+// Everything outside the padded grid is "stop" (map boundary, cpp:632-636).
+void build_distance_field(const int8_t *grid, int W, int H, int Wp, int Hp, int Wps, std::vector<uint8_t> &dist)
+{
+    std::vector<int> d((size_t)Hp * Wp);
+    const int BIG = 1 << 20;
+    for (int yp = 0; yp < Hp; ++yp)
+        for (int xp = 0; xp < Wp; ++xp) {
+            int gx = std::max(xp - 1, 0), gy = std::max(yp - 1, 0);
+            d[(size_t)yp * Wp + xp] = (grid[(size_t)gy * W + gx] > 50) ? 0 : BIG;
+        }
+    auto at = [&](int x, int y) -> int { return (x < 0 || y < 0 || x >= Wp || y >= Hp) ? 0 : d[(size_t)y * Wp + x]; };
+    for (int y = 0; y < Hp; ++y)
+        for (int x = 0; x < Wp; ++x) {
+            int v = d[(size_t)y * Wp + x];
+            if (v == 0) continue;
+            int m = std::min(std::min(at(x - 1, y - 1), at(x, y - 1)), std::min(at(x + 1, y - 1), at(x - 1, y)));
+            d[(size_t)y * Wp + x] = std::min(v, m + 1);
+        }
+    for (int y = Hp - 1; y >= 0; --y)
+        for (int x = Wp - 1; x >= 0; --x) {
+            int v = d[(size_t)y * Wp + x];
+            if (v == 0) continue;
+            int m = std::min(std::min(at(x + 1, y + 1), at(x, y + 1)), std::min(at(x - 1, y + 1), at(x + 1, y)));
+            d[(size_t)y * Wp + x] = std::min(v, m + 1);
+        }
+    dist.assign((size_t)Hp * Wps, 0);
+    for (int y = 0; y < Hp; ++y)
+        for (int x = 0; x < Wp; ++x) dist[(size_t)y * Wps + x] = (uint8_t)std::min(d[(size_t)y * Wp + x], 255);
+}
+
+// cpp:452-471
+void motion_scalars(const double action[3], double &dt, double &v, double &w)
+{
+    dt = 0.01; v = 0.0; w = 0.0;
+    double fd = action[0], ad = action[2];
+    if (std::abs(fd) > 0.001) {
+        if (std::abs(fd) < 0.1) dt = std::abs(fd) / 1.0;
+        else dt = std::abs(fd) / 5.0;
+        dt = std::max(0.001, std::min(dt, 0.1));
+        v = fd / dt;
+    }
+    if (std::abs(ad) > 0.001) w = ad / dt;
+}
+
+// cpp:549-554, 570, 573; NaN -> 0
+void obs_indices(const float *obs, int B, double res, int P, std::vector<int32_t> &out)
+{
+    out.resize(B);
+    for (int j = 0; j < B; ++j) {
+        float px = (float)((double)obs[j] / res);
+        if (px > (float)P) px = (float)P;
+        float r = std::round(px);
+        int idx;
+        if (r != r) idx = 0;
+        else if (r <= -2147483648.0f) idx = 0;
+        else idx = (int)r;
+        idx = std::max(0, std::min(idx, P));
+        out[j] = idx;
+    }
+}
+
+int ensure_lt(mcl_engine *h)
+{
+    size_t need = (size_t)(h->P + 1) * h->bpad;
+    if (need > h->lt_capacity) {
+        dfree(h->d_Lt);
+        HIPCHK(h, hipMalloc(&h->d_Lt, need * sizeof(float)));
+        h->lt_capacity = need;
+    }
+    return MCL_OK;
+}
+
+int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset, uint64_t *d_total)
+{
+    int nb = (int)((n + mcl::kScanTile - 1) / mcl::kScanTile);
+    hipLaunchKernelGGL(mcl::k_scan_partials, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot);
+    hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total);
+    hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+}
+
+// weights/q/sums from either log-weights (from_log) or raw weights already in d_w
+int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override)
+{
+    const int64_t n = h->N;
+    const double *src = from_log ? h->d_logw : h->d_w;
+    if (!d_max_override) {
+        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, n, h->d_part);
+        hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+    }
+    hipLaunchKernelGGL(mcl::k_weights, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, from_log ? 1 : 0,
+                       h->d_scalars, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, h->d_w, h->d_q, h->d_part);
+    hipLaunchKernelGGL(mcl::k_final_sums, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+}
+
+int fetch_scalars(mcl_engine *h)
+{
+    HIPCHK(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint64_t qt;
+    std::memcpy(&qt, &h->h_scalars[2], 8);
+    h->q_total = qt;
+    h->global_sums[0] = h->h_scalars[1];
+    h->global_sums[1] = h->h_scalars[3];
+    h->global_sums[2] = h->h_scalars[4];
+    h->global_sums[3] = h->h_scalars[5];
+    h->global_sums[4] = h->h_scalars[6];
+    return MCL_OK;
+}
+
+int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n)
+{
+    mcl::RayArgs a{};
+    a.x = x; a.y = y; a.th = th; a.n = n;
+    a.B = h->B; a.bpad = h->bpad; a.P = h->P;
+    a.beam_cs = h->d_beam_cs; a.beam_angle = h->d_angle; a.Lt = h->d_Lt;
+    a.logw = h->d_logw;
+    a.steps = h->cfg.keep_ray_steps ? h->d_steps : nullptr;
+    a.grid = h->d_grid; a.W = h->W; a.H = h->H;
+    a.res = h->res; a.ox = h->ox; a.oy = h->oy;
+    a.dist = h->d_dist; a.Wp = h->Wp; a.Hp = h->Hp; a.Wps = h->Wps;
+    a.tw_cells = h->tw_cells;
+    a.counters = h->d_counters;
+    a.force_exact = h->cfg.debug_force_exact;
+    int mode = h->cfg.ray_kernel == MCL_RAYS_MARCH ? 1 : 2;
+    int64_t want = (n + 15) / 16;
+    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
+    if (mode == 1) {
+        hipLaunchKernelGGL(mcl::k_rays<1>, dim3(grid), dim3(mcl::kRayThreads), 0, h->stream, a);
+    } else {
+        size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
+        hipLaunchKernelGGL(mcl::k_rays<2>, dim3(grid), dim3(mcl::kRayThreads), lds, h->stream, a);
+    }
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+}
+
+// obs -> obs_idx upload + per-update transposed log table
+int prepare_observation(mcl_engine *h, const float *obs)
+{
+    std::vector<int32_t> oi;
+    obs_indices(obs, h->B, h->res, h->P, oi);
+    HIPCHK(h, hipMemcpyAsync(h->d_obs_idx, oi.data(), (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // oi is a stack-lifetime buffer
+    int rc = ensure_lt(h);
+    if (rc) return rc;
+    dim3 g((h->bpad + 255) / 256, h->P + 1);
+    hipLaunchKernelGGL(mcl::k_build_lt, g, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->bpad, h->P + 1, h->d_Lt);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+}
+
+int sensor_and_weights(mcl_engine *h, const double *d_global_max)
+{
+    // d_logw holds the log-weights of the current particle set
+    if (h->cfg.weight_mode == MCL_WEIGHT_PRODUCT) {
+        if (!h->cfg.keep_ray_steps) return fail(h, MCL_ERR_UNSUPPORTED, "weight_mode PRODUCT needs keep_ray_steps");
+        int64_t n = h->N;
+        hipLaunchKernelGGL(mcl::k_product_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_steps,
+                           h->d_obs_idx, n, h->B, h->d_table, h->P + 1, 1.0 / h->cfg.squash_factor, h->d_w);
+        HIPCHK(h, hipGetLastError());
+        return weight_stats(h, false, nullptr);
+    }
+    return weight_stats(h, true, d_global_max);
+}
+
+bool ready(mcl_engine *h, bool need_particles)
+{
+    return h && h->have_map && h->B > 0 && (!need_particles || h->have_particles);
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcl_abi_version(void) { return MCL_ABI_VERSION; }
+
+void mcl_default_config(mcl_config_t *c)
+{
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->max_particles = 2000;       // cpp:24, yaml:6
+    c->device = 0;
+    c->seed = 0;
+    c->max_range_m = 12.0;         // cpp:27
+    c->z_hit = 0.80; c->z_short = 0.01; c->z_max = 0.07; c->z_rand = 0.12; c->sigma_hit = 8.0;   // cpp:30-34
+    c->squash_factor = 2.2;        // cpp:26
+    c->motion_dispersion_x = 0.05; c->motion_dispersion_y = 0.025; c->motion_dispersion_theta = 0.25;   // cpp:35-37
+    c->resample_mode = MCL_RESAMPLE_MULTINOMIAL;
+    c->weight_mode = MCL_WEIGHT_LOG;
+    c->ray_kernel = MCL_RAYS_AUTO;
+}
+
+const char *mcl_last_error(const mcl_engine_t *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
+{
+    g_create_error.clear();
+    if (!cfg || !out) { g_create_error = "null argument"; return MCL_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (cfg->max_particles <= 0 || cfg->max_particles > ((int64_t)1 << 30) || cfg->squash_factor <= 0 || cfg->max_range_m <= 0) {
+        g_create_error = "bad config (max_particles / squash_factor / max_range_m)";
+        return MCL_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = "no HIP device (this engine has no CPU path)";
+        return MCL_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) {
+        g_create_error = "hipSetDevice/hipGetDeviceProperties failed";
+        return MCL_ERR_NO_DEVICE;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", engine is built for gfx950 only";
+        return MCL_ERR_NO_DEVICE;
+    }
+    mcl_engine *h = new mcl_engine();
+    h->cfg = *cfg;
+    h->num_cu = prop.multiProcessorCount;
+    h->cap = cfg->max_particles;
+    auto bail = [&](const char *what) {
+        g_create_error = std::string(what) + ": " + h->err;
+        mcl_destroy(h);
+        return MCL_ERR_HIP;
+    };
+#define CRT(call)                                                         \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) { h->err = hipGetErrorString(e_); return bail(#call); } \
+    } while (0)
+    CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < EV_COUNT; ++i) CRT(hipEventCreate(&h->ev[i]));
+    const size_t nb = (size_t)h->cap * sizeof(double);
+    for (int b = 0; b < 2; ++b) {
+        CRT(hipMalloc(&h->d_x[b], nb)); CRT(hipMalloc(&h->d_y[b], nb)); CRT(hipMalloc(&h->d_th[b], nb));
+    }
+    CRT(hipMalloc(&h->d_w, nb)); CRT(hipMalloc(&h->d_logw, nb)); CRT(hipMalloc(&h->d_tmp, nb * 3));
+    CRT(hipMalloc(&h->d_q, (size_t)h->cap * 8)); CRT(hipMalloc(&h->d_cdf, (size_t)h->cap * 8));
+    h->blocktot_capacity = (size_t)h->cap / mcl::kScanTile + 2;
+    CRT(hipMalloc(&h->d_blocktot, h->blocktot_capacity * 8));
+    CRT(hipMalloc(&h->d_idx, (size_t)h->cap * 4));
+    CRT(hipMalloc(&h->d_part, (size_t)mcl::kRedBlocks * 8 * sizeof(double)));
+    CRT(hipMalloc(&h->d_scalars, 8 * sizeof(double)));
+    CRT(hipMalloc(&h->d_counters, 4 * sizeof(unsigned long long)));
+    CRT(hipMalloc(&h->d_inject, nb * 4));
+    CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
+    CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#undef CRT
+    *out = h;
+    return MCL_OK;
+}
+
+void mcl_destroy(mcl_engine_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
+    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject);
+    dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt);
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t height, float resolution, double origin_x,
+                double origin_y)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!data || width == 0 || height == 0 || width > 200000 || height > 200000) return fail(h, MCL_ERR_INVALID_ARG, "bad map dimensions");
+    if (!(resolution > 0.0f)) return fail(h, MCL_ERR_INVALID_ARG, "invalid map resolution");   // cpp:236-240
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const double res = (double)resolution;                    // cpp:191
+    const int P = (int)(h->cfg.max_range_m / res);            // cpp:195
+    if (P < 1 || P > 255) return fail(h, MCL_ERR_UNSUPPORTED, "MAX_RANGE_PX must be in [1,255] (step indices are bytes)");
+    h->W = (int)width; h->H = (int)height; h->P = P;
+    h->res = res; h->ox = origin_x; h->oy = origin_y;
+    h->Wp = h->W + 1; h->Hp = h->H + 1; h->Wps = (h->Wp + 7) & ~7;
+    // LDS window: as large as 160 KiB allows (nibbles), multiple of 8 cells
+    h->tw_cells = 568;
+    build_sensor_table(h->cfg, P, h->table);
+    const int tw = P + 1;
+    std::vector<float> L((size_t)tw * tw);
+    const double inv_squash = 1.0 / h->cfg.squash_factor;     // cpp:53
+    for (int r = 0; r < tw; ++r)
+        for (int d = 0; d < tw; ++d) L[(size_t)r * tw + d] = (float)(std::log(h->table[(size_t)d * tw + r]) * inv_squash);
+    std::vector<uint8_t> dist;
+    build_distance_field(data, h->W, h->H, h->Wp, h->Hp, h->Wps, dist);
+    dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
+    HIPCHK(h, hipMalloc(&h->d_grid, (size_t)h->W * h->H));
+    HIPCHK(h, hipMalloc(&h->d_dist, dist.size()));
+    HIPCHK(h, hipMalloc(&h->d_L, L.size() * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->d_table, h->table.size() * sizeof(double)));
+    HIPCHK(h, hipMemcpy(h->d_grid, data, (size_t)h->W * h->H, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_dist, dist.data(), dist.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->lt_capacity = 0; dfree(h->d_Lt);
+    h->have_map = true;
+    return MCL_OK;
+}
+
+int mcl_get_max_range_px(const mcl_engine_t *h, int32_t *out)
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    if (!h->have_map) return MCL_ERR_NOT_READY;
+    *out = h->P;
+    return MCL_OK;
+}
+
+int mcl_get_sensor_table(const mcl_engine_t *h, double *out, size_t n)
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    if (!h->have_map) return MCL_ERR_NOT_READY;
+    if (n != h->table.size()) return MCL_ERR_INVALID_ARG;
+    std::memcpy(out, h->table.data(), n * sizeof(double));
+    return MCL_OK;
+}
+
+int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!angles || n_beams <= 0 || n_beams > 65536) return fail(h, MCL_ERR_INVALID_ARG, "bad beam angles");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->B = n_beams; h->bpad = (n_beams + 63) & ~63;
+    h->angles.assign(angles, angles + n_beams);
+    std::vector<double2> cs(n_beams);
+    for (int j = 0; j < n_beams; ++j) {
+        double a = (double)angles[j];                 // cpp:533 widens the float angle
+        cs[j] = make_double2(std::cos(a), std::sin(a));
+    }
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx);
+    HIPCHK(h, hipMalloc(&h->d_angle, (size_t)n_beams * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->d_beam_cs, (size_t)n_beams * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_obs_idx, (size_t)n_beams * sizeof(int32_t)));
+    HIPCHK(h, hipMemcpy(h->d_angle, angles, (size_t)n_beams * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)n_beams * sizeof(double2), hipMemcpyHostToDevice));
+    h->lt_capacity = 0; dfree(h->d_Lt);
+    if (h->cfg.keep_ray_steps) {
+        size_t need = (size_t)h->cap * n_beams;
+        if (need > h->steps_capacity) {
+            dfree(h->d_steps);
+            HIPCHK(h, hipMalloc(&h->d_steps, need));
+            h->steps_capacity = need;
+        }
+    }
+    return MCL_OK;
+}
+
+int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!xyz || !weights || n <= 0 || n > h->cap) return fail(h, MCL_ERR_INVALID_ARG, "bad particle arrays / count");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t nb = (size_t)n * sizeof(double);
+    const int c = h->cur;
+    HIPCHK(h, hipMemcpyAsync(h->d_x[c], xyz, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_y[c], xyz + n, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_th[c], xyz + 2 * n, nb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_w, weights, nb, hipMemcpyHostToDevice, h->stream));
+    h->N = n;
+    int rc = weight_stats(h, false, nullptr);
+    if (rc) return rc;
+    rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+    if (rc) return rc;
+    rc = fetch_scalars(h);
+    if (rc) return rc;
+    h->have_particles = true;
+    h->have_idx = h->have_steps = h->have_logw = false;
+    return MCL_OK;
+}
+
+int mcl_get_particles(mcl_engine_t *h, double *xyz, int64_t n)
+{
+    if (!h || !xyz) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    if (n != h->N) return fail(h, MCL_ERR_INVALID_ARG, "n != active particle count");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t nb = (size_t)n * sizeof(double);
+    const int c = h->cur;
+    HIPCHK(h, hipMemcpyAsync(xyz, h->d_x[c], nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(xyz + n, h->d_y[c], nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(xyz + 2 * n, h->d_th[c], nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_get_weights(mcl_engine_t *h, double *weights, int64_t n)
+{
+    if (!h || !weights) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    if (n != h->N) return fail(h, MCL_ERR_INVALID_ARG, "n != active particle count");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(mcl::k_normalized, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_w, n, h->global_sums[0], h->d_tmp);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(weights, h->d_tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_sample_particles(mcl_engine_t *h, int32_t k, const double *uniforms, double *out)
+{
+    if (!h || !out || k <= 0 || k > 65536) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    double *d_u = nullptr;
+    double *d_out = h->d_tmp;
+    if ((int64_t)k * 4 > h->cap * 3) return fail(h, MCL_ERR_INVALID_ARG, "k too large for this engine");
+    if (uniforms) {
+        d_u = h->d_tmp + (size_t)3 * k;
+        HIPCHK(h, hipMemcpyAsync(d_u, uniforms, (size_t)k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    const int c = h->cur;
+    hipLaunchKernelGGL(mcl::k_sample, dim3((k + 63) / 64), dim3(64), 0, h->stream, h->d_x[c], h->d_y[c], h->d_th[c], h->d_cdf, h->N,
+                       h->q_total, d_u, (uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32), h->update_idx, k, d_out);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)3 * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_particle_mean(mcl_engine_t *h, double out[3])
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int c = h->cur;
+    const int nb = 256;
+    hipLaunchKernelGGL(mcl::k_colsum, dim3(nb), dim3(mcl::kRedThreads), 0, h->stream, h->d_x[c], h->d_y[c], h->d_th[c], h->N, h->d_part);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> part((size_t)nb * 4);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double s[3] = {0, 0, 0};
+    for (int b = 0; b < nb; ++b) { s[0] += part[b * 4]; s[1] += part[b * 4 + 1]; s[2] += part[b * 4 + 2]; }
+    for (int k = 0; k < 3; ++k) out[k] = s[k] / (double)h->N;
+    return MCL_OK;
+}
+
+static int do_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, const double *normals,
+                     const double *uniforms, bool resample_and_move)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
+    if (!obs || n_beams != h->B || (resample_and_move && !action)) return fail(h, MCL_ERR_INVALID_ARG, "bad action/observation");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t n = h->N;
+    const double *d_norm = nullptr, *d_uni = nullptr;
+    if (resample_and_move) {
+        if (normals) {
+            HIPCHK(h, hipMemcpyAsync(h->d_inject, normals, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            d_norm = h->d_inject;
+        }
+        if (uniforms) {
+            HIPCHK(h, hipMemcpyAsync(h->d_inject + (size_t)3 * h->cap, uniforms, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            d_uni = h->d_inject + (size_t)3 * h->cap;
+        }
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
+    if (resample_and_move) {
+        const int c = h->cur, nx = c ^ 1;
+        mcl::ResampleArgs a{};
+        a.px = h->d_x[c]; a.py = h->d_y[c]; a.pth = h->d_th[c];
+        a.cdf = h->d_cdf; a.n_parents = n; a.q_total = h->q_total;
+        a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
+        a.idx_out = h->d_idx;
+        a.n_children = n; a.child_first = 0; a.n_children_total = n;
+        a.mode = h->cfg.resample_mode;
+        a.uniforms = d_uni; a.normals = d_norm;
+        a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+        a.update_idx = h->update_idx;
+        a.k0 = 0;
+        if (a.mode == MCL_RESAMPLE_SYSTEMATIC) {
+            // one 32-bit offset per update: Philox stream 3 (host restatement of the same function)
+            uint32_t c0 = 0, c1 = h->update_idx, c2 = 3, c3 = 0, k0 = a.seed_lo, k1 = a.seed_hi;
+            for (int r = 0; r < 10; ++r) {
+                uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+                uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+            }
+            a.k0 = c0;
+            if (uniforms) a.k0 = (uint32_t)(std::min(std::max(uniforms[0], 0.0), 0.99999999976716936) * 4294967296.0);
+        }
+        motion_scalars(action, a.dt, a.v, a.w);
+        a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
+        a.do_resample = 1; a.do_motion = 1;
+        hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+        HIPCHK(h, hipGetLastError());
+        h->cur = nx;                       // cpp:689 as a pointer swap
+        h->have_idx = true;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
+    int rc = prepare_observation(h, obs);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
+    rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    rc = sensor_and_weights(h, nullptr);
+    if (rc) return rc;
+    rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);   // CDF for the next resample / visualize
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    rc = fetch_scalars(h);                 // synchronises the stream
+    if (rc) return rc;
+    h->have_logw = true;
+    h->have_steps = h->cfg.keep_ray_steps != 0;
+    if (resample_and_move) h->update_idx++;
+    h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
+    h->timings[1] = 0.0;                   // motion is fused into the resample/gather kernel
+    h->timings[2] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_QUERY]);
+    h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
+    h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
+    h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->ray_ms = h->timings[3];
+    return MCL_OK;
+}
+
+int mcl_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, const double *normals_nx3,
+               const double *uniforms_n)
+{
+    return do_update(h, action, obs, n_beams, normals_nx3, uniforms_n, true);
+}
+
+int mcl_sensor_update(mcl_engine_t *h, const float *obs, int32_t n_beams)
+{
+    return do_update(h, nullptr, obs, n_beams, nullptr, nullptr, false);
+}
+
+int mcl_expected_pose(mcl_engine_t *h, double out[3])
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    const double s = h->global_sums[0];
+    // cpp:704-713 sums w_i*x_i with normalised w_i; here the division by sum(w) comes last
+    double k = (s > 0.0) ? 1.0 / s : 1.0;
+    out[0] = h->global_sums[1] * k;
+    out[1] = h->global_sums[2] * k;
+    out[2] = std::atan2(h->global_sums[3] * k, h->global_sums[4] * k);
+    return MCL_OK;
+}
+
+int mcl_get_stage_timings(const mcl_engine_t *h, double ms[6])
+{
+    if (!h || !ms) return MCL_ERR_INVALID_ARG;
+    std::memcpy(ms, h->timings, sizeof(h->timings));
+    return MCL_OK;
+}
+
+int mcl_get_resample_indices(mcl_engine_t *h, int32_t *idx, int64_t n)
+{
+    if (!h || !idx) return MCL_ERR_INVALID_ARG;
+    if (!h->have_idx) return MCL_ERR_NOT_READY;
+    if (n != h->N) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(idx, h->d_idx, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_get_ray_steps(mcl_engine_t *h, uint8_t *steps, size_t n)
+{
+    if (!h || !steps) return MCL_ERR_INVALID_ARG;
+    if (!h->cfg.keep_ray_steps) return fail(h, MCL_ERR_UNSUPPORTED, "engine created without keep_ray_steps");
+    if (!h->have_steps) return MCL_ERR_NOT_READY;
+    if (n != (size_t)h->N * h->B) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(steps, h->d_steps, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_get_log_weights(mcl_engine_t *h, double *logw, int64_t n)
+{
+    if (!h || !logw) return MCL_ERR_INVALID_ARG;
+    if (!h->have_logw) return MCL_ERR_NOT_READY;
+    if (n != h->N) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(logw, h->d_logw, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_get_counters(mcl_engine_t *h, uint64_t out[4])
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    for (int i = 0; i < 4; ++i) out[i] = h->h_counters[i];
+    return MCL_OK;
+}
+
+int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms)
+{
+    if (!h || !ms) return MCL_ERR_INVALID_ARG;
+    *ms = h->ray_ms;
+    return MCL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU staging
+// ---------------------------------------------------------------------------------------------
+int mcl_device_ptr(mcl_engine_t *h, int32_t which, void **p)
+{
+    if (!h || !p) return MCL_ERR_INVALID_ARG;
+    switch (which) {
+    case MCL_BUF_X: *p = h->d_x[h->cur]; break;
+    case MCL_BUF_Y: *p = h->d_y[h->cur]; break;
+    case MCL_BUF_THETA: *p = h->d_th[h->cur]; break;
+    case MCL_BUF_QWEIGHT: *p = h->d_q; break;
+    case MCL_BUF_LOGW: *p = h->d_logw; break;
+    case MCL_BUF_SCALARS: *p = h->d_scalars; break;
+    default: return MCL_ERR_INVALID_ARG;
+    }
+    return MCL_OK;
+}
+
+int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
+                        int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
+                        const double action[3], const float *obs, int32_t n_beams)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
+    if (!d_px || !d_py || !d_pth || !d_cdf || !action || !obs || n_beams != h->B || n_parents <= 0)
+        return fail(h, MCL_ERR_INVALID_ARG, "bad stage_propagate arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int64_t n = h->N;
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
+    const int nx = h->cur ^ 1;
+    mcl::ResampleArgs a{};
+    a.px = d_px; a.py = d_py; a.pth = d_pth; a.cdf = d_cdf; a.n_parents = n_parents; a.q_total = q_total;
+    a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
+    a.idx_out = h->d_idx;
+    a.n_children = n; a.child_first = child_first; a.n_children_total = n_children_total;
+    a.mode = h->cfg.resample_mode;
+    a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    a.update_idx = h->update_idx;
+    if (a.mode == MCL_RESAMPLE_SYSTEMATIC) {
+        uint32_t c0 = 0, c1 = h->update_idx, c2 = 3, c3 = 0, k0 = a.seed_lo, k1 = a.seed_hi;
+        for (int r = 0; r < 10; ++r) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        a.k0 = c0;
+    }
+    motion_scalars(action, a.dt, a.v, a.w);
+    a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
+    a.do_resample = 1; a.do_motion = 1;
+    hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    h->cur = nx;
+    h->have_idx = true;
+    HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
+    int rc = prepare_observation(h, obs);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
+    rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
+    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_logw = true;
+    h->have_steps = h->cfg.keep_ray_steps != 0;
+    h->update_idx++;
+    h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
+    h->timings[1] = 0.0;
+    h->timings[2] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_QUERY]);
+    h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
+    h->ray_ms = h->timings[3];
+    return MCL_OK;
+}
+
+int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!h->have_logw) return MCL_ERR_NOT_READY;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_scalars, &global_max_logw, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc = weight_stats(h, true, h->d_scalars);
+    if (rc) return rc;
+    return fetch_scalars(h);
+}
+
+int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5])
+{
+    if (!h || !global_sums) return MCL_ERR_INVALID_ARG;
+    for (int i = 0; i < 5; ++i) h->global_sums[i] = global_sums[i];
+    return MCL_OK;
+}
+
+int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset)
+{
+    if (!h || !d_q || !d_cdf || n <= 0) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    size_t need = (size_t)n / mcl::kScanTile + 2;
+    if (need > h->blocktot_capacity) {   // spine scratch is sized for cap; grow it for gathered arrays
+        dfree(h->d_blocktot);
+        HIPCHK(h, hipMalloc(&h->d_blocktot, need * 8));
+        h->blocktot_capacity = need;
+    }
+    int rc = scan_weights(h, d_q, d_cdf, n, offset, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+}  // extern "C"

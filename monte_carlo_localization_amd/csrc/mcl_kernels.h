@@ -1,0 +1,627 @@
+// mcl_kernels.h — the HIP kernels of the particle-filter update (gfx950 / CDNA4, wave64).
+//
+//   K5  k_scan_*            exact uint64 inclusive scan of fixed-point weights (resample CDF)
+//   K6+K1+K2 k_resample_motion   threshold -> CDF search -> parent gather -> motion + noise
+//   K3  k_rays<MODE>        fused ray cast + beam-model log-likelihood  (the dominant kernel)
+//   K4  k_reduce_max / k_weights / k_final_*   max-subtracted weights, fixed-point weights, sums
+//   K7  (fused into k_weights) weighted pose sums
+//
+// Reference rows: R = cpp:656-665, M = cpp:449-503, Q/C/E = cpp:506-650,
+// N = cpp:678-686, P = cpp:696-716.
+#pragma once
+#include "mcl_device_math.h"
+
+namespace mcl {
+
+// ------------------------------------------------------------------------------------------------
+// K5: inclusive scan of uint64.  2048 items per 256-thread block (8 per thread), three launches:
+// per-block totals -> single-block exclusive scan of the totals -> block-local scan + offset.
+// Integer addition is associative, so the result does not depend on N, the block size or the
+// number of GPUs the particle set is sharded over.
+// ------------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = (uint64_t)__shfl_up((long long)v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_partials(const uint64_t *__restrict__ q, int64_t n,
+                                                               uint64_t *__restrict__ block_tot)
+{
+    __shared__ uint64_t sm[kScanThreads / 64];
+    int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) s += q[base + k];
+    s = wave_sum_u64(s);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int i = 0; i < kScanThreads / 64; ++i) t += sm[i];
+        block_tot[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of nb block totals in place (single block of 1024 threads), adds `offset`.
+__global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *__restrict__ block_tot, int nb, uint64_t offset,
+                                                     uint64_t *__restrict__ grand_total)
+{
+    __shared__ uint64_t sm[16];
+    __shared__ uint64_t carry_s;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = offset;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        uint64_t v = (i < nb) ? block_tot[i] : 0;
+        uint64_t inc = wave_incl_scan_u64(v, lane);
+        if (lane == 63) sm[w] = inc;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += sm[k];
+        uint64_t carry = carry_s;
+        if (i < nb) block_tot[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && grand_total) *grand_total = carry_s;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__restrict__ q, int64_t n,
+                                                            const uint64_t *__restrict__ block_off,
+                                                            uint64_t *__restrict__ cdf)
+{
+    __shared__ uint64_t sm[kScanThreads / 64];
+    int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint64_t x = (base + k < n) ? q[base + k] : 0;
+        s += x;
+        v[k] = s;
+    }
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = wave_incl_scan_u64(s, lane);
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint64_t off = block_off[blockIdx.x] + inc - s;
+    for (int k = 0; k < w; ++k) off += sm[k];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) cdf[base + k] = off + v[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 + K1 + K2: one thread per child m (global child index child_first + m).
+//   threshold:   multinomial  k53_m * Q   vs   C_i * 2^53      (k53 = floor(u*2^53), u Philox or injected)
+//                systematic   (m*2^32 + k0) * Q   vs   C_i * (N_children * 2^32)
+//   idx = first i with C_i*lmul > rhs  (C inclusive)  == upper_bound; Q == 0 -> idx = 0 (reference:
+//   NaN CDF -> every draw returns 0).
+//   then row gather (cpp:664) and the motion model (cpp:474-502) with the three normals.
+// ------------------------------------------------------------------------------------------------
+struct ResampleArgs {
+    const double *px, *py, *pth;      // parents
+    const uint64_t *cdf;              // inclusive CDF over parents
+    int64_t n_parents;
+    uint64_t q_total;
+    double *cx, *cy, *cth;            // children out
+    int32_t *idx_out;                 // may be null
+    int64_t n_children;               // children handled by this launch
+    int64_t child_first;              // global index of child 0 of this launch
+    int64_t n_children_total;         // global number of children (systematic spacing)
+    int mode;                         // 0 multinomial, 1 systematic
+    const double *uniforms;           // injected uniforms (per local child) or null
+    const double *normals;            // injected normals n x 3 row-major or null
+    uint32_t seed_lo, seed_hi, update_idx, k0;
+    double dt, v, w;                  // motion scalars (cpp:452-471, computed on the host)
+    double disp_x, disp_y, disp_th;
+    int do_resample;                  // 0: children = parents (identity), used by tests
+    int do_motion;
+};
+
+__global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
+{
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.n_children) return;
+    uint64_t g = (uint64_t)(a.child_first + m);
+    int64_t idx = m;
+    if (a.do_resample) {
+        idx = 0;
+        if (a.q_total != 0) {
+            uint64_t lmul, r0, r1 = a.q_total;
+            if (a.mode == 0) {
+                uint64_t k53;
+                if (a.uniforms) {
+                    double u = a.uniforms[m];
+                    u = (u >= 0.0) ? u : 0.0;
+                    k53 = (uint64_t)(u * 9007199254740992.0);
+                    if (k53 > 9007199254740991ull) k53 = 9007199254740991ull;
+                } else {
+                    u32x4 o = philox4x32((uint32_t)g, a.update_idx, 2u, (uint32_t)(g >> 32), a.seed_lo, a.seed_hi);
+                    k53 = bits53(o.v[0], o.v[1]);
+                }
+                r0 = k53; lmul = 1ull << 53;
+            } else {
+                r0 = g * 4294967296ull + a.k0;
+                lmul = (uint64_t)a.n_children_total * 4294967296ull;
+            }
+            int64_t lo = 0, len = a.n_parents;
+            while (len > 0) {
+                int64_t half = len >> 1, mid = lo + half;
+                if (!mul_gt(a.cdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
+                else len = half;
+            }
+            idx = (lo >= a.n_parents) ? a.n_parents - 1 : lo;
+        }
+    }
+    if (a.idx_out) a.idx_out[m] = (int32_t)idx;
+    double x = a.px[idx], y = a.py[idx], th = a.pth[idx];
+    if (a.do_motion) {
+        double n0, n1, n2;
+        if (a.normals) {
+            n0 = a.normals[3 * m + 0]; n1 = a.normals[3 * m + 1]; n2 = a.normals[3 * m + 2];
+        } else {
+            const double TWO_M53 = 1.0 / 9007199254740992.0;
+            const double TWO_PI = 2.0 * 3.14159265358979323846;
+            u32x4 o = philox4x32((uint32_t)g, a.update_idx, 0u, (uint32_t)(g >> 32), a.seed_lo, a.seed_hi);
+            double u1 = (double)(bits53(o.v[0], o.v[1]) + 1) * TWO_M53;
+            double u2 = (double)bits53(o.v[2], o.v[3]) * TWO_M53;
+            double rad = sqrt(-2.0 * log(u1));
+            n0 = rad * cos(TWO_PI * u2);
+            n1 = rad * sin(TWO_PI * u2);
+            o = philox4x32((uint32_t)g, a.update_idx, 1u, (uint32_t)(g >> 32), a.seed_lo, a.seed_hi);
+            u1 = (double)(bits53(o.v[0], o.v[1]) + 1) * TWO_M53;
+            u2 = (double)bits53(o.v[2], o.v[3]) * TWO_M53;
+            rad = sqrt(-2.0 * log(u1));
+            n2 = rad * cos(TWO_PI * u2);
+        }
+        double nx, ny, nth;
+        if (fabs(a.w) < 1e-6) {                       // cpp:480-484
+            nx = x + a.v * a.dt * cos(th);
+            ny = y + a.v * a.dt * sin(th);
+            nth = th;
+        } else {                                      // cpp:485-493
+            double radius = a.v / a.w;
+            double dth = a.w * a.dt;
+            nx = x + radius * (sin(th + dth) - sin(th));
+            ny = y - radius * (cos(th + dth) - cos(th));
+            nth = th + dth;
+        }
+        nx += n0 * a.disp_x;                          // cpp:496-498
+        ny += n1 * a.disp_y;
+        nth += n2 * a.disp_th;
+        nth = normalize_angle(nth);                   // cpp:501
+        x = nx; y = ny; th = nth;
+    }
+    a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
+}
+
+// per-update transposed log table: Lt[d * bpad + j] = L[obs_idx[j] * (P+1) + d]
+__global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int bpad, int tw,
+                           float *__restrict__ Lt)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int d = blockIdx.y;
+    if (j >= bpad) return;
+    float v = 0.f;
+    if (j < B) v = L[(size_t)obs_idx[j] * tw + d];
+    Lt[(size_t)d * bpad + j] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: ray cast + likelihood.
+// ------------------------------------------------------------------------------------------------
+struct RayArgs {
+    const double *x, *y, *th;      // particles (this launch's)
+    int64_t n;
+    int B, bpad, P;
+    const double2 *beam_cs;        // (cos a_j, sin a_j) of (double)angle_f32[j], host fp64
+    const float *beam_angle;       // float angles (MARCH path uses theta + (double)angle)
+    const float *Lt;               // (P+1) x bpad
+    double *logw;                  // out
+    uint8_t *steps;                // out N*B or null
+    // map
+    const int8_t *grid; int W, H;
+    double res, ox, oy;
+    const uint8_t *dist;           // padded distance field Hp x Wps bytes (0 = stop), cap 255
+    int Wp, Hp, Wps;
+    int tw_cells;                  // LDS window side (multiple of 8)
+    unsigned long long *counters;  // [0] exact-fallback rays, [1] particles off-window, [2] probes
+    int force_exact;
+};
+
+// literal restatement of cast_ray (cpp:611-650) on the int8 grid; returns the step index
+// (0..P-1) or P for "no hit within MAX_RANGE_PX samples".
+__device__ __forceinline__ int march_exact(const RayArgs &a, double x, double y, double angle)
+{
+    double dx = cos(angle) * a.res;
+    double dy = sin(angle) * a.res;
+    double cx = x, cy = y;
+    for (int step = 0; step < a.P; ++step) {
+        cx += dx;
+        cy += dy;
+        int gx = (int)((cx - a.ox) / a.res);
+        int gy = (int)((cy - a.oy) / a.res);
+        if (gx < 0 || gx >= a.W || gy < 0 || gy >= a.H) return step;
+        if (a.grid[(size_t)gy * a.W + gx] > 50) return step;
+    }
+    return a.P;
+}
+
+constexpr int kRayThreads = 1024;
+constexpr int kRayWaves = kRayThreads / 64;
+// fixed-point extraction: t = p + kMagic puts floor(p)+2^19 in the low 20 bits of the high dword
+// and the fraction (2^-32 units, biased by +4) in the low dword.  lo < kGuard  <=>  p is within
+// ~2^-30 px of a cell boundary  ->  the lane re-does the ray with march_exact.
+constexpr double kMagic = 1572864.0 + 0x1p-30;   // 1.5 * 2^20 + 2^-30
+constexpr uint32_t kGuard = 8u;
+constexpr int kCellBase = 1 << 19;
+
+// MODE 1: literal march for every ray.  MODE 2: empty-space skipping.
+template <int MODE>
+__global__ __launch_bounds__(kRayThreads) void k_rays(RayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // contiguous slice of particles for this workgroup
+    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
+    const int64_t p_begin = (int64_t)blockIdx.x * per;
+    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
+
+    unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0;
+    int wx0 = 0, wy0 = 0;
+    const int TW = a.tw_cells;
+    const int strideB = TW >> 1;
+
+    if (MODE == 2) {
+        // ---- window placement: centred on the mean padded-pixel position of this slice ----
+        double *red = reinterpret_cast<double *>(lds_raw);   // scratch, overwritten by the window later
+        double sx = 0.0, sy = 0.0;
+        for (int64_t i = p_begin + threadIdx.x; i < p_end; i += kRayThreads) {
+            double gx = (a.x[i] - a.ox) / a.res, gy = (a.y[i] - a.oy) / a.res;
+            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
+        __syncthreads();
+        double mx = 0.0, my = 0.0;
+        for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
+        int64_t cntp = p_end - p_begin;
+        if (cntp > 0) { mx /= (double)cntp; my /= (double)cntp; }
+        // padded coordinate = global + 1
+        wx0 = (((int)floor(mx) + 1 - TW / 2)) & ~7;
+        wy0 = (int)floor(my) + 1 - TW / 2;
+        __syncthreads();
+        // ---- load the window: 8 cells (8 bytes of the distance field) -> one 32-bit word ----
+        uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw);
+        const int wpr = TW >> 3;                 // words per row
+        const int nwords = wpr * TW;
+        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
+            int row = wi / wpr, cw = wi - row * wpr;
+            int gy = wy0 + row, gx = wx0 + cw * 8;
+            uint32_t word = 0;
+            if (gy >= 0 && gy < a.Hp && gx >= 0 && gx < a.Wps) {
+                uint64_t b8 = *reinterpret_cast<const uint64_t *>(a.dist + (size_t)gy * a.Wps + gx);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t d = (uint32_t)(b8 >> (8 * k)) & 0xFFu;
+                    d = d > 15u ? 15u : d;
+                    word |= d << (4 * k);
+                }
+            }
+            win[wi] = word;
+        }
+        __syncthreads();
+    }
+
+    for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
+        const double x = a.x[i], y = a.y[i], th = a.th[i];
+        double acc = 0.0;
+        if (MODE == 1) {
+            for (int j0 = 0; j0 < a.B; j0 += 64) {
+                int j = j0 + lane;
+                if (j < a.B) {
+                    int r = march_exact(a, x, y, th + (double)a.beam_angle[j]);   // cpp:533
+                    acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                    if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                    cnt_probe += (r < a.P) ? (r + 1) : a.P;
+                }
+            }
+        } else {
+            double sth, cth;
+            sincos(th, &sth, &cth);
+            const double gpx = (x - a.ox) / a.res;        // global pixel coordinate of the particle
+            const double gpy = (y - a.oy) / a.res;
+            const double wpx = gpx - (double)(wx0 - 1);   // window-relative padded coordinate
+            const double wpy = gpy - (double)(wy0 - 1);
+            const double reach = (double)(a.P + 2);
+            const bool inwin = (wpx - reach >= 0.0) && (wpx + reach < (double)TW) &&
+                               (wpy - reach >= 0.0) && (wpy + reach < (double)TW);
+            // outside the window the same algorithm runs on the global byte field, in padded
+            // global coordinates shifted by 2^18 so that the magic add sees positive values
+            const bool sane = (gpx > -200000.0) && (gpx < 200000.0) && (gpy > -200000.0) && (gpy < 200000.0);
+            const double p0x = inwin ? (wpx + kMagic) : ((gpx + 1.0 + 262144.0) + kMagic);
+            const double p0y = inwin ? (wpy + kMagic) : ((gpy + 1.0 + 262144.0) + kMagic);
+            const int base = inwin ? kCellBase : (kCellBase + 262144);
+            const unsigned char *ldsb = lds_raw;
+            if (!inwin && lane == 0) ++cnt_off;
+            // the particle's own cell gives a first skip shared by all its beams
+            uint32_t amb0 = 0;
+            int s0 = 1;
+            if (inwin || sane) {
+                uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+                int cx = (__double2hiint(p0x) & 0xFFFFF) - base;
+                int cy = (__double2hiint(p0y) & 0xFFFFF) - base;
+                amb0 = lox < loy ? lox : loy;
+                int d;
+                if (inwin) {
+                    uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
+                    d = (byte >> ((cx & 1) * 4)) & 15;
+                } else {
+                    d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+                }
+                s0 = d > 1 ? d : 1;
+            }
+            for (int j0 = 0; j0 < a.B; j0 += 64) {
+                int j = j0 + lane;
+                if (j < a.B) {
+                    double2 cs = a.beam_cs[j];
+                    double ux = cth * cs.x - sth * cs.y;      // cos(theta + a_j)
+                    double uy = sth * cs.x + cth * cs.y;      // sin(theta + a_j)
+                    int s = s0, r = a.P;
+                    uint32_t amb = amb0;
+                    unsigned np = 0;
+                    if (inwin) {
+                        while (true) {
+                            double sd = (double)s;
+                            double tx = __builtin_fma(sd, ux, p0x);
+                            double ty = __builtin_fma(sd, uy, p0y);
+                            uint32_t lox = (uint32_t)__double2loint(tx), loy = (uint32_t)__double2loint(ty);
+                            int cx = (__double2hiint(tx) & 0xFFFFF) - kCellBase;
+                            int cy = (__double2hiint(ty) & 0xFFFFF) - kCellBase;
+                            uint32_t mlo = lox < loy ? lox : loy;
+                            amb = amb < mlo ? amb : mlo;
+                            uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
+                            int d = (byte >> ((cx & 1) * 4)) & 15;
+                            ++np;
+                            if (d == 0) { r = s - 1; break; }
+                            s += d;
+                            if (s > a.P) break;
+                        }
+                    } else if (sane && s <= a.P) {
+                        while (true) {
+                            double sd = (double)s;
+                            double tx = __builtin_fma(sd, ux, p0x);
+                            double ty = __builtin_fma(sd, uy, p0y);
+                            uint32_t lox = (uint32_t)__double2loint(tx), loy = (uint32_t)__double2loint(ty);
+                            int cx = (__double2hiint(tx) & 0xFFFFF) - base;
+                            int cy = (__double2hiint(ty) & 0xFFFFF) - base;
+                            uint32_t mlo = lox < loy ? lox : loy;
+                            amb = amb < mlo ? amb : mlo;
+                            int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp)
+                                        ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+                            ++np;
+                            if (d == 0) { r = s - 1; break; }
+                            s += d;
+                            if (s > a.P) break;
+                        }
+                    }
+                    if (amb < kGuard || a.force_exact || !(inwin || sane)) {
+                        r = march_exact(a, x, y, th + (double)a.beam_angle[j]);
+                        ++cnt_exact;
+                    }
+                    acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                    if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                    cnt_probe += np;
+                }
+            }
+        }
+        acc = wave_sum(acc);          // exact: fp32 table entries, |sum| < 2^13
+        if (lane == 0) a.logw[i] = acc;
+    }
+    if (a.counters) {
+        cnt_exact = wave_sum_u64(cnt_exact);
+        cnt_off = wave_sum_u64(cnt_off);
+        cnt_probe = wave_sum_u64(cnt_probe);
+        if (lane == 0) {
+            if (cnt_exact) atomicAdd(&a.counters[0], cnt_exact);
+            if (cnt_off) atomicAdd(&a.counters[1], cnt_off);
+            if (cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
+        }
+    }
+}
+
+// product-as-reference weights (cpp:566-578) from materialised steps: one thread per particle,
+// sequential double product in beam order, then pow(.,inv_squash).
+__global__ void k_product_weights(const uint8_t *__restrict__ steps, const int32_t *__restrict__ obs_idx, int64_t n, int B,
+                                  const double *__restrict__ table /* col-major (P+1)^2 */, int tw, double inv_squash,
+                                  double *__restrict__ w_out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double w = 1.0;
+    for (int j = 0; j < B; ++j) w *= table[(size_t)steps[(size_t)i * B + j] * tw + obs_idx[j]];
+    w_out[i] = pow(w, inv_squash);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 / K7: reductions.  Fixed grid (kRedBlocks x 256) with grid-stride loops and a fixed-order
+// final pass: deterministic for a given N.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;
+constexpr int kRedThreads = 256;
+
+__global__ __launch_bounds__(kRedThreads) void k_reduce_max(const double *__restrict__ v, int64_t n, double *__restrict__ part)
+{
+    __shared__ double sm[kRedThreads / 64];
+    double m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRedThreads)
+        m = fmax(m, v[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kRedThreads / 64; ++k) m = fmax(m, sm[k]);
+        part[blockIdx.x] = m;
+    }
+}
+__global__ __launch_bounds__(kRedThreads) void k_final_max(const double *__restrict__ part, int nb, double *__restrict__ out)
+{
+    __shared__ double sm[kRedThreads / 64];
+    double m = -INFINITY;
+    for (int i = threadIdx.x; i < nb; i += kRedThreads) m = fmax(m, part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kRedThreads / 64; ++k) m = fmax(m, sm[k]);
+        out[0] = m;
+    }
+}
+
+// from_log: w = det_exp(logw - *maxp) (max element -> exactly 1); else w given, scaled by 1/ *maxp
+// for the fixed-point value only.  Writes w, q and per-block partials
+// [sum w, sum q (bits), sum w x, sum w y, sum w sin, sum w cos].
+__global__ __launch_bounds__(kRedThreads) void k_weights(const double *__restrict__ logw_or_w, int from_log,
+                                                        const double *__restrict__ maxp, const double *__restrict__ x,
+                                                        const double *__restrict__ y, const double *__restrict__ th, int64_t n,
+                                                        double *__restrict__ w_out, uint64_t *__restrict__ q_out,
+                                                        double *__restrict__ part /* gridDim.x * 8 */)
+{
+    __shared__ double sm[kRedThreads / 64][6];
+    const double mx = *maxp;
+    double sw = 0, swx = 0, swy = 0, sws = 0, swc = 0;
+    uint64_t sq = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRedThreads) {
+        double w, wq;
+        if (from_log) { w = det_exp(logw_or_w[i] - mx); wq = w; }
+        else {
+            w = logw_or_w[i];
+            wq = (mx > 0.0 && w > 0.0) ? (w / mx) : 0.0;
+        }
+        uint64_t q = (uint64_t)(wq * kWeightScale);
+        w_out[i] = w;
+        q_out[i] = q;
+        double s, c;
+        sincos(th[i], &s, &c);
+        sw += w; sq += q; swx += w * x[i]; swy += w * y[i]; sws += w * s; swc += w * c;
+    }
+    sw = wave_sum(sw); swx = wave_sum(swx); swy = wave_sum(swy); sws = wave_sum(sws); swc = wave_sum(swc);
+    sq = wave_sum_u64(sq);
+    int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wv][0] = sw; sm[wv][1] = __longlong_as_double((long long)sq); sm[wv][2] = swx; sm[wv][3] = swy; sm[wv][4] = sws; sm[wv][5] = swc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tq = 0;
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < kRedThreads / 64; ++k) {
+            t[0] += sm[k][0]; tq += (uint64_t)__double_as_longlong(sm[k][1]);
+            t[2] += sm[k][2]; t[3] += sm[k][3]; t[4] += sm[k][4]; t[5] += sm[k][5];
+        }
+        double *p = part + (size_t)blockIdx.x * 8;
+        p[0] = t[0]; p[1] = __longlong_as_double((long long)tq); p[2] = t[2]; p[3] = t[3]; p[4] = t[4]; p[5] = t[5];
+    }
+}
+// scalars[1..6] = fixed-order sums of the partials (scalars[0] = max stays)
+__global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__restrict__ part, int nb, double *__restrict__ scalars)
+{
+    __shared__ double sm[kRedThreads / 64][6];
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t tq = 0;
+    for (int i = threadIdx.x; i < nb; i += kRedThreads) {
+        const double *p = part + (size_t)i * 8;
+        t[0] += p[0]; tq += (uint64_t)__double_as_longlong(p[1]); t[2] += p[2]; t[3] += p[3]; t[4] += p[4]; t[5] += p[5];
+    }
+    t[0] = wave_sum(t[0]); t[2] = wave_sum(t[2]); t[3] = wave_sum(t[3]); t[4] = wave_sum(t[4]); t[5] = wave_sum(t[5]);
+    tq = wave_sum_u64(tq);
+    int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wv][0] = t[0]; sm[wv][1] = __longlong_as_double((long long)tq); sm[wv][2] = t[2]; sm[wv][3] = t[3]; sm[wv][4] = t[4]; sm[wv][5] = t[5];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r[6] = {0, 0, 0, 0, 0, 0};
+        uint64_t rq = 0;
+        for (int k = 0; k < kRedThreads / 64; ++k) {
+            r[0] += sm[k][0]; rq += (uint64_t)__double_as_longlong(sm[k][1]);
+            r[2] += sm[k][2]; r[3] += sm[k][3]; r[4] += sm[k][4]; r[5] += sm[k][5];
+        }
+        scalars[1] = r[0]; scalars[2] = __longlong_as_double((long long)rq);
+        scalars[3] = r[2]; scalars[4] = r[3]; scalars[5] = r[4]; scalars[6] = r[5];
+    }
+}
+
+// out[i] = w[i] / sum (sum > 0) else w[i]   (cpp:680-686)
+__global__ void k_normalized(const double *__restrict__ w, int64_t n, double sum, double *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (sum > 0.0) ? (w[i] / sum) : w[i];
+}
+
+// column sums for particles_.colwise().mean() (cpp:904); part = gridDim.x * 4 doubles
+__global__ __launch_bounds__(kRedThreads) void k_colsum(const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ th, int64_t n, double *__restrict__ part)
+{
+    __shared__ double sm[kRedThreads / 64][3];
+    double a = 0, b = 0, c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRedThreads) {
+        a += x[i]; b += y[i]; c += th[i];
+    }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[wv][0] = a; sm[wv][1] = b; sm[wv][2] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int k = 0; k < kRedThreads / 64; ++k) { t0 += sm[k][0]; t1 += sm[k][1]; t2 += sm[k][2]; }
+        part[blockIdx.x * 4 + 0] = t0; part[blockIdx.x * 4 + 1] = t1; part[blockIdx.x * 4 + 2] = t2;
+    }
+}
+
+// k draws from the current CDF (visualize, cpp:949-956): out k x 3 column-major
+__global__ void k_sample(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ th,
+                         const uint64_t *__restrict__ cdf, int64_t n, uint64_t q_total, const double *__restrict__ uniforms,
+                         uint32_t seed_lo, uint32_t seed_hi, uint32_t ctr, int k, double *__restrict__ out)
+{
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= k) return;
+    uint64_t k53;
+    if (uniforms) {
+        double u = uniforms[m];
+        u = (u >= 0.0) ? u : 0.0;
+        k53 = (uint64_t)(u * 9007199254740992.0);
+        if (k53 > 9007199254740991ull) k53 = 9007199254740991ull;
+    } else {
+        u32x4 o = philox4x32((uint32_t)m, ctr, 4u, 0u, seed_lo, seed_hi);
+        k53 = bits53(o.v[0], o.v[1]);
+    }
+    int64_t idx = 0;
+    if (q_total) {
+        int64_t lo = 0, len = n;
+        while (len > 0) {
+            int64_t half = len >> 1, mid = lo + half;
+            if (!mul_gt(cdf[mid], 1ull << 53, k53, q_total)) { lo = mid + 1; len = len - half - 1; }
+            else len = half;
+        }
+        idx = lo >= n ? n - 1 : lo;
+    }
+    out[m] = x[idx]; out[k + m] = y[idx]; out[2 * k + m] = th[idx];
+}
+
+}  // namespace mcl

@@ -1,0 +1,248 @@
+"""ctypes binding of the C ABI in include/mcl_hip_engine.h (libmcl_hip_engine.so).
+
+This is plumbing only: every numeric step runs in the HIP library.  There is no fallback — if the
+shared library is missing or no gfx950 device is visible the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcl_hip_engine.so")
+
+MCL_OK = 0
+RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
+WEIGHT_LOG, WEIGHT_PRODUCT = 0, 1
+RAYS_AUTO, RAYS_MARCH, RAYS_SKIP = 0, 1, 2
+BUF_X, BUF_Y, BUF_THETA, BUF_QWEIGHT, BUF_LOGW, BUF_SCALARS = range(6)
+
+EXPORTS = [
+    "mcl_abi_version", "mcl_default_config", "mcl_create", "mcl_destroy", "mcl_last_error", "mcl_set_map",
+    "mcl_get_max_range_px", "mcl_get_sensor_table", "mcl_set_beam_angles", "mcl_set_particles",
+    "mcl_get_particles", "mcl_get_weights", "mcl_sample_particles", "mcl_particle_mean", "mcl_update",
+    "mcl_sensor_update", "mcl_expected_pose", "mcl_get_stage_timings", "mcl_get_resample_indices",
+    "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
+    "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("max_particles", C.c_int64), ("device", C.c_int32), ("seed", C.c_uint64), ("max_range_m", C.c_double),
+        ("z_hit", C.c_double), ("z_short", C.c_double), ("z_max", C.c_double), ("z_rand", C.c_double),
+        ("sigma_hit", C.c_double), ("squash_factor", C.c_double), ("motion_dispersion_x", C.c_double),
+        ("motion_dispersion_y", C.c_double), ("motion_dispersion_theta", C.c_double), ("resample_mode", C.c_int32),
+        ("weight_mode", C.c_int32), ("ray_kernel", C.c_int32), ("keep_ray_steps", C.c_int32),
+        ("debug_force_exact", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libmcl_hip_engine.so (built by __graft_entry__.build()); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.mcl_last_error.restype = C.c_char_p
+        lib.mcl_last_error.argtypes = [C.c_void_p]
+        lib.mcl_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        lib.mcl_destroy.argtypes = [C.c_void_p]
+        lib.mcl_destroy.restype = None
+        lib.mcl_default_config.argtypes = [C.POINTER(Config)]
+        lib.mcl_default_config.restype = None
+        _lib = lib
+    return _lib
+
+
+def default_config(**over) -> Config:
+    cfg = Config()
+    load_library().mcl_default_config(C.byref(cfg))
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+class Engine:
+    """One engine == one GPU == one particle shard."""
+
+    def __init__(self, cfg: Config | None = None, **over):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        if cfg is not None:
+            for k, v in over.items():
+                setattr(self.cfg, k, v)
+        h = C.c_void_p()
+        rc = self.lib.mcl_create(C.byref(self.cfg), C.byref(h))
+        if rc != MCL_OK:
+            raise EngineError(f"mcl_create rc={rc}: {self.lib.mcl_last_error(None).decode()}")
+        self._h = h
+        self.n = 0
+        self.n_beams = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mcl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != MCL_OK:
+            raise EngineError(f"{what} rc={rc}: {self.lib.mcl_last_error(self._h).decode()}")
+
+    # -- map / beams
+    def set_map(self, grid, resolution, origin_x, origin_y):
+        g = _c(grid, np.int8)
+        H, W = g.shape
+        self._chk(self.lib.mcl_set_map(self._h, _p(g), C.c_uint32(W), C.c_uint32(H), C.c_float(np.float32(resolution)),
+                                       C.c_double(origin_x), C.c_double(origin_y)), "mcl_set_map")
+
+    @property
+    def max_range_px(self) -> int:
+        v = C.c_int32()
+        self._chk(self.lib.mcl_get_max_range_px(self._h, C.byref(v)), "mcl_get_max_range_px")
+        return v.value
+
+    def sensor_table(self):
+        P = self.max_range_px
+        out = np.empty((P + 1) * (P + 1), np.float64)
+        self._chk(self.lib.mcl_get_sensor_table(self._h, _p(out), C.c_size_t(out.size)), "mcl_get_sensor_table")
+        return out.reshape(P + 1, P + 1)      # [d, r]
+
+    def set_beam_angles(self, angles):
+        a = _c(angles, np.float32)
+        self._chk(self.lib.mcl_set_beam_angles(self._h, _p(a), C.c_int32(a.size)), "mcl_set_beam_angles")
+        self.n_beams = a.size
+
+    # -- particles
+    def set_particles(self, xyz_colmajor, weights):
+        p = _c(xyz_colmajor, np.float64)
+        assert p.ndim == 2 and p.shape[0] == 3
+        w = _c(weights, np.float64)
+        n = p.shape[1]
+        assert w.size == n
+        self._chk(self.lib.mcl_set_particles(self._h, _p(p), _p(w), C.c_int64(n)), "mcl_set_particles")
+        self.n = n
+
+    def get_particles(self):
+        out = np.empty((3, self.n), np.float64)
+        self._chk(self.lib.mcl_get_particles(self._h, _p(out), C.c_int64(self.n)), "mcl_get_particles")
+        return out
+
+    def get_weights(self):
+        out = np.empty(self.n, np.float64)
+        self._chk(self.lib.mcl_get_weights(self._h, _p(out), C.c_int64(self.n)), "mcl_get_weights")
+        return out
+
+    def sample_particles(self, k, uniforms=None):
+        u = _c(uniforms, np.float64)
+        out = np.empty((3, k), np.float64)
+        self._chk(self.lib.mcl_sample_particles(self._h, C.c_int32(k), _p(u), _p(out)), "mcl_sample_particles")
+        return out
+
+    def particle_mean(self):
+        out = np.empty(3)
+        self._chk(self.lib.mcl_particle_mean(self._h, _p(out)), "mcl_particle_mean")
+        return out
+
+    # -- update
+    def update(self, action, obs, normals=None, uniforms=None):
+        a = _c(action, np.float64)
+        o = _c(obs, np.float32)
+        nrm, u = _c(normals, np.float64), _c(uniforms, np.float64)
+        if nrm is not None:
+            assert nrm.size == 3 * self.n
+        if u is not None:
+            assert u.size == self.n
+        self._chk(self.lib.mcl_update(self._h, _p(a), _p(o), C.c_int32(o.size), _p(nrm), _p(u)), "mcl_update")
+
+    def sensor_update(self, obs):
+        o = _c(obs, np.float32)
+        self._chk(self.lib.mcl_sensor_update(self._h, _p(o), C.c_int32(o.size)), "mcl_sensor_update")
+
+    def expected_pose(self):
+        out = np.empty(3)
+        self._chk(self.lib.mcl_expected_pose(self._h, _p(out)), "mcl_expected_pose")
+        return out
+
+    def stage_timings(self):
+        out = np.empty(6)
+        self._chk(self.lib.mcl_get_stage_timings(self._h, _p(out)), "mcl_get_stage_timings")
+        return out
+
+    # -- diagnostics
+    def resample_indices(self):
+        out = np.empty(self.n, np.int32)
+        self._chk(self.lib.mcl_get_resample_indices(self._h, _p(out), C.c_int64(self.n)), "mcl_get_resample_indices")
+        return out
+
+    def ray_steps(self):
+        out = np.empty(self.n * self.n_beams, np.uint8)
+        self._chk(self.lib.mcl_get_ray_steps(self._h, _p(out), C.c_size_t(out.size)), "mcl_get_ray_steps")
+        return out.reshape(self.n, self.n_beams)
+
+    def log_weights(self):
+        out = np.empty(self.n, np.float64)
+        self._chk(self.lib.mcl_get_log_weights(self._h, _p(out), C.c_int64(self.n)), "mcl_get_log_weights")
+        return out
+
+    def counters(self):
+        out = np.zeros(4, np.uint64)
+        self._chk(self.lib.mcl_get_counters(self._h, _p(out)), "mcl_get_counters")
+        return dict(exact_fallback_rays=int(out[0]), off_window_particles=int(out[1]), probes=int(out[2]))
+
+    def ray_kernel_ms(self):
+        v = C.c_double()
+        self._chk(self.lib.mcl_get_ray_kernel_ms(self._h, C.byref(v)), "mcl_get_ray_kernel_ms")
+        return v.value
+
+    # -- multi-GPU staging (raw device pointers as ints)
+    def device_ptr(self, which) -> int:
+        p = C.c_void_p()
+        self._chk(self.lib.mcl_device_ptr(self._h, C.c_int32(which), C.byref(p)), "mcl_device_ptr")
+        return int(p.value or 0)
+
+    def stage_propagate(self, d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action, obs):
+        a = _c(action, np.float64)
+        o = _c(obs, np.float32)
+        self._chk(self.lib.mcl_stage_propagate(self._h, C.c_void_p(d_px), C.c_void_p(d_py), C.c_void_p(d_pth),
+                                               C.c_void_p(d_cdf), C.c_int64(n_parents), C.c_uint64(q_total),
+                                               C.c_int64(child_first), C.c_int64(n_children_total), _p(a), _p(o),
+                                               C.c_int32(o.size)), "mcl_stage_propagate")
+
+    def stage_weights(self, global_max):
+        self._chk(self.lib.mcl_stage_weights(self._h, C.c_double(global_max)), "mcl_stage_weights")
+
+    def stage_finish(self, sums5):
+        s = _c(sums5, np.float64)
+        self._chk(self.lib.mcl_stage_finish(self._h, _p(s)), "mcl_stage_finish")
+
+    def scan_weights(self, d_q, d_cdf, n, offset=0):
+        self._chk(self.lib.mcl_scan_weights(self._h, C.c_void_p(d_q), C.c_void_p(d_cdf), C.c_int64(n),
+                                            C.c_uint64(offset)), "mcl_scan_weights")

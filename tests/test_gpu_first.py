@@ -1,0 +1,40 @@
+"""First end-to-end GPU parity checks through the C ABI (expanded in the other test_gpu_* files)."""
+import numpy as np
+import pytest
+
+from conftest import make_engine, tracking_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kernel", ["march", "skip", "skip_forced_exact"])
+def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_oracle, kernel):
+    om = spielberg_oracle
+    ang = orc.beam_angles(angle_step=9)       # 121 beams
+    scan, _ = orc.cast_many(om, np.zeros(ang.size), np.zeros(ang.size), ang.astype(np.float64))
+    rng = np.random.default_rng(1)
+    N = 777
+    p = tracking_cloud(rng, N)
+    cfg = dict(keep_ray_steps=1)
+    cfg["ray_kernel"] = engine_mod.RAYS_MARCH if kernel == "march" else engine_mod.RAYS_SKIP
+    if kernel == "skip_forced_exact":
+        cfg["debug_force_exact"] = 1
+    e = make_engine(engine_mod, spielberg, ang, N, **cfg)
+    e.set_particles(p, np.full(N, 1.0 / N))
+    e.sensor_update(scan)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    oi = orc.obs_index(scan, om)
+    logw, steps, probes = orc.eng_log_weights(om, p, ang, oi, L, want_steps=True)
+    got = e.ray_steps()
+    assert np.array_equal(got, steps), f"{(got != steps).sum()} of {steps.size} ray steps differ"
+    assert np.array_equal(e.log_weights(), logw)          # exact fp64 sums of fp32 entries
+    c = e.counters()
+    if kernel == "skip_forced_exact":
+        assert c["exact_fallback_rays"] == N * ang.size
+    if kernel == "march":
+        assert c["probes"] == probes
+
+
+def test_full_step_matches_reference_chain(orc, engine_mod, spielberg, spielberg_oracle):
+    import __graft_entry__ as g
+    g.smoke()
