@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — MCL updates/s as particle*beam/s on synthetic scans (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full update (resample -> motion -> ray cast + likelihood -> normalise -> expected
+pose) of the 4M-particle x 1081-beam Spielberg workload (BASELINE.json configs[2]; SURVEY.md §8(d)
+inputs), per GPU.  N > 1 is launched by torch.distributed.run, one rank per GPU; particles are
+sharded 4M per GPU (weak scaling, configs[4] at N=8) with RCCL all-gather / all-reduce per update
+(monte_carlo_localization_amd/dist.py).  Inputs are resident in HBM before the timed region; the
+per-update host->device traffic is the 1081-float scan and the 3-double action only.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_rays) against the HBM peak
+with the ALGORITHMIC bytes of SURVEY.md §8(d): per ray S-bar grid probes of 1 B (as the reference
+reads them, cpp:642) + one 4 B table entry (cpp:576), per particle 24 B state in + 8 B log-weight
+out; its duration is measured inside the engine with HIP events on the engine's own stream.
+`cpu_baseline` times the CPU oracle's as-reference step (same materialised arrays and the same
+`omp parallel for schedule(dynamic)` ray loop as cpp:593) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_PER_GPU = 4 * 1024 * 1024
+ACTION = (0.05, 0.0, 0.01)
+TRUE_POSE = (0.0, 0.0, 0.0)
+
+
+def cpu_baseline(m, ang, scan, budget_s=20.0):
+    """Oracle (kind 'port'): BASELINE config #1 = 4000 particles x 1081 beams, all host cores,
+    plus the 1-thread figure because the reference's chunk-1 dynamic schedule does not scale
+    (SURVEY D11).  Also returns S-bar, the mean number of grid probes per ray of the fixed-step
+    march on this input."""
+    from oracle import oracle as orc
+    om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
+    n = 4000
+    T = orc.sensor_table(om.max_range_px)
+    s = orc.RefStream(42)
+    p, w = orc.init_particles_pose(s, TRUE_POSE, n)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    out = {}
+    for label, thr, share in (("all", cores, 0.7), ("one", 1, 0.3)):
+        orc.omp_threads(thr)
+        pp, ww = p.copy(), w.copy()
+        times, t_start = [], time.perf_counter()
+        while True:
+            u, nrm = s.uniforms(n), s.normals(3 * n).reshape(n, 3)
+            t0 = time.perf_counter()
+            r = orc.mcl_step(om, pp, ww, ACTION, ang, scan, T, u, nrm, use_omp=True, want_steps=False)
+            times.append(time.perf_counter() - t0)
+            pp, ww = r["particles"], np.full(n, 1.0 / n)   # the reference product underflows at 1081 beams (D4)
+            if len(times) >= 2 and time.perf_counter() - t_start > budget_s * share:
+                break
+        out[label] = (n * ang.size / float(np.median(times)), len(times))
+    orc.omp_threads(cores)
+    L = orc.eng_log_table(T)
+    _, _, probes = orc.eng_log_weights(om, p, ang, orc.obs_index(scan, om), L)
+    sbar = probes / float(n * ang.size)
+    base = {"value": out["all"][0], "unit": "particle*beam/s", "cores": cores, "kind": "port",
+            "sample": f"{out['all'][1]} updates of 4000 particles x {ang.size} beams (BASELINE config #1), "
+                      f"Spielberg_map, tracking-regime cloud, omp schedule(dynamic) as cpp:593",
+            "single_thread_value": out["one"][0]}
+    return base, sbar
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    from monte_carlo_localization_amd import engine, maps, synth
+
+    n = args.particles_per_gpu
+    m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
+    ang = synth.beam_angles()
+    B = ang.size
+    mode = engine.RESAMPLE_MULTINOMIAL if args.resample == "multinomial" else engine.RESAMPLE_SYSTEMATIC
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    e = engine.Engine(max_particles=n, device=local_rank, seed=42, resample_mode=mode)
+    e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+    e.set_beam_angles(ang)
+    scan = synth.scan_from_pose(e, m, ang, TRUE_POSE)
+    rng = np.random.default_rng(42 + rank)
+    p = synth.tracking_cloud(rng, n, TRUE_POSE)
+    e.set_particles(p, np.full(n, 1.0 / (n * world)))
+    del p
+
+    if world > 1:
+        from monte_carlo_localization_amd.dist import ShardedFilter
+        dev = torch.device("cuda", local_rank)
+        sf = ShardedFilter(e, n, dev)
+
+        def step():
+            sf.update(ACTION, scan)
+    else:
+        def step():
+            e.update(ACTION, scan)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ray_ms, probes = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ray_ms.append(e.ray_kernel_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    pose = sf.expected_pose() if world > 1 else e.expected_pose()
+    counters = e.counters()
+
+    if rank == 0:
+        ms = elapsed * 1e3 / args.steps
+        value = n * world * B / (elapsed / args.steps)
+        base, sbar = (None, 43.4)
+        if world == 1 and not args.no_cpu_baseline:
+            base, sbar = cpu_baseline(m, ang, scan)
+        k_ms = float(np.mean(ray_ms))
+        alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per k_rays launch (one GPU's shard)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_rays_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MCL updates/sec (particle*beam/s) at 4M particles x 1081 beams",
+            "value": value, "unit": "particle*beam/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n} particles/GPU x {B} beams, Spielberg_map (2000x2000 @ 0.05796), "
+                                   f"tracking-regime cloud N((0,0,0),(0.5 m,0.5 m,0.4 rad)), action {ACTION}, "
+                                   f"stock sensor/motion params, {args.resample} resampling, Philox seed 42",
+                       "particles_total": n * world, "beams": B,
+                       "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_rays<2>",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar,
+                         "note": "algorithmic (effective) bytes per SURVEY 8(d); real HBM traffic is far lower because "
+                                 "the grid window lives in LDS and the kernel skips empty space; it is VALU/LDS-bound"},
+            "cpu_baseline": base,
+            "pose": [float(v) for v in pose],
+            "counters_last_update": counters,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    e.close()
+
+
+if __name__ == "__main__":
+    main()

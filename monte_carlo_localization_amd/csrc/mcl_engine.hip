@@ -759,6 +759,30 @@ int mcl_device_ptr(mcl_engine_t *h, int32_t which, void **p)
     return MCL_OK;
 }
 
+int mcl_export_state(mcl_engine_t *h, double *d_x, double *d_y, double *d_theta, uint64_t *d_q)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t nb = (size_t)h->N * 8;
+    const int c = h->cur;
+    if (d_x) HIPCHK(h, hipMemcpyAsync(d_x, h->d_x[c], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (d_y) HIPCHK(h, hipMemcpyAsync(d_y, h->d_y[c], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (d_theta) HIPCHK(h, hipMemcpyAsync(d_theta, h->d_th[c], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (d_q) HIPCHK(h, hipMemcpyAsync(d_q, h->d_q, nb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_get_scalars(mcl_engine_t *h, double out[8])
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
 int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
                         int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
                         const double action[3], const float *obs, int32_t n_beams)

@@ -25,7 +25,8 @@ EXPORTS = [
     "mcl_get_particles", "mcl_get_weights", "mcl_sample_particles", "mcl_particle_mean", "mcl_update",
     "mcl_sensor_update", "mcl_expected_pose", "mcl_get_stage_timings", "mcl_get_resample_indices",
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
-    "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights",
+    "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
+    "mcl_get_scalars",
 ]
 
 
@@ -227,6 +228,15 @@ class Engine:
         p = C.c_void_p()
         self._chk(self.lib.mcl_device_ptr(self._h, C.c_int32(which), C.byref(p)), "mcl_device_ptr")
         return int(p.value or 0)
+
+    def export_state(self, d_x=0, d_y=0, d_th=0, d_q=0):
+        self._chk(self.lib.mcl_export_state(self._h, C.c_void_p(d_x or None), C.c_void_p(d_y or None),
+                                            C.c_void_p(d_th or None), C.c_void_p(d_q or None)), "mcl_export_state")
+
+    def scalars(self):
+        out = np.empty(8)
+        self._chk(self.lib.mcl_get_scalars(self._h, _p(out)), "mcl_get_scalars")
+        return out
 
     def stage_propagate(self, d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action, obs):
         a = _c(action, np.float64)
