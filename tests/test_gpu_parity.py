@@ -1,0 +1,306 @@
+"""GPU parity tests proper: every stage of the update through the C ABI (ctypes -> libmcl_hip_engine.so)
+against the CPU oracle and the committed golden fixtures.
+
+Tolerances: integer/index results bit-exact; sensor table bit-exact (fp64);
+log-weights bit-exact vs the engine-spec restatement; weights rtol 1e-5 vs the reference product
+(<= 121 beams) and vs the log-domain restatement; motion output rtol 1e-13 (device libm vs glibc);
+pose within 1 cm / 0.5 deg under identical injected randomness.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_engine, tracking_cloud
+
+pytestmark = pytest.mark.gpu
+
+ACTION = (0.05, 0.0, 0.01)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+# ------------------------------------------------------------------------------------------- T / H1
+@pytest.mark.parametrize("mapname,P", [("spielberg", 207), ("sibal1", 239)])
+def test_sensor_table_bit_exact(request, orc, engine_mod, mapname, P):
+    m = request.getfixturevalue(mapname)
+    e = make_engine(engine_mod, m, orc.beam_angles(angle_step=18), 8)
+    assert e.max_range_px == P
+    T = e.sensor_table()
+    assert np.array_equal(T, orc.sensor_table(P))
+    assert np.array_equal(T, load(f"g1_sensor_table_P{P}.npz")["table"])
+
+
+# ------------------------------------------------------------------------------------------- C (G2)
+@pytest.mark.parametrize("name", ["Spielberg_map", "sibal1"])
+@pytest.mark.parametrize("kernel", ["march", "skip"])
+def test_cast_ray_golden(orc, engine_mod, maps_mod, name, kernel):
+    """One particle per golden ray, a single beam at angle 0: step index == fixture (incl. rays that
+    start outside the map, inside walls, within a cell of the lower/left edge, axis-aligned)."""
+    m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{name}.npz"))
+    z = load(f"g2_cast_ray_{name}.npz")
+    n = z["x"].size
+    rk = engine_mod.RAYS_MARCH if kernel == "march" else engine_mod.RAYS_SKIP
+    e = make_engine(engine_mod, m, np.zeros(1, np.float32), n, keep_ray_steps=1, ray_kernel=rk)
+    e.set_particles(np.stack([z["x"], z["y"], z["theta"]]), np.full(n, 1.0 / n))
+    e.sensor_update(np.array([1.0], np.float32))
+    assert np.array_equal(e.ray_steps()[:, 0].astype(np.int16), z["steps"])
+
+
+def test_cast_ray_many_beams_scattered_particles(orc, engine_mod, sibal1, sibal1_oracle):
+    """Particles scattered over the whole (small) map and beyond it: exercises the off-window path."""
+    om = sibal1_oracle
+    ang = orc.beam_angles(angle_step=5)
+    rng = np.random.default_rng(11)
+    n = 600
+    p = np.stack([om.origin_x + rng.uniform(-2, 20, n), om.origin_y + rng.uniform(-2, 11, n), rng.uniform(-np.pi, np.pi, n)])
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    obs = np.full(ang.size, 3.0, np.float32)
+    e.sensor_update(obs)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+    assert np.array_equal(e.ray_steps(), steps)
+    assert np.array_equal(e.log_weights(), logw)
+
+
+def test_global_regime_uses_fallback_and_stays_exact(orc, engine_mod, spielberg, spielberg_oracle):
+    from monte_carlo_localization_amd import synth
+    om = spielberg_oracle
+    ang = orc.beam_angles(angle_step=40)
+    rng = np.random.default_rng(12)
+    n = 2048
+    p = synth.global_cloud(rng, spielberg, n)
+    e = make_engine(engine_mod, spielberg, ang, n, keep_ray_steps=1)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    obs = load("scan_Spielberg_map_origin.npz")["ranges"][::40].copy()
+    e.sensor_update(obs)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+    assert np.array_equal(e.ray_steps(), steps)
+    assert np.array_equal(e.log_weights(), logw)
+    assert e.counters()["off_window_particles"] > 0
+
+
+def test_nonfinite_particles_do_not_hang_or_crash(orc, engine_mod, sibal1):
+    ang = orc.beam_angles(angle_step=60)
+    n = 64
+    p = np.zeros((3, n))
+    p[0, 0] = np.nan; p[1, 1] = np.inf; p[0, 2] = -np.inf; p[2, 3] = np.nan; p[0, 4] = 1e300; p[2, 5] = 1e300
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(np.full(ang.size, 2.0, np.float32))
+    assert e.ray_steps().shape == (n, ang.size)
+    e.update(ACTION, np.full(ang.size, 2.0, np.float32))     # motion + normalize_angle on garbage must terminate
+
+
+# ------------------------------------------------------------------------------------------- E / D4
+@pytest.mark.parametrize("B", [61, 121])
+def test_weights_match_reference_product(orc, engine_mod, spielberg, spielberg_oracle, B):
+    z = load(f"g3_mcl_step_B{B}.npz")
+    n = z["particles_out"].shape[1]
+    for mode, rtol in ((engine_mod.WEIGHT_LOG, 1e-5), (engine_mod.WEIGHT_PRODUCT, 1e-12)):
+        e = make_engine(engine_mod, spielberg, z["angles"], n, keep_ray_steps=1, weight_mode=mode)
+        e.set_particles(z["particles_out"], np.full(n, 1.0 / n))
+        e.sensor_update(z["obs"])
+        assert np.array_equal(e.ray_steps(), z["steps"])
+        np.testing.assert_allclose(e.get_weights(), z["weights_out"], rtol=rtol, atol=0)
+        pose = e.expected_pose()
+        np.testing.assert_allclose(pose, z["pose"], rtol=0, atol=1e-6)
+
+
+def test_underflow_witness_1081_beams(orc, engine_mod, spielberg):
+    """G4 / SURVEY D4: product mode reproduces the reference's all-zero weights bit for bit; log mode
+    stays finite and equals the log-domain restatement."""
+    z = load("g4_underflow_B1081.npz")
+    ang = orc.beam_angles()
+    obs = load("scan_Spielberg_map_origin.npz")["ranges"]
+    n = z["particles_out"].shape[1]
+    e = make_engine(engine_mod, spielberg, ang, n, keep_ray_steps=1, weight_mode=engine_mod.WEIGHT_PRODUCT)
+    e.set_particles(z["particles_out"], np.full(n, 1.0 / n))
+    e.sensor_update(obs)
+    assert np.array_equal(e.ray_steps(), z["steps"])
+    assert np.array_equal(e.get_weights(), z["ref_weights"]) and e.get_weights().sum() == 0.0
+    # and the next resample degenerates exactly like the reference: every index 0
+    e.update(ACTION, obs, normals=np.zeros((n, 3)), uniforms=np.linspace(0.01, 0.99, n))
+    assert (e.resample_indices() == 0).all()
+    e2 = make_engine(engine_mod, spielberg, ang, n, keep_ray_steps=1)
+    e2.set_particles(z["particles_out"], np.full(n, 1.0 / n))
+    e2.sensor_update(obs)
+    assert np.array_equal(e2.log_weights(), z["eng_logw"])
+    w, q, mx = orc.eng_weights_from_log(z["eng_logw"])
+    np.testing.assert_allclose(e2.get_weights(), w / w.sum(), rtol=1e-13)
+    assert np.isfinite(e2.get_weights()).all() and abs(e2.get_weights().sum() - 1.0) < 1e-12
+
+
+def test_observation_edge_cases(orc, engine_mod, sibal1, sibal1_oracle):
+    """G6: obs = +inf, > max range, NaN, negative."""
+    om = sibal1_oracle
+    ang = orc.beam_angles(angle_step=120)
+    obs = np.array([np.inf, 100.0, np.nan, -3.0, 0.0, 5.0, 11.99, 12.0, 0.024, 0.026], np.float32)[: ang.size]
+    assert list(orc.obs_index(obs, om)[:5]) == [om.max_range_px, om.max_range_px, 0, 0, 0]
+    rng = np.random.default_rng(4)
+    n = 200
+    p = tracking_cloud(rng, n, (2.0, 2.0, 0.3), (0.3, 0.3, 0.3))
+    e = make_engine(engine_mod, sibal1, ang, n)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(obs)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    logw, _, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L)
+    assert np.array_equal(e.log_weights(), logw)
+
+
+# ------------------------------------------------------------------------------------------- M
+@pytest.mark.parametrize("action", [(0.05, 0.0, 0.01), (0.3, 0.0, -0.2), (0.0005, 0.0, 0.0005), (0.0, 0.0, 0.05),
+                                    (-0.08, 0.0, 0.0)])
+def test_motion_model_injected_normals(orc, engine_mod, sibal1, action):
+    rng = np.random.default_rng(7)
+    n = 1000
+    p = tracking_cloud(rng, n, (2.0, 2.0, 3.0), (0.3, 0.3, 0.5))
+    nrm = rng.normal(size=(n, 3))
+    nrm[:10, 2] = 20.0          # forces several +-2pi wraps
+    ang = orc.beam_angles(angle_step=120)
+    e = make_engine(engine_mod, sibal1, ang, n)
+    w = np.zeros(n); w[:] = 1.0 / n
+    e.set_particles(p, w)
+    u = (np.arange(n) + 0.5) / n            # uniform weights + these uniforms -> identity resample
+    e.update(action, np.full(ang.size, 2.0, np.float32), normals=nrm, uniforms=u)
+    assert np.array_equal(e.resample_indices(), np.arange(n))
+    want = orc.motion_model(p, action, nrm)
+    got = e.get_particles()
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13)
+    assert (np.abs(got[2]) <= np.pi + 1e-12).all()
+
+
+# ------------------------------------------------------------------------------------------- R
+@pytest.mark.parametrize("B", [61, 121])
+def test_full_step_golden_g3(orc, engine_mod, spielberg, B):
+    z = load(f"g3_mcl_step_B{B}.npz")
+    n = z["particles_in"].shape[1]
+    e = make_engine(engine_mod, spielberg, z["angles"], n, keep_ray_steps=1)
+    e.set_particles(z["particles_in"], z["weights_in"])
+    np.testing.assert_allclose(e.get_weights(), z["weights_in"], rtol=1e-14)
+    e.update(z["action"], z["obs"], normals=z["normals"], uniforms=z["uniforms"])
+    assert np.array_equal(e.resample_indices(), z["idx"])                       # bit-exact parents
+    np.testing.assert_allclose(e.get_particles(), z["particles_out"], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(e.ray_steps(), z["steps"])                            # bit-exact ray steps
+    np.testing.assert_allclose(e.get_weights(), z["weights_out"], rtol=1e-5)
+    pose = e.expected_pose()
+    assert abs(pose[0] - z["pose"][0]) < 1e-6 and abs(pose[1] - z["pose"][1]) < 1e-6 and abs(pose[2] - z["pose"][2]) < 1e-6
+    t = e.stage_timings()
+    assert t.shape == (6,) and t[5] > 0 and t[3] > 0
+
+
+def test_resample_indices_bit_exact_native_philox(orc, engine_mod, sibal1):
+    """No injection: Philox uniforms + exact integer CDF, multinomial and systematic, vs the scalar
+    restatement (orc_eng_*), from arbitrary weights."""
+    rng = np.random.default_rng(9)
+    n = 5000
+    ang = orc.beam_angles(angle_step=120)
+    p = tracking_cloud(rng, n, (2.0, 2.0, 0.0), (0.2, 0.2, 0.2))
+    w = rng.random(n) ** 6
+    w[rng.integers(0, n, 300)] = 0.0
+    obs = np.full(ang.size, 2.0, np.float32)
+    for mode in (engine_mod.RESAMPLE_MULTINOMIAL, engine_mod.RESAMPLE_SYSTEMATIC):
+        e = make_engine(engine_mod, sibal1, ang, n, seed=0xDEADBEEF1234, resample_mode=mode)
+        e.set_particles(p, w)
+        q = orc.eng_quantize_weights(w)
+        for upd in range(2):
+            if upd == 1:
+                _, q, _ = orc.eng_weights_from_log(e.log_weights())
+            e.update(ACTION, obs)
+            if mode == engine_mod.RESAMPLE_MULTINOMIAL:
+                want = orc.eng_resample_indices(q, 0, k53=orc.eng_philox_k53(0xDEADBEEF1234, upd, 0, n))
+            else:
+                want = orc.eng_resample_indices(q, 1, k0=orc.eng_philox_k0(0xDEADBEEF1234, upd))
+            assert np.array_equal(e.resample_indices(), want), (mode, upd)
+
+
+def test_native_philox_motion_noise(orc, engine_mod, sibal1):
+    rng = np.random.default_rng(10)
+    n = 4096
+    ang = orc.beam_angles(angle_step=120)
+    p = tracking_cloud(rng, n, (2.0, 2.0, 0.0), (0.2, 0.2, 0.2))
+    e = make_engine(engine_mod, sibal1, ang, n, seed=77)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.update(ACTION, np.full(ang.size, 2.0, np.float32))
+    idx = e.resample_indices()
+    nrm = orc.eng_philox_normals(77, 0, 0, n)
+    want = orc.motion_model(p[:, idx], ACTION, nrm)
+    np.testing.assert_allclose(e.get_particles(), want, rtol=1e-12, atol=1e-12)
+    assert abs(nrm.mean()) < 0.05 and abs(nrm.std() - 1.0) < 0.05
+
+
+def test_all_zero_weights_resample_like_reference(orc, engine_mod, sibal1):
+    n = 256
+    ang = orc.beam_angles(angle_step=120)
+    rng = np.random.default_rng(2)
+    p = tracking_cloud(rng, n, (2.0, 2.0, 0.0), (0.2, 0.2, 0.2))
+    e = make_engine(engine_mod, sibal1, ang, n)
+    e.set_particles(p, np.zeros(n))
+    u = rng.random(n)
+    e.update(ACTION, np.full(ang.size, 2.0, np.float32), normals=np.zeros((n, 3)), uniforms=u)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(e.resample_indices(), orc.resample_indices(np.zeros(n), u))   # all 0
+
+
+# ------------------------------------------------------------------------------------------- D (G5)
+def test_closed_loop_trajectory_g5(orc, engine_mod, spielberg, spielberg_oracle):
+    """30 updates, N=2000, B=61, identical injected randomness: pose within 1 cm / 0.5 deg of the
+    reference chain at every step (BASELINE.json north_star)."""
+    z = load("g5_trajectory_N2000_B61.npz")
+    om = spielberg_oracle
+    a = orc.beam_angles(angle_step=18)
+    s = orc.RefStream(42)
+    N = 2000
+    p, w = orc.init_particles_pose(s, (0.0, 0.0, 0.0), N)
+    e = make_engine(engine_mod, spielberg, a, N)
+    e.set_particles(p, w)
+    worst = np.zeros(3)
+    for k in range(30):
+        pose_true = z["truth"][k]
+        obs, _ = orc.cast_many(om, np.full(a.size, pose_true[0]), np.full(a.size, pose_true[1]), pose_true[2] + a.astype(np.float64))
+        u, nrm = s.uniforms(N), s.normals(3 * N).reshape(N, 3)
+        e.update(ACTION, obs, normals=nrm, uniforms=u)
+        worst = np.maximum(worst, np.abs(e.expected_pose() - z["poses"][k]))
+    assert worst[0] < 0.01 and worst[1] < 0.01 and worst[2] < np.deg2rad(0.5), worst
+    np.testing.assert_allclose(e.get_particles(), z["final_particles"], rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------- misc ABI
+def test_sample_particles_and_mean(orc, engine_mod, sibal1):
+    rng = np.random.default_rng(3)
+    n = 3000
+    ang = orc.beam_angles(angle_step=120)
+    p = tracking_cloud(rng, n, (2.0, 2.0, 0.0), (0.2, 0.2, 0.2))
+    w = rng.random(n)
+    e = make_engine(engine_mod, sibal1, ang, n)
+    e.set_particles(p, w)
+    u = rng.random(60)
+    got = e.sample_particles(60, u)                                   # visualize(): cpp:949-956
+    idx = orc.resample_indices(w, u) if False else orc.eng_resample_indices(
+        orc.eng_quantize_weights(w), 0, n_children=60, k53=np.floor(u * 2.0 ** 53).astype(np.uint64))
+    assert np.array_equal(got, p[:, idx])
+    np.testing.assert_allclose(e.particle_mean(), p.mean(axis=1), rtol=1e-12)
+    np.testing.assert_allclose(e.get_weights(), w / w.sum(), rtol=1e-13)
+    np.testing.assert_allclose(e.expected_pose(), orc.expected_pose(p, w / w.sum()), atol=1e-12)
+    assert e.sample_particles(60).shape == (3, 60)
+
+
+def test_error_codes(orc, engine_mod, sibal1):
+    e = engine_mod.Engine(max_particles=16)
+    with pytest.raises(engine_mod.EngineError):       # nothing set yet
+        e.sensor_update(np.zeros(4, np.float32))
+    e.set_map(sibal1.data, sibal1.resolution, sibal1.origin_x, sibal1.origin_y)
+    e.set_beam_angles(np.zeros(4, np.float32))
+    with pytest.raises(engine_mod.EngineError):       # too many particles
+        e.set_particles(np.zeros((3, 17)), np.ones(17))
+    e.set_particles(np.zeros((3, 16)), np.ones(16))
+    with pytest.raises(engine_mod.EngineError):       # beam count mismatch
+        e.sensor_update(np.zeros(5, np.float32))
+    with pytest.raises(engine_mod.EngineError):       # steps not kept
+        e.ray_steps()
+    with pytest.raises(engine_mod.EngineError):       # invalid resolution (cpp:236-240)
+        e.set_map(sibal1.data, 0.0, 0.0, 0.0)
