@@ -77,8 +77,11 @@ typedef struct {
     int32_t weight_mode;            /* mcl_weight_mode                                         */
     int32_t ray_kernel;             /* mcl_ray_kernel                                          */
     int32_t keep_ray_steps;         /* !=0: keep the N*B uint8 step indices of the last update */
-    int32_t debug_force_exact;      /* !=0: treat every ray as "ambiguous" (tests the fallback)*/
-    int32_t reserved[7];
+    int32_t debug_force_exact;      /* 1: every ray takes the literal-march fallback (level 3);
+                                       2: every ray takes the fp64 skipping loop (level 2)     */
+    int32_t debug_count_probes;     /* !=0: tally examined grid probes (counters[2]); slower   */
+    int32_t rays_per_lane;          /* SKIP kernel: independent rays in flight per lane (1..4); 0 = default */
+    int32_t reserved[5];
 } mcl_config_t;
 
 /* Fills *cfg with the reference's defaults (config/mcl_config.yaml:6-40, cpp:23-47). */
@@ -142,8 +145,9 @@ int mcl_get_stage_timings(const mcl_engine_t *h, double ms[6]);
 int mcl_get_resample_indices(mcl_engine_t *h, int32_t *idx, int64_t n);      /* parents of last update */
 int mcl_get_ray_steps(mcl_engine_t *h, uint8_t *steps, size_t n);            /* N*B, needs keep_ray_steps */
 int mcl_get_log_weights(mcl_engine_t *h, double *logw, int64_t n);           /* un-normalised log w   */
-/* counters of the last update: [0] rays resolved by the exact fallback, [1] particles that did
- * not fit the LDS window (global-memory path), [2] grid probes examined, [3] reserved */
+/* counters of the last update: [0] rays resolved by the literal-march fallback (level 3),
+ * [1] particles that did not fit the LDS window (global-memory path), [2] grid probes examined
+ * (only with debug_count_probes), [3] rays re-run by the fp64 loop (level 2) */
 int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
 /* duration (ms) of the dominant kernel (ray cast + likelihood) in the last update, measured
  * with HIP events on the engine's own stream */

@@ -255,11 +255,23 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     int mode = h->cfg.ray_kernel == MCL_RAYS_MARCH ? 1 : 2;
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
+    const bool count = h->cfg.debug_count_probes != 0;
+    size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
+    dim3 g(grid), b(mcl::kRayThreads);
+    int R = h->cfg.rays_per_lane;
+    if (R <= 0) R = 1;   // measured on MI355X: the kernel is VALU-issue-bound, extra chains per lane only add idle slots
     if (mode == 1) {
-        hipLaunchKernelGGL(mcl::k_rays<1>, dim3(grid), dim3(mcl::kRayThreads), 0, h->stream, a);
+        if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
+        else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
+    } else if (count) {
+        hipLaunchKernelGGL((mcl::k_rays_skip<1, true>), g, b, lds, h->stream, a);
     } else {
-        size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
-        hipLaunchKernelGGL(mcl::k_rays<2>, dim3(grid), dim3(mcl::kRayThreads), lds, h->stream, a);
+        switch (R) {
+        case 1: hipLaunchKernelGGL((mcl::k_rays_skip<1, false>), g, b, lds, h->stream, a); break;
+        case 2: hipLaunchKernelGGL((mcl::k_rays_skip<2, false>), g, b, lds, h->stream, a); break;
+        case 3: hipLaunchKernelGGL((mcl::k_rays_skip<3, false>), g, b, lds, h->stream, a); break;
+        default: hipLaunchKernelGGL((mcl::k_rays_skip<4, false>), g, b, lds, h->stream, a); break;
+        }
     }
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
@@ -384,7 +396,11 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_inject, nb * 4));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
     CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
-    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef CRT
     *out = h;
     return MCL_OK;

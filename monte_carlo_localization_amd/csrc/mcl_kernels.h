@@ -263,33 +263,112 @@ __device__ __forceinline__ int march_exact(const RayArgs &a, double x, double y,
 
 constexpr int kRayThreads = 1024;
 constexpr int kRayWaves = kRayThreads / 64;
-// fixed-point extraction: t = p + kMagic puts floor(p)+2^19 in the low 20 bits of the high dword
-// and the fraction (2^-32 units, biased by +4) in the low dword.  lo < kGuard  <=>  p is within
-// ~2^-30 px of a cell boundary  ->  the lane re-does the ray with march_exact.
+
+// ---- K3a: literal march for every ray (MCL_RAYS_MARCH): the on-device ground truth -------------
+template <bool COUNT>
+__global__ __launch_bounds__(kRayThreads) void k_rays_march(RayArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
+    const int64_t p_begin = (int64_t)blockIdx.x * per;
+    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
+    unsigned long long cnt_probe = 0;
+    for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
+        const double x = a.x[i], y = a.y[i], th = a.th[i];
+        double acc = 0.0;
+        for (int j0 = 0; j0 < a.B; j0 += 64) {
+            int j = j0 + lane;
+            if (j < a.B) {
+                int r = march_exact(a, x, y, th + (double)a.beam_angle[j]);   // cpp:533
+                acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                if (COUNT) cnt_probe += (r < a.P) ? (r + 1) : a.P;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) a.logw[i] = acc;
+    }
+    if (COUNT && a.counters) {
+        cnt_probe = wave_sum_u64(cnt_probe);
+        if (lane == 0 && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
+    }
+}
+
+// ---- K3b: empty-space skipping on the same sample lattice (MCL_RAYS_SKIP) ----------------------
+//
+// A ray's k-th sample is p0 + k*u (pixel units).  D(c) = Chebyshev distance from cell c to the
+// nearest "stop" cell (occupied or outside the map).  Successive samples are at most one cell apart
+// in either axis, so if sample k lies in cell c the samples k+1 .. k+D(c)-1 cannot be stops: the
+// march may jump from k to k+max(D(c),1) and still returns exactly the first stop sample of the
+// fixed-step march (cpp:622-647).  Three precision levels keep that claim bit-exact:
+//   level 1  32-bit fixed point (22 fractional bits) on the LDS window: T = P0 + s*U with
+//            P0 = rint(p0*2^22), U = rint(u*2^22)  =>  |T - exact| <= (1+s)/2 <= 128 units (s <= 255);
+//            a sample with fraction in [kG1, 2^22-kG1) units is in the cell the reference computes;
+//   level 2  rays with any level-1 sample closer than that to a cell boundary are re-run with fp64
+//            positions (error ~1 unit of 2^-32 px, guard 2^-30 px);
+//   level 3  what is still ambiguous, and every ray of a particle whose own cell is ambiguous,
+//            is re-run by march_exact (the literal restatement).
+// The reference's own accumulated rounding (207 sequential fp64 adds at |x| ~ 85 m) stays below
+// 3e-11 px, far inside the level-2 guard, which is what makes the equality with cpp:611-650 hold.
+constexpr int kFx = 22;
+constexpr uint32_t kG1 = 132u;
+// fp64 fixed-point extraction: t = p + kMagic puts floor(p)+2^19 in the low 20 bits of the high
+// dword and the fraction (2^-32 units, biased by +4) in the low dword; lo < kGuard <=> within 2^-30 px.
 constexpr double kMagic = 1572864.0 + 0x1p-30;   // 1.5 * 2^20 + 2^-30
 constexpr uint32_t kGuard = 8u;
 constexpr int kCellBase = 1 << 19;
 
-// MODE 1: literal march for every ray.  MODE 2: empty-space skipping.
-template <int MODE>
-__global__ __launch_bounds__(kRayThreads) void k_rays(RayArgs a)
+// fp64 skipping march of one ray, on the LDS nibble window (LDSWIN) or on the global byte field.
+template <bool LDSWIN, bool COUNT>
+__device__ __forceinline__ int trace_fp64(const RayArgs &a, const unsigned char *ldsb, int strideB, int base, double p0x, double p0y,
+                                          double ux, double uy, int s0, uint32_t &amb, unsigned &np)
+{
+    int s = s0, r = a.P;
+    if (s > a.P) return r;
+    while (true) {
+        double sd = (double)s;
+        double tx = __builtin_fma(sd, ux, p0x);
+        double ty = __builtin_fma(sd, uy, p0y);
+        uint32_t lox = (uint32_t)__double2loint(tx), loy = (uint32_t)__double2loint(ty);
+        int cx = (__double2hiint(tx) & 0xFFFFF) - base;
+        int cy = (__double2hiint(ty) & 0xFFFFF) - base;
+        uint32_t mlo = lox < loy ? lox : loy;
+        amb = amb < mlo ? amb : mlo;
+        int d;
+        if (LDSWIN) {
+            uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
+            d = (byte >> ((cx & 1) * 4)) & 15;
+        } else {
+            d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+        }
+        if (COUNT) ++np;
+        if (d == 0) { r = s - 1; break; }
+        s += d;
+        if (s > a.P) break;
+    }
+    return r;
+}
+
+// R = rays per lane per pass (independent dependency chains that hide the LDS round trip).
+template <int R, bool COUNT>
+__global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // contiguous slice of particles for this workgroup
     const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
     const int64_t p_begin = (int64_t)blockIdx.x * per;
     const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
 
-    unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0;
-    int wx0 = 0, wy0 = 0;
+    unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0, cnt_l2 = 0;
     const int TW = a.tw_cells;
     const int strideB = TW >> 1;
-
-    if (MODE == 2) {
+    const int wpr = TW >> 3;                 // 32-bit words (8 cells) per window row
+    int wx0, wy0;
+    {
         // ---- window placement: centred on the mean padded-pixel position of this slice ----
-        double *red = reinterpret_cast<double *>(lds_raw);   // scratch, overwritten by the window later
+        double *red = reinterpret_cast<double *>(lds_raw);   // scratch, overwritten by the window below
         double sx = 0.0, sy = 0.0;
         for (int64_t i = p_begin + threadIdx.x; i < p_end; i += kRayThreads) {
             double gx = (a.x[i] - a.ox) / a.res, gy = (a.y[i] - a.oy) / a.res;
@@ -302,13 +381,11 @@ __global__ __launch_bounds__(kRayThreads) void k_rays(RayArgs a)
         for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
         int64_t cntp = p_end - p_begin;
         if (cntp > 0) { mx /= (double)cntp; my /= (double)cntp; }
-        // padded coordinate = global + 1
-        wx0 = (((int)floor(mx) + 1 - TW / 2)) & ~7;
+        wx0 = (((int)floor(mx) + 1 - TW / 2)) & ~7;      // padded coordinate = global + 1
         wy0 = (int)floor(my) + 1 - TW / 2;
         __syncthreads();
         // ---- load the window: 8 cells (8 bytes of the distance field) -> one 32-bit word ----
         uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw);
-        const int wpr = TW >> 3;                 // words per row
         const int nwords = wpr * TW;
         for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
             int row = wi / wpr, cw = wi - row * wpr;
@@ -327,106 +404,136 @@ __global__ __launch_bounds__(kRayThreads) void k_rays(RayArgs a)
         }
         __syncthreads();
     }
+    const uint32_t *ldsw = reinterpret_cast<const uint32_t *>(lds_raw);
+    const unsigned char *ldsb = lds_raw;
+    const int ngroups = (a.B + 64 * R - 1) / (64 * R);
 
     for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
         const double x = a.x[i], y = a.y[i], th = a.th[i];
         double acc = 0.0;
-        if (MODE == 1) {
-            for (int j0 = 0; j0 < a.B; j0 += 64) {
-                int j = j0 + lane;
-                if (j < a.B) {
-                    int r = march_exact(a, x, y, th + (double)a.beam_angle[j]);   // cpp:533
-                    acc += (double)a.Lt[(size_t)r * a.bpad + j];
-                    if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
-                    cnt_probe += (r < a.P) ? (r + 1) : a.P;
+        double sth, cth;
+        sincos(th, &sth, &cth);
+        const double gpx = (x - a.ox) / a.res;        // global pixel coordinate of the particle
+        const double gpy = (y - a.oy) / a.res;
+        const double wpx = gpx - (double)(wx0 - 1);   // window-relative padded coordinate
+        const double wpy = gpy - (double)(wy0 - 1);
+        const double reach = (double)(a.P + 2);
+        const bool inwin = (wpx - reach >= 0.0) && (wpx + reach < (double)TW) && (wpy - reach >= 0.0) && (wpy + reach < (double)TW);
+        // outside the window the same algorithm runs on the global byte field, in padded global
+        // coordinates shifted by 2^18 so that the magic add sees positive values
+        const bool sane = (gpx > -200000.0) && (gpx < 200000.0) && (gpy > -200000.0) && (gpy < 200000.0);
+        const double p0x = inwin ? (wpx + kMagic) : ((gpx + 1.0 + 262144.0) + kMagic);
+        const double p0y = inwin ? (wpy + kMagic) : ((gpy + 1.0 + 262144.0) + kMagic);
+        const int base = inwin ? kCellBase : (kCellBase + 262144);
+        if (!inwin && lane == 0) ++cnt_off;
+        // the particle's own cell gives a first skip shared by all its beams
+        uint32_t amb0 = 0;
+        int s0 = 1;
+        if (inwin || sane) {
+            uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+            int cx = (__double2hiint(p0x) & 0xFFFFF) - base;
+            int cy = (__double2hiint(p0y) & 0xFFFFF) - base;
+            amb0 = lox < loy ? lox : loy;
+            int d;
+            if (inwin) {
+                uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
+                d = (byte >> ((cx & 1) * 4)) & 15;
+            } else {
+                d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+            }
+            s0 = d > 1 ? d : 1;
+        }
+
+        if (inwin) {
+            const uint32_t P0x = (uint32_t)(long long)rint(wpx * 4194304.0);
+            const uint32_t P0y = (uint32_t)(long long)rint(wpy * 4194304.0);
+            const uint32_t g0 = (amb0 < kGuard) ? 0u : 0xFFFFFFFFu;
+            const int s_start = s0 <= a.P ? s0 : a.P;
+            for (int grp = 0; grp < ngroups; ++grp) {
+                int Ux[R], Uy[R], s[R];
+                uint32_t g[R], d[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    int j = (grp * R + k) * 64 + lane;
+                    bool valid = j < a.B;
+                    double2 cs = a.beam_cs[valid ? j : 0];
+                    double ux = cth * cs.x - sth * cs.y;      // cos(theta + a_j)
+                    double uy = sth * cs.x + cth * cs.y;      // sin(theta + a_j)
+                    Ux[k] = valid ? (int)rint(ux * 4194304.0) : 0;
+                    Uy[k] = valid ? (int)rint(uy * 4194304.0) : 0;
+                    s[k] = valid ? s_start : a.P;             // an invalid slot re-probes the own cell once
+                    g[k] = g0;
+                    d[k] = 0;
+                }
+                // ---- level 1: all R rays of the lane advance together; a finished ray keeps
+                //      re-probing its last sample (same state every trip) until the wave is done ----
+                bool any;
+                do {
+                    any = false;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        uint32_t Tx = (uint32_t)(__mul24(s[k], Ux[k]) + (int)P0x);
+                        uint32_t Ty = (uint32_t)(__mul24(s[k], Uy[k]) + (int)P0y);
+                        uint32_t gx = (Tx << (32 - kFx)) + (kG1 << (32 - kFx));
+                        uint32_t gy = (Ty << (32 - kFx)) + (kG1 << (32 - kFx));
+                        uint32_t gm = gx < gy ? gx : gy;
+                        g[k] = g[k] < gm ? g[k] : gm;
+                        uint32_t t = Tx >> (kFx - 2);
+                        uint32_t word = ldsw[__umul24(Ty >> kFx, (uint32_t)wpr) + (t >> 5)];
+                        d[k] = (word >> (t & 28u)) & 15u;
+                        int s1 = s[k] + (int)d[k];
+                        bool go = (d[k] != 0u) && (s1 <= a.P);
+                        s[k] = go ? s1 : s[k];
+                        any |= go;
+                        if (COUNT) cnt_probe += go ? 1 : 0;
+                    }
+                } while (any);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    int j = (grp * R + k) * 64 + lane;
+                    if (j < a.B) {
+                        int r = (d[k] == 0u) ? s[k] - 1 : a.P;
+                        if (COUNT) ++cnt_probe;
+                        if (g[k] < ((2u * kG1) << (32 - kFx)) || a.force_exact) {
+                            // ---- level 2 (and 3): rare, everything recomputed from scratch ----
+                            double2 cs = a.beam_cs[j];
+                            double ux = cth * cs.x - sth * cs.y;
+                            double uy = sth * cs.x + cth * cs.y;
+                            uint32_t amb = amb0;
+                            unsigned np = 0;
+                            r = trace_fp64<true, COUNT>(a, ldsb, strideB, kCellBase, p0x, p0y, ux, uy, s0, amb, np);
+                            ++cnt_l2;
+                            if (COUNT) cnt_probe += np;
+                            if (amb < kGuard || a.force_exact == 1) {
+                                r = march_exact(a, x, y, th + (double)a.beam_angle[j]);
+                                ++cnt_exact;
+                            }
+                        }
+                        acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                        if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                    }
                 }
             }
         } else {
-            double sth, cth;
-            sincos(th, &sth, &cth);
-            const double gpx = (x - a.ox) / a.res;        // global pixel coordinate of the particle
-            const double gpy = (y - a.oy) / a.res;
-            const double wpx = gpx - (double)(wx0 - 1);   // window-relative padded coordinate
-            const double wpy = gpy - (double)(wy0 - 1);
-            const double reach = (double)(a.P + 2);
-            const bool inwin = (wpx - reach >= 0.0) && (wpx + reach < (double)TW) &&
-                               (wpy - reach >= 0.0) && (wpy + reach < (double)TW);
-            // outside the window the same algorithm runs on the global byte field, in padded
-            // global coordinates shifted by 2^18 so that the magic add sees positive values
-            const bool sane = (gpx > -200000.0) && (gpx < 200000.0) && (gpy > -200000.0) && (gpy < 200000.0);
-            const double p0x = inwin ? (wpx + kMagic) : ((gpx + 1.0 + 262144.0) + kMagic);
-            const double p0y = inwin ? (wpy + kMagic) : ((gpy + 1.0 + 262144.0) + kMagic);
-            const int base = inwin ? kCellBase : (kCellBase + 262144);
-            const unsigned char *ldsb = lds_raw;
-            if (!inwin && lane == 0) ++cnt_off;
-            // the particle's own cell gives a first skip shared by all its beams
-            uint32_t amb0 = 0;
-            int s0 = 1;
-            if (inwin || sane) {
-                uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
-                int cx = (__double2hiint(p0x) & 0xFFFFF) - base;
-                int cy = (__double2hiint(p0y) & 0xFFFFF) - base;
-                amb0 = lox < loy ? lox : loy;
-                int d;
-                if (inwin) {
-                    uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
-                    d = (byte >> ((cx & 1) * 4)) & 15;
-                } else {
-                    d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
-                }
-                s0 = d > 1 ? d : 1;
-            }
             for (int j0 = 0; j0 < a.B; j0 += 64) {
                 int j = j0 + lane;
                 if (j < a.B) {
-                    double2 cs = a.beam_cs[j];
-                    double ux = cth * cs.x - sth * cs.y;      // cos(theta + a_j)
-                    double uy = sth * cs.x + cth * cs.y;      // sin(theta + a_j)
-                    int s = s0, r = a.P;
-                    uint32_t amb = amb0;
+                    int r = a.P;
                     unsigned np = 0;
-                    if (inwin) {
-                        while (true) {
-                            double sd = (double)s;
-                            double tx = __builtin_fma(sd, ux, p0x);
-                            double ty = __builtin_fma(sd, uy, p0y);
-                            uint32_t lox = (uint32_t)__double2loint(tx), loy = (uint32_t)__double2loint(ty);
-                            int cx = (__double2hiint(tx) & 0xFFFFF) - kCellBase;
-                            int cy = (__double2hiint(ty) & 0xFFFFF) - kCellBase;
-                            uint32_t mlo = lox < loy ? lox : loy;
-                            amb = amb < mlo ? amb : mlo;
-                            uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
-                            int d = (byte >> ((cx & 1) * 4)) & 15;
-                            ++np;
-                            if (d == 0) { r = s - 1; break; }
-                            s += d;
-                            if (s > a.P) break;
-                        }
-                    } else if (sane && s <= a.P) {
-                        while (true) {
-                            double sd = (double)s;
-                            double tx = __builtin_fma(sd, ux, p0x);
-                            double ty = __builtin_fma(sd, uy, p0y);
-                            uint32_t lox = (uint32_t)__double2loint(tx), loy = (uint32_t)__double2loint(ty);
-                            int cx = (__double2hiint(tx) & 0xFFFFF) - base;
-                            int cy = (__double2hiint(ty) & 0xFFFFF) - base;
-                            uint32_t mlo = lox < loy ? lox : loy;
-                            amb = amb < mlo ? amb : mlo;
-                            int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp)
-                                        ? a.dist[(size_t)cy * a.Wps + cx] : 0;
-                            ++np;
-                            if (d == 0) { r = s - 1; break; }
-                            s += d;
-                            if (s > a.P) break;
-                        }
+                    uint32_t amb = amb0;
+                    if (sane) {
+                        double2 cs = a.beam_cs[j];
+                        double ux = cth * cs.x - sth * cs.y;
+                        double uy = sth * cs.x + cth * cs.y;
+                        r = trace_fp64<false, COUNT>(a, ldsb, strideB, base, p0x, p0y, ux, uy, s0, amb, np);
                     }
-                    if (amb < kGuard || a.force_exact || !(inwin || sane)) {
+                    if (!sane || amb < kGuard || a.force_exact == 1) {
                         r = march_exact(a, x, y, th + (double)a.beam_angle[j]);
                         ++cnt_exact;
                     }
                     acc += (double)a.Lt[(size_t)r * a.bpad + j];
                     if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
-                    cnt_probe += np;
+                    if (COUNT) cnt_probe += np;
                 }
             }
         }
@@ -437,10 +544,12 @@ __global__ __launch_bounds__(kRayThreads) void k_rays(RayArgs a)
         cnt_exact = wave_sum_u64(cnt_exact);
         cnt_off = wave_sum_u64(cnt_off);
         cnt_probe = wave_sum_u64(cnt_probe);
+        cnt_l2 = wave_sum_u64(cnt_l2);
         if (lane == 0) {
             if (cnt_exact) atomicAdd(&a.counters[0], cnt_exact);
             if (cnt_off) atomicAdd(&a.counters[1], cnt_off);
             if (cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
+            if (cnt_l2) atomicAdd(&a.counters[3], cnt_l2);
         }
     }
 }

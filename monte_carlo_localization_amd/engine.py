@@ -37,7 +37,8 @@ class Config(C.Structure):
         ("sigma_hit", C.c_double), ("squash_factor", C.c_double), ("motion_dispersion_x", C.c_double),
         ("motion_dispersion_y", C.c_double), ("motion_dispersion_theta", C.c_double), ("resample_mode", C.c_int32),
         ("weight_mode", C.c_int32), ("ray_kernel", C.c_int32), ("keep_ray_steps", C.c_int32),
-        ("debug_force_exact", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("debug_force_exact", C.c_int32), ("debug_count_probes", C.c_int32), ("rays_per_lane", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -216,7 +217,8 @@ class Engine:
     def counters(self):
         out = np.zeros(4, np.uint64)
         self._chk(self.lib.mcl_get_counters(self._h, _p(out)), "mcl_get_counters")
-        return dict(exact_fallback_rays=int(out[0]), off_window_particles=int(out[1]), probes=int(out[2]))
+        return dict(exact_fallback_rays=int(out[0]), off_window_particles=int(out[1]), probes=int(out[2]),
+                    level2_rays=int(out[3]))
 
     def ray_kernel_ms(self):
         v = C.c_double()
