@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the sharded (torch.distributed/RCCL) path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,10 +103,13 @@ def main():
     mode = engine.RESAMPLE_MULTINOMIAL if args.resample == "multinomial" else engine.RESAMPLE_SYSTEMATIC
 
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -119,7 +124,7 @@ def main():
     e.set_particles(p, np.full(n, 1.0 / (n * world)))
     del p
 
-    if world > 1:
+    if use_dist:
         from monte_carlo_localization_amd.dist import ShardedFilter
         dev = torch.device("cuda", local_rank)
         sf = ShardedFilter(e, n, dev)
@@ -149,7 +154,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    pose = sf.expected_pose() if world > 1 else e.expected_pose()
+    pose = sf.expected_pose() if use_dist else e.expected_pose()
     counters = e.counters()
 
     if rank == 0:
@@ -165,7 +170,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_rays_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_rays_skip_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -179,7 +184,7 @@ def main():
                        "particles_total": n * world, "beams": B,
                        "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_rays<2>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_rays_skip<1,false>",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar,
                          "note": "algorithmic (effective) bytes per SURVEY 8(d); real HBM traffic is far lower because "
                                  "the grid window lives in LDS and the kernel skips empty space; it is VALU/LDS-bound"},

@@ -846,6 +846,7 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
     hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;

@@ -1,0 +1,60 @@
+"""Worker for the world_size>1 tests: one rank of a ShardedFilter over gloo (CPU, oracle-backed shard)
+or over the real HIP engine (GPU box; ranks share the one GPU).  Writes its shard's result to an .npz."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    backend_kind, out_dir, n_local, steps, mode = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from monte_carlo_localization_amd import maps
+    from monte_carlo_localization_amd.dist import ShardedFilter
+    from oracle import oracle as orc
+    m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
+    ang = orc.beam_angles(angle_step=30)
+    obs = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"][::30].copy()
+    rng = np.random.default_rng(123)
+    ntot = n_local * world
+    p = np.stack([rng.normal(0, 0.5, ntot), rng.normal(0, 0.5, ntot), rng.normal(0, 0.4, ntot)])
+    mine = slice(rank * n_local, (rank + 1) * n_local)
+    w = np.full(n_local, 1.0 / ntot)
+    if backend_kind == "oracle":
+        from oracle_shard import OracleShard
+        om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
+        shard = OracleShard(om, ang, seed=2024, resample_mode=mode)
+        shard.set_particles(p[:, mine], w)
+        device = torch.device("cpu")
+    else:
+        from monte_carlo_localization_amd import engine
+        shard = engine.Engine(max_particles=n_local, device=0, seed=2024, resample_mode=mode)
+        shard.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+        shard.set_beam_angles(ang)
+        shard.set_particles(p[:, mine], w)
+        device = torch.device("cuda", 0)
+    sf = ShardedFilter(shard, n_local, device)
+    poses = []
+    for _ in range(steps):
+        poses.append(sf.update((0.05, 0.0, 0.01), obs))
+    if backend_kind == "oracle":
+        parts, q, idx = shard.p, shard.q, shard.idx
+    else:
+        parts, idx = shard.get_particles(), shard.resample_indices()
+        qt = torch.empty(n_local, dtype=torch.int64, device=device)
+        shard.export_state(0, 0, 0, qt.data_ptr())
+        q = qt.cpu().numpy().view(np.uint64)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
