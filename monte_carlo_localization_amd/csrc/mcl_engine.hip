@@ -67,6 +67,7 @@ struct mcl_engine {
     double *d_scalars = nullptr;        // 8
     unsigned long long *d_counters = nullptr;  // 4
     double *d_inject = nullptr;         // cap*4 (normals + uniforms)
+    double4 *d_pc = nullptr;            // cap: per-particle constants for k_rays_skip
     double h_scalars[8]{};
     uint64_t q_total = 0;
     double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
@@ -122,37 +123,88 @@ void build_sensor_table(const mcl_config_t &c, int P, std::vector<double> &t)
     }
 }
 
-// Padded stop grid + exact Chebyshev distance (two-pass 8-neighbour chamfer), capped at 255.
+// Padded stop grid + skip-distance field.
 // Padded cell (xp,yp), xp in [0,W], yp in [0,H], stands for reference cell (max(xp-1,0), max(yp-1,0)):
 // the reference truncates toward zero (cpp:628-629), so pixel coordinates in (-1,0) read cell 0.
 // Everything outside the padded grid is "stop" (map boundary, cpp:632-636).
+//
+// skip(c) = how far the fixed-step march may jump from a sample inside cell c without being able to
+// land in a stop cell earlier.  Samples are exactly one pixel apart along the ray, so sample k+j lies at
+// Euclidean distance j from sample k; it can be inside stop cell t only if j >= dist(p_k, t) >= gap(c, t),
+// the distance between the two (closed) cell squares, with equality only for p_k on the boundary of c
+// (such samples are caught by the kernel's boundary guard).  Hence skip(c) = floor(min_t gap(c,t)) + 1.
+// gap^2(c,t) = max(|dx|-1,0)^2 + max(|dy|-1,0)^2 is the squared centre distance from c to the 3x3
+// dilation of t, so one exact integer squared-EDT (Felzenszwalb & Huttenlocher lower envelopes) of the
+// dilated stop set gives it.  Stop cells get 0; values are capped at 255.
+void edt_1d(const int64_t *f, int n, int64_t *d, int *v, double *z)
+{
+    const int64_t INF = (int64_t)1 << 40;
+    int k = 0;
+    v[0] = 0; z[0] = -1e30; z[1] = 1e30;
+    for (int q = 1; q < n; ++q) {
+        if (f[q] >= INF) continue;
+        while (true) {
+            if (f[v[k]] >= INF) { v[k] = q; z[k] = -1e30; z[k + 1] = 1e30; break; }
+            double s = ((double)(f[q] + (int64_t)q * q) - (double)(f[v[k]] + (int64_t)v[k] * v[k])) / (2.0 * q - 2.0 * v[k]);
+            if (s <= z[k]) { --k; if (k < 0) { k = 0; v[0] = q; z[0] = -1e30; z[1] = 1e30; break; } continue; }
+            ++k; v[k] = q; z[k] = s; z[k + 1] = 1e30;
+            break;
+        }
+    }
+    k = 0;
+    for (int q = 0; q < n; ++q) {
+        while (z[k + 1] < q) ++k;
+        int64_t dq = (int64_t)(q - v[k]);
+        d[q] = (f[v[k]] >= INF) ? INF : dq * dq + f[v[k]];
+    }
+}
+
 void build_distance_field(const int8_t *grid, int W, int H, int Wp, int Hp, int Wps, std::vector<uint8_t> &dist)
 {
-    std::vector<int> d((size_t)Hp * Wp);
-    const int BIG = 1 << 20;
+    // work grid = padded grid plus a one-cell stop border on every side
+    const int Ww = Wp + 2, Hw = Hp + 2;
+    std::vector<uint8_t> stop((size_t)Hw * Ww, 1), dil((size_t)Hw * Ww, 0);
     for (int yp = 0; yp < Hp; ++yp)
         for (int xp = 0; xp < Wp; ++xp) {
             int gx = std::max(xp - 1, 0), gy = std::max(yp - 1, 0);
-            d[(size_t)yp * Wp + xp] = (grid[(size_t)gy * W + gx] > 50) ? 0 : BIG;
+            stop[(size_t)(yp + 1) * Ww + xp + 1] = grid[(size_t)gy * W + gx] > 50;
         }
-    auto at = [&](int x, int y) -> int { return (x < 0 || y < 0 || x >= Wp || y >= Hp) ? 0 : d[(size_t)y * Wp + x]; };
-    for (int y = 0; y < Hp; ++y)
-        for (int x = 0; x < Wp; ++x) {
-            int v = d[(size_t)y * Wp + x];
-            if (v == 0) continue;
-            int m = std::min(std::min(at(x - 1, y - 1), at(x, y - 1)), std::min(at(x + 1, y - 1), at(x - 1, y)));
-            d[(size_t)y * Wp + x] = std::min(v, m + 1);
+    for (int y = 0; y < Hw; ++y)
+        for (int x = 0; x < Ww; ++x) {
+            if (!stop[(size_t)y * Ww + x]) continue;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int yy = y + dy, xx = x + dx;
+                    if (yy >= 0 && yy < Hw && xx >= 0 && xx < Ww) dil[(size_t)yy * Ww + xx] = 1;
+                }
         }
-    for (int y = Hp - 1; y >= 0; --y)
-        for (int x = Wp - 1; x >= 0; --x) {
-            int v = d[(size_t)y * Wp + x];
-            if (v == 0) continue;
-            int m = std::min(std::min(at(x + 1, y + 1), at(x, y + 1)), std::min(at(x - 1, y + 1), at(x + 1, y)));
-            d[(size_t)y * Wp + x] = std::min(v, m + 1);
-        }
+    const int64_t INF = (int64_t)1 << 40;
+    std::vector<int64_t> g((size_t)Hw * Ww);
+    const int nmax = std::max(Ww, Hw);
+    std::vector<int64_t> f(nmax), d(nmax);
+    std::vector<int> v(nmax + 1);
+    std::vector<double> z(nmax + 2);
+    for (int x = 0; x < Ww; ++x) {            // columns
+        for (int y = 0; y < Hw; ++y) f[y] = dil[(size_t)y * Ww + x] ? 0 : INF;
+        edt_1d(f.data(), Hw, d.data(), v.data(), z.data());
+        for (int y = 0; y < Hw; ++y) g[(size_t)y * Ww + x] = d[y];
+    }
     dist.assign((size_t)Hp * Wps, 0);
-    for (int y = 0; y < Hp; ++y)
-        for (int x = 0; x < Wp; ++x) dist[(size_t)y * Wps + x] = (uint8_t)std::min(d[(size_t)y * Wp + x], 255);
+    for (int y = 1; y <= Hp; ++y) {           // rows
+        for (int x = 0; x < Ww; ++x) f[x] = g[(size_t)y * Ww + x];
+        edt_1d(f.data(), Ww, d.data(), v.data(), z.data());
+        for (int x = 1; x <= Wp; ++x) {
+            int val = 0;
+            if (!stop[(size_t)y * Ww + x]) {
+                int64_t g2 = d[x];
+                int64_t r = (int64_t)std::sqrt((double)g2);
+                while (r * r > g2) --r;
+                while ((r + 1) * (r + 1) <= g2) ++r;
+                val = (int)std::min<int64_t>(r + 1, 255);
+            }
+            dist[(size_t)(y - 1) * Wps + (x - 1)] = (uint8_t)val;
+        }
+    }
 }
 
 // cpp:452-471
@@ -242,6 +294,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
 {
     mcl::RayArgs a{};
     a.x = x; a.y = y; a.th = th; a.n = n;
+    a.pc = h->d_pc;
     a.B = h->B; a.bpad = h->bpad; a.P = h->P;
     a.beam_cs = h->d_beam_cs; a.beam_angle = h->d_angle; a.Lt = h->d_Lt;
     a.logw = h->d_logw;
@@ -255,6 +308,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     int mode = h->cfg.ray_kernel == MCL_RAYS_MARCH ? 1 : 2;
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
+    if (mode != 1)
+        hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
+                           h->res, h->d_pc);
     const bool count = h->cfg.debug_count_probes != 0;
     size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
     dim3 g(grid), b(mcl::kRayThreads);
@@ -394,6 +450,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_scalars, 8 * sizeof(double)));
     CRT(hipMalloc(&h->d_counters, 4 * sizeof(unsigned long long)));
     CRT(hipMalloc(&h->d_inject, nb * 4));
+    CRT(hipMalloc(&h->d_pc, (size_t)h->cap * sizeof(double4)));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
     CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -413,7 +470,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -483,17 +540,18 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->B = n_beams; h->bpad = (n_beams + 63) & ~63;
     h->angles.assign(angles, angles + n_beams);
-    std::vector<double2> cs(n_beams);
-    for (int j = 0; j < n_beams; ++j) {
-        double a = (double)angles[j];                 // cpp:533 widens the float angle
+    const int ncs = (n_beams + 255) & ~255;           // padded so that k_rays_skip never clamps its beam index
+    std::vector<double2> cs(ncs);
+    for (int j = 0; j < ncs; ++j) {
+        double a = (double)angles[j < n_beams ? j : n_beams - 1];   // cpp:533 widens the float angle
         cs[j] = make_double2(std::cos(a), std::sin(a));
     }
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx);
     HIPCHK(h, hipMalloc(&h->d_angle, (size_t)n_beams * sizeof(float)));
-    HIPCHK(h, hipMalloc(&h->d_beam_cs, (size_t)n_beams * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_beam_cs, (size_t)ncs * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_obs_idx, (size_t)n_beams * sizeof(int32_t)));
     HIPCHK(h, hipMemcpy(h->d_angle, angles, (size_t)n_beams * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)n_beams * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)ncs * sizeof(double2), hipMemcpyHostToDevice));
     h->lt_capacity = 0; dfree(h->d_Lt);
     if (h->cfg.keep_ray_steps) {
         size_t need = (size_t)h->cap * n_beams;

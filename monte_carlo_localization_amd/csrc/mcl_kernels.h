@@ -226,6 +226,7 @@ __global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restric
 // ------------------------------------------------------------------------------------------------
 struct RayArgs {
     const double *x, *y, *th;      // particles (this launch's)
+    const double4 *pc;             // per particle (cos th, sin th, (x-ox)/res, (y-oy)/res), k_particle_prep
     int64_t n;
     int B, bpad, P;
     const double2 *beam_cs;        // (cos a_j, sin a_j) of (double)angle_f32[j], host fp64
@@ -263,6 +264,29 @@ __device__ __forceinline__ int march_exact(const RayArgs &a, double x, double y,
 
 constexpr int kRayThreads = 1024;
 constexpr int kRayWaves = kRayThreads / 64;
+
+// per-particle constants of the skipping march, computed once by one lane instead of by all 64 lanes
+// of the wave that owns the particle
+__global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict__ x, const double *__restrict__ y,
+                                                      const double *__restrict__ th, int64_t n, double ox, double oy, double res,
+                                                      double4 *__restrict__ pc)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    sincos(th[i], &s, &c);
+    pc[i] = make_double4(c, s, (x[i] - ox) / res, (y[i] - oy) / res);
+}
+
+// D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
+__device__ __forceinline__ uint32_t mad_i24(int a, int b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// round-to-nearest-even double -> int32 through the 1.5*2^52 magic add (|x| < 2^31)
+__device__ __forceinline__ int rint_i32(double x) { return __double2loint(x + 6755399441055744.0); }
 
 // ---- K3a: literal march for every ray (MCL_RAYS_MARCH): the on-device ground truth -------------
 template <bool COUNT>
@@ -371,7 +395,8 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
         double *red = reinterpret_cast<double *>(lds_raw);   // scratch, overwritten by the window below
         double sx = 0.0, sy = 0.0;
         for (int64_t i = p_begin + threadIdx.x; i < p_end; i += kRayThreads) {
-            double gx = (a.x[i] - a.ox) / a.res, gy = (a.y[i] - a.oy) / a.res;
+            double4 c = a.pc[i];
+            double gx = c.z, gy = c.w;
             if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; }
         }
         sx = wave_sum(sx); sy = wave_sum(sy);
@@ -396,7 +421,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     uint32_t d = (uint32_t)(b8 >> (8 * k)) & 0xFFu;
-                    d = d > 15u ? 15u : d;
+                    d = d > 15u ? 15u : d;           // nibble = skip distance, 0 = stop
                     word |= d << (4 * k);
                 }
             }
@@ -404,17 +429,15 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
         }
         __syncthreads();
     }
-    const uint32_t *ldsw = reinterpret_cast<const uint32_t *>(lds_raw);
     const unsigned char *ldsb = lds_raw;
     const int ngroups = (a.B + 64 * R - 1) / (64 * R);
 
     for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
-        const double x = a.x[i], y = a.y[i], th = a.th[i];
+        const double4 pci = a.pc[i];
         double acc = 0.0;
-        double sth, cth;
-        sincos(th, &sth, &cth);
-        const double gpx = (x - a.ox) / a.res;        // global pixel coordinate of the particle
-        const double gpy = (y - a.oy) / a.res;
+        const double cth = pci.x, sth = pci.y;
+        const double gpx = pci.z;                     // global pixel coordinate of the particle
+        const double gpy = pci.w;
         const double wpx = gpx - (double)(wx0 - 1);   // window-relative padded coordinate
         const double wpy = gpy - (double)(wy0 - 1);
         const double reach = (double)(a.P + 2);
@@ -445,25 +468,26 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
         }
 
         if (inwin) {
-            const uint32_t P0x = (uint32_t)(long long)rint(wpx * 4194304.0);
-            const uint32_t P0y = (uint32_t)(long long)rint(wpy * 4194304.0);
+            const uint32_t P0x = (uint32_t)rint_i32(wpx * 4194304.0 - 2147483648.0) + 0x80000000u;   // rint(wpx*2^22) mod 2^32
+            const uint32_t P0y = (uint32_t)rint_i32(wpy * 4194304.0 - 2147483648.0) + 0x80000000u;
             const uint32_t g0 = (amb0 < kGuard) ? 0u : 0xFFFFFFFFu;
-            const int s_start = s0 <= a.P ? s0 : a.P;
+            const int rem_start = s0 <= a.P ? a.P - s0 : 0;
+            const double ncth22 = -cth * 4194304.0, sth22 = sth * 4194304.0;
             for (int grp = 0; grp < ngroups; ++grp) {
-                int Ux[R], Uy[R], s[R];
-                uint32_t g[R], d[R];
+                int NUx[R], NUy[R], rem[R], n[R];
+                uint32_t Pex[R], Pey[R], g[R];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    int j = (grp * R + k) * 64 + lane;
-                    bool valid = j < a.B;
-                    double2 cs = a.beam_cs[valid ? j : 0];
-                    double ux = cth * cs.x - sth * cs.y;      // cos(theta + a_j)
-                    double uy = sth * cs.x + cth * cs.y;      // sin(theta + a_j)
-                    Ux[k] = valid ? (int)rint(ux * 4194304.0) : 0;
-                    Uy[k] = valid ? (int)rint(uy * 4194304.0) : 0;
-                    s[k] = valid ? s_start : a.P;             // an invalid slot re-probes the own cell once
+                    int j = (grp * R + k) * 64 + lane;        // beam_cs is padded: no clamp needed
+                    double2 cs = a.beam_cs[j];
+                    // -U = -rint(2^22 * (cos, sin)(theta + a_j)); T(s) = P0 + s*U = Pe - rem*U with rem = P - s
+                    NUx[k] = rint_i32(__builtin_fma(ncth22, cs.x, sth22 * cs.y));
+                    NUy[k] = rint_i32(__builtin_fma(ncth22, cs.y, -(sth22 * cs.x)));
+                    Pex[k] = mad_i24(-a.P, NUx[k], P0x);
+                    Pey[k] = mad_i24(-a.P, NUy[k], P0y);
+                    rem[k] = (j < a.B) ? rem_start : 0;       // a padding slot probes its end sample once
                     g[k] = g0;
-                    d[k] = 0;
+                    n[k] = 0;
                 }
                 // ---- level 1: all R rays of the lane advance together; a finished ray keeps
                 //      re-probing its last sample (same state every trip) until the wave is done ----
@@ -472,18 +496,21 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                     any = false;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        uint32_t Tx = (uint32_t)(__mul24(s[k], Ux[k]) + (int)P0x);
-                        uint32_t Ty = (uint32_t)(__mul24(s[k], Uy[k]) + (int)P0y);
+                        uint32_t Tx = mad_i24(rem[k], NUx[k], Pex[k]);
+                        uint32_t Ty = mad_i24(rem[k], NUy[k], Pey[k]);
                         uint32_t gx = (Tx << (32 - kFx)) + (kG1 << (32 - kFx));
                         uint32_t gy = (Ty << (32 - kFx)) + (kG1 << (32 - kFx));
                         uint32_t gm = gx < gy ? gx : gy;
                         g[k] = g[k] < gm ? g[k] : gm;
-                        uint32_t t = Tx >> (kFx - 2);
-                        uint32_t word = ldsw[__umul24(Ty >> kFx, (uint32_t)wpr) + (t >> 5)];
-                        d[k] = (word >> (t & 28u)) & 15u;
-                        int s1 = s[k] + (int)d[k];
-                        bool go = (d[k] != 0u) && (s1 <= a.P);
-                        s[k] = go ? s1 : s[k];
+                        uint32_t off = __umul24(Ty >> kFx, (uint32_t)strideB) + ((Tx >> (kFx + 1)) & 0x1FCu);
+                        uint32_t word = *reinterpret_cast<const uint32_t *>(lds_raw + off);
+                        n[k] = (int)__builtin_amdgcn_ubfe(word, (Tx >> (kFx - 2)) & 28u, 4u);   // skip distance, 0 on a stop
+                        bool go = (uint32_t)(n[k] - 1) < (uint32_t)rem[k];                       // 1 <= skip <= samples left
+                        if (R == 1) {
+                            rem[k] -= n[k];                                                      // unchanged on a stop
+                        } else {
+                            rem[k] = go ? rem[k] - n[k] : rem[k];
+                        }
                         any |= go;
                         if (COUNT) cnt_probe += go ? 1 : 0;
                     }
@@ -492,7 +519,8 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                 for (int k = 0; k < R; ++k) {
                     int j = (grp * R + k) * 64 + lane;
                     if (j < a.B) {
-                        int r = (d[k] == 0u) ? s[k] - 1 : a.P;
+                        // R == 1: rem was decremented once more after an overshoot; only the stop case reads it
+                        int r = (n[k] == 0) ? a.P - rem[k] - 1 : a.P;
                         if (COUNT) ++cnt_probe;
                         if (g[k] < ((2u * kG1) << (32 - kFx)) || a.force_exact) {
                             // ---- level 2 (and 3): rare, everything recomputed from scratch ----
@@ -505,7 +533,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                             ++cnt_l2;
                             if (COUNT) cnt_probe += np;
                             if (amb < kGuard || a.force_exact == 1) {
-                                r = march_exact(a, x, y, th + (double)a.beam_angle[j]);
+                                r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
                                 ++cnt_exact;
                             }
                         }
@@ -528,7 +556,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                         r = trace_fp64<false, COUNT>(a, ldsb, strideB, base, p0x, p0y, ux, uy, s0, amb, np);
                     }
                     if (!sane || amb < kGuard || a.force_exact == 1) {
-                        r = march_exact(a, x, y, th + (double)a.beam_angle[j]);
+                        r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
                         ++cnt_exact;
                     }
                     acc += (double)a.Lt[(size_t)r * a.bpad + j];
