@@ -153,6 +153,14 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
  * with HIP events on the engine's own stream */
 int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
 
+/* ---- host-side precomputation, callable without a device (what mcl_set_map uploads) --------- */
+/* (P+1)^2 doubles, Eigen column-major (index d*(P+1)+r): the restatement of precompute_sensor_model
+ * (cpp:233-292) the engine uses. */
+int mcl_host_sensor_table(const mcl_config_t *cfg, int32_t max_range_px, double *out, size_t n);
+/* Skip-distance field of DESIGN.md §4.2 on the padded grid: (height+1) x (width+1) bytes, row-major,
+ * 0 = stop cell, otherwise how many samples the fixed-step march may advance from a sample in that cell. */
+int mcl_host_skip_field(const int8_t *data, uint32_t width, uint32_t height, uint8_t *out, size_t n);
+
 /* ---- multi-GPU staging (one engine per rank; collectives are the host's) -- */
 /* Device pointers of engine-owned buffers so the host can hand them to RCCL without copies. */
 typedef enum {

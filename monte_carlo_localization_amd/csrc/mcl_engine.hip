@@ -815,6 +815,25 @@ int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms)
     return MCL_OK;
 }
 
+int mcl_host_sensor_table(const mcl_config_t *cfg, int32_t P, double *out, size_t n)
+{
+    if (!cfg || !out || P < 1 || n != (size_t)(P + 1) * (P + 1)) return MCL_ERR_INVALID_ARG;
+    std::vector<double> t;
+    build_sensor_table(*cfg, P, t);
+    std::memcpy(out, t.data(), n * sizeof(double));
+    return MCL_OK;
+}
+
+int mcl_host_skip_field(const int8_t *data, uint32_t width, uint32_t height, uint8_t *out, size_t n)
+{
+    if (!data || !out || width == 0 || height == 0 || n != (size_t)(width + 1) * (height + 1)) return MCL_ERR_INVALID_ARG;
+    const int Wp = (int)width + 1, Hp = (int)height + 1, Wps = (Wp + 7) & ~7;
+    std::vector<uint8_t> d;
+    build_distance_field(data, (int)width, (int)height, Wp, Hp, Wps, d);
+    for (int y = 0; y < Hp; ++y) std::memcpy(out + (size_t)y * Wp, d.data() + (size_t)y * Wps, Wp);
+    return MCL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // multi-GPU staging
 // ---------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ EXPORTS = [
     "mcl_sensor_update", "mcl_expected_pose", "mcl_get_stage_timings", "mcl_get_resample_indices",
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
-    "mcl_get_scalars",
+    "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field",
 ]
 
 
@@ -84,6 +84,27 @@ def _p(a):
 
 def _c(a, dt):
     return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def host_sensor_table(P: int, cfg: Config | None = None) -> np.ndarray:
+    """The engine's host-side sensor table (no device needed); returned as T[d, r]."""
+    cfg = cfg or default_config()
+    out = np.empty((P + 1) * (P + 1), np.float64)
+    rc = load_library().mcl_host_sensor_table(C.byref(cfg), C.c_int32(P), _p(out), C.c_size_t(out.size))
+    if rc != MCL_OK:
+        raise EngineError(f"mcl_host_sensor_table rc={rc}")
+    return out.reshape(P + 1, P + 1)
+
+
+def host_skip_field(grid) -> np.ndarray:
+    """The engine's padded skip-distance field (no device needed): shape (H+1, W+1), uint8."""
+    g = _c(grid, np.int8)
+    H, W = g.shape
+    out = np.empty((H + 1, W + 1), np.uint8)
+    rc = load_library().mcl_host_skip_field(_p(g), C.c_uint32(W), C.c_uint32(H), _p(out), C.c_size_t(out.size))
+    if rc != MCL_OK:
+        raise EngineError(f"mcl_host_skip_field rc={rc}")
+    return out
 
 
 class Engine:
