@@ -282,7 +282,14 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
 __device__ __forceinline__ uint32_t mad_i24(int a, int b, uint32_t c)
 {
     uint32_t d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// D = a*b + c on the low 24 bits (unsigned): LDS byte offset = row * stride + column byte
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 // round-to-nearest-even double -> int32 through the 1.5*2^52 magic add (|x| < 2^31)
@@ -431,6 +438,10 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     }
     const unsigned char *ldsb = lds_raw;
     const int ngroups = (a.B + 64 * R - 1) / (64 * R);
+    // the level-1 loop addresses the window with raw LDS offsets: the dynamic segment must start at 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != 0u) __builtin_trap();
+    uint32_t strideB_v = (uint32_t)strideB, gbias_v = kG1 << (32 - kFx);
+    asm volatile("" : "+v"(strideB_v), "+v"(gbias_v));   // keep both in VGPRs across the loop
 
     for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
         const double4 pci = a.pc[i];
@@ -496,20 +507,37 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                     any = false;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        uint32_t Tx = mad_i24(rem[k], NUx[k], Pex[k]);
-                        uint32_t Ty = mad_i24(rem[k], NUy[k], Pey[k]);
-                        uint32_t gx = (Tx << (32 - kFx)) + (kG1 << (32 - kFx));
-                        uint32_t gy = (Ty << (32 - kFx)) + (kG1 << (32 - kFx));
-                        uint32_t gm = gx < gy ? gx : gy;
-                        g[k] = g[k] < gm ? g[k] : gm;
-                        uint32_t off = __umul24(Ty >> kFx, (uint32_t)strideB) + ((Tx >> (kFx + 1)) & 0x1FCu);
-                        uint32_t word = *reinterpret_cast<const uint32_t *>(lds_raw + off);
-                        n[k] = (int)__builtin_amdgcn_ubfe(word, (Tx >> (kFx - 2)) & 28u, 4u);   // skip distance, 0 on a stop
-                        bool go = (uint32_t)(n[k] - 1) < (uint32_t)rem[k];                       // 1 <= skip <= samples left
+                        // One hand-scheduled block per probe (13 VALU + 1 LDS read): position update, LDS byte
+                        // address = row * stride + (cx >> 1) (the window starts at LDS offset 0), boundary guard
+                        // and nibble select overlapped with the LDS round trip.
+                        uint32_t Tx, Ty, t0, t1, addr, byte;
+                        asm volatile(
+                            "v_mad_i32_i24 %[tx], %[rem], %[nux], %[pex]\n\t"     // Tx = rem*NUx + Pex
+                            "v_mad_i32_i24 %[ty], %[rem], %[nuy], %[pey]\n\t"     // Ty = rem*NUy + Pey
+                            "v_lshrrev_b32 %[t0], 23, %[tx]\n\t"                  // cx >> 1
+                            "v_lshrrev_b32 %[t1], 22, %[ty]\n\t"                  // cy
+                            "v_mad_u32_u24 %[ad], %[t1], %[str], %[t0]\n\t"       // byte address
+                            "ds_read_u8 %[by], %[ad]\n\t"
+                            "v_lshl_add_u32 %[t0], %[tx], 10, %[gb]\n\t"          // biased fraction of x in the top 22 bits
+                            "v_lshl_add_u32 %[t1], %[ty], 10, %[gb]\n\t"
+                            "v_min3_u32 %[g], %[g], %[t0], %[t1]\n\t"             // closest approach to a cell boundary so far
+                            "v_lshrrev_b32 %[t0], 20, %[tx]\n\t"
+                            "v_and_b32 %[t0], 4, %[t0]\n\t"                       // nibble select: (cx & 1) * 4
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_bfe_u32 %[by], %[by], %[t0], 4"                     // skip distance, 0 on a stop
+                            : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte),
+                              [g] "+v"(g[k])
+                            : [rem] "v"(rem[k]), [nux] "v"(NUx[k]), [nuy] "v"(NUy[k]), [pex] "v"(Pex[k]), [pey] "v"(Pey[k]),
+                              [str] "v"(strideB_v), [gb] "v"(gbias_v)
+                            : "memory");
+                        n[k] = (int)byte;
+                        uint32_t nr;
+                        bool over = __builtin_usub_overflow((uint32_t)rem[k], (uint32_t)n[k], &nr);   // skip > samples left
+                        bool go = !over && n[k] != 0;
                         if (R == 1) {
-                            rem[k] -= n[k];                                                      // unchanged on a stop
+                            rem[k] = (int)nr;                                                    // unchanged on a stop
                         } else {
-                            rem[k] = go ? rem[k] - n[k] : rem[k];
+                            rem[k] = go ? (int)nr : rem[k];
                         }
                         any |= go;
                         if (COUNT) cnt_probe += go ? 1 : 0;
