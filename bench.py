@@ -34,7 +34,7 @@ ACTION = (0.05, 0.0, 0.01)
 TRUE_POSE = (0.0, 0.0, 0.0)
 
 
-def cpu_baseline(m, ang, scan, budget_s=20.0):
+def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
     """Oracle (kind 'port'): BASELINE config #1 = 4000 particles x 1081 beams, all host cores,
     plus the 1-thread figure because the reference's chunk-1 dynamic schedule does not scale
     (SURVEY D11).  Also returns S-bar, the mean number of grid probes per ray of the fixed-step
@@ -44,7 +44,7 @@ def cpu_baseline(m, ang, scan, budget_s=20.0):
     n = 4000
     T = orc.sensor_table(om.max_range_px)
     s = orc.RefStream(42)
-    p, w = orc.init_particles_pose(s, TRUE_POSE, n)
+    p, w = orc.init_particles_pose(s, true_pose, n)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))
     out = {}
@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--map", choices=["spielberg", "levine"], default="spielberg",
+                    help="levine = the synthetic 2049x2049 @0.05 stand-in (maps/levine.pgm is absent from the reference)")
+    ap.add_argument("--regime", choices=["tracking", "global"], default="tracking")
     ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -97,7 +100,12 @@ def main():
     from monte_carlo_localization_amd import engine, maps, synth
 
     n = args.particles_per_gpu
-    m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
+    if args.map == "spielberg":
+        m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
+        true_pose = TRUE_POSE
+    else:
+        m = maps.synthetic_levine()
+        true_pose = (-34.0, -34.9, 0.0)          # corridor centre near the lower-left corner of the loop
     ang = synth.beam_angles()
     B = ang.size
     mode = engine.RESAMPLE_MULTINOMIAL if args.resample == "multinomial" else engine.RESAMPLE_SYSTEMATIC
@@ -118,9 +126,12 @@ def main():
     e.set_beam_angles(ang)
     # noise-free scan from the true pose: the committed fixture (tests assert the engine regenerates it
     # bit for bit); keeps the profiled run free of a stray 1-particle k_rays launch
-    scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
+    if args.map == "spielberg":
+        scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
+    else:
+        scan = synth.scan_from_pose(e, m, ang, true_pose)
     rng = np.random.default_rng(42 + rank)
-    p = synth.tracking_cloud(rng, n, TRUE_POSE)
+    p = synth.tracking_cloud(rng, n, true_pose) if args.regime == "tracking" else synth.global_cloud(rng, m, n)
     e.set_particles(p, np.full(n, 1.0 / (n * world)))
     del p
 
@@ -162,7 +173,7 @@ def main():
         value = n * world * B / (elapsed / args.steps)
         base, sbar = (None, 43.4)
         if world == 1 and not args.no_cpu_baseline:
-            base, sbar = cpu_baseline(m, ang, scan)
+            base, sbar = cpu_baseline(m, ang, scan, true_pose)
         k_ms = float(np.mean(ray_ms))
         alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per k_rays launch (one GPU's shard)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -178,8 +189,12 @@ def main():
             "value": value, "unit": "particle*beam/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n} particles/GPU x {B} beams, Spielberg_map (2000x2000 @ 0.05796), "
-                                   f"tracking-regime cloud N((0,0,0),(0.5 m,0.5 m,0.4 rad)), action {ACTION}, "
+            "config": {"workload": f"{n} particles/GPU x {B} beams, "
+                                   + ("Spielberg_map (2000x2000 @ 0.05796), " if args.map == "spielberg"
+                                      else "SYNTHETIC levine stand-in (2049x2049 @ 0.05), ")
+                                   + (f"tracking-regime cloud N({true_pose},(0.5 m,0.5 m,0.4 rad)), " if args.regime == "tracking"
+                                      else "global-regime cloud (uniform over free cells), ")
+                                   + f"action {ACTION}, "
                                    f"stock sensor/motion params, {args.resample} resampling, Philox seed 42",
                        "particles_total": n * world, "beams": B,
                        "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU"},
