@@ -113,6 +113,13 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams);
 /* After initialize_particles_pose / initialize_global rewrote the host copies (cpp:388-398,
  * 433-443).  n must be <= max_particles and becomes the active particle count. */
 int mcl_set_particles(mcl_engine_t *h, const double *xyz_colmajor, const double *weights, int64_t n);
+/* Device-side versions of the two initialisers (Philox draws instead of the host's rng_; same formulas):
+ * Gaussian cloud (0.5 m, 0.5 m, 0.4 rad) around `pose` (cpp:388-398) / uniform over free cells with
+ * theta ~ U[0,2pi) (cpp:408-443).  n particles become active with weights 1/n_total; first_global_index is
+ * this shard's offset in a sharded set (0 and n_total = n on a single GPU).  At 4M-32M particles this
+ * replaces a 100-800 MB host->device upload. */
+int mcl_init_particles_pose(mcl_engine_t *h, const double pose[3], int64_t n, int64_t first_global_index, int64_t n_total);
+int mcl_init_global(mcl_engine_t *h, int64_t n, int64_t first_global_index, int64_t n_total);
 int mcl_get_particles(mcl_engine_t *h, double *xyz_colmajor, int64_t n);
 int mcl_get_weights(mcl_engine_t *h, double *weights, int64_t n);
 /* visualize()'s weighted sample of k rows (cpp:949-956): k draws from the current weights.
@@ -130,6 +137,9 @@ int mcl_particle_mean(mcl_engine_t *h, double out[3]);
  * in [0,1) as discrete_distribution would draw them (cpp:663).  Either may be NULL -> Philox. */
 int mcl_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams,
                const double *normals_nx3, const double *uniforms_n);
+/* Same update fed with the RAW LaserScan.ranges: the engine keeps every angle_step-th range like
+ * lidarCB does (cpp:316-320) — ceil(n_ranges/angle_step) must equal the number of beam angles set. */
+int mcl_update_scan(mcl_engine_t *h, const double action[3], const float *ranges, int32_t n_ranges, int32_t angle_step);
 /* sensor_model() + normalisation only, on the current particles (cpp:676-686): no resample, no
  * motion.  Used by parity tests of the ray-cast / likelihood stage. */
 int mcl_sensor_update(mcl_engine_t *h, const float *obs, int32_t n_beams);

@@ -50,6 +50,11 @@ struct mcl_engine {
     float *d_angle = nullptr;
     double2 *d_beam_cs = nullptr;
     int32_t *d_obs_idx = nullptr;
+    float *d_obs = nullptr;
+    float *h_obs = nullptr;             // pinned staging for the per-update scan
+    uint32_t *d_free = nullptr;         // linear indices of free cells (data == 0), row-major, cpp:199-213
+    uint64_t n_free = 0;
+    uint32_t init_idx = 0;
     float *d_Lt = nullptr;
     size_t lt_capacity = 0;
 
@@ -221,23 +226,6 @@ void motion_scalars(const double action[3], double &dt, double &v, double &w)
     if (std::abs(ad) > 0.001) w = ad / dt;
 }
 
-// cpp:549-554, 570, 573; NaN -> 0
-void obs_indices(const float *obs, int B, double res, int P, std::vector<int32_t> &out)
-{
-    out.resize(B);
-    for (int j = 0; j < B; ++j) {
-        float px = (float)((double)obs[j] / res);
-        if (px > (float)P) px = (float)P;
-        float r = std::round(px);
-        int idx;
-        if (r != r) idx = 0;
-        else if (r <= -2147483648.0f) idx = 0;
-        else idx = (int)r;
-        idx = std::max(0, std::min(idx, P));
-        out[j] = idx;
-    }
-}
-
 int ensure_lt(mcl_engine *h)
 {
     size_t need = (size_t)(h->P + 1) * h->bpad;
@@ -334,12 +322,11 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
 }
 
 // obs -> obs_idx upload + per-update transposed log table
-int prepare_observation(mcl_engine *h, const float *obs)
+int prepare_observation(mcl_engine *h, const float *obs, int stride)
 {
-    std::vector<int32_t> oi;
-    obs_indices(obs, h->B, h->res, h->P, oi);
-    HIPCHK(h, hipMemcpyAsync(h->d_obs_idx, oi.data(), (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // oi is a stack-lifetime buffer
+    for (int j = 0; j < h->B; ++j) h->h_obs[j] = obs[(size_t)j * stride];   // cpp:316-320 when stride = ANGLE_STEP
+    HIPCHK(h, hipMemcpyAsync(h->d_obs, h->h_obs, (size_t)h->B * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(mcl::k_obs_index, dim3(1), dim3(256), 0, h->stream, h->d_obs, h->B, h->res, h->P, h->d_obs_idx);
     int rc = ensure_lt(h);
     if (rc) return rc;
     dim3 g((h->bpad + 255) / 256, h->P + 1);
@@ -472,7 +459,8 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
+    if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -512,6 +500,17 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
     h->lt_capacity = 0; dfree(h->d_Lt);
+    {   // free-space list for initialize_global (cpp:199-213, 411-421): row-major order of data == 0
+        std::vector<uint32_t> fr;
+        for (size_t i = 0; i < (size_t)h->W * h->H; ++i)
+            if (data[i] == 0) fr.push_back((uint32_t)i);
+        dfree(h->d_free);
+        h->n_free = fr.size();
+        if (h->n_free) {
+            HIPCHK(h, hipMalloc(&h->d_free, fr.size() * sizeof(uint32_t)));
+            HIPCHK(h, hipMemcpy(h->d_free, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
     h->have_map = true;
     return MCL_OK;
 }
@@ -546,7 +545,10 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
         double a = (double)angles[j < n_beams ? j : n_beams - 1];   // cpp:533 widens the float angle
         cs[j] = make_double2(std::cos(a), std::sin(a));
     }
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_obs);
+    if (h->h_obs) { (void)hipHostFree(h->h_obs); h->h_obs = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_obs, (size_t)n_beams * sizeof(float)));
+    HIPCHK(h, hipHostMalloc(&h->h_obs, (size_t)n_beams * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->d_angle, (size_t)n_beams * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->d_beam_cs, (size_t)ncs * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_obs_idx, (size_t)n_beams * sizeof(int32_t)));
@@ -585,6 +587,50 @@ int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights,
     h->have_particles = true;
     h->have_idx = h->have_steps = h->have_logw = false;
     return MCL_OK;
+}
+
+static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
+{
+    h->N = n;
+    hipLaunchKernelGGL(mcl::k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_w, n, 1.0 / (double)n_total);
+    HIPCHK(h, hipGetLastError());
+    int rc = weight_stats(h, false, nullptr);
+    if (rc) return rc;
+    rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+    if (rc) return rc;
+    rc = fetch_scalars(h);
+    if (rc) return rc;
+    h->have_particles = true;
+    h->have_idx = h->have_steps = h->have_logw = false;
+    h->init_idx++;
+    return MCL_OK;
+}
+
+int mcl_init_particles_pose(mcl_engine_t *h, const double pose[3], int64_t n, int64_t first_global_index, int64_t n_total)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!pose || n <= 0 || n > h->cap || first_global_index < 0 || n_total < n) return fail(h, MCL_ERR_INVALID_ARG, "bad init arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int c = h->cur;
+    hipLaunchKernelGGL(mcl::k_init_pose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, pose[0], pose[1], pose[2], n,
+                       first_global_index, (uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32), h->init_idx, h->d_x[c], h->d_y[c], h->d_th[c]);
+    HIPCHK(h, hipGetLastError());
+    return finish_init(h, n, n_total);
+}
+
+int mcl_init_global(mcl_engine_t *h, int64_t n, int64_t first_global_index, int64_t n_total)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!h->have_map) return fail(h, MCL_ERR_NOT_READY, "map not set");                 // cpp:403
+    if (h->n_free == 0) return fail(h, MCL_ERR_NOT_READY, "No free space found in map!");   // cpp:423-427
+    if (n <= 0 || n > h->cap || first_global_index < 0 || n_total < n) return fail(h, MCL_ERR_INVALID_ARG, "bad init arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int c = h->cur;
+    hipLaunchKernelGGL(mcl::k_init_global, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_free, h->n_free, h->W, h->res,
+                       h->ox, h->oy, n, first_global_index, (uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32), h->init_idx, h->d_x[c],
+                       h->d_y[c], h->d_th[c]);
+    HIPCHK(h, hipGetLastError());
+    return finish_init(h, n, n_total);
 }
 
 int mcl_get_particles(mcl_engine_t *h, double *xyz, int64_t n)
@@ -655,7 +701,7 @@ int mcl_particle_mean(mcl_engine_t *h, double out[3])
 }
 
 static int do_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, const double *normals,
-                     const double *uniforms, bool resample_and_move)
+                     const double *uniforms, bool resample_and_move, int obs_stride = 1)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
@@ -709,7 +755,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->have_idx = true;
     }
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
-    int rc = prepare_observation(h, obs);
+    int rc = prepare_observation(h, obs, obs_stride);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
@@ -745,6 +791,14 @@ int mcl_update(mcl_engine_t *h, const double action[3], const float *obs, int32_
 int mcl_sensor_update(mcl_engine_t *h, const float *obs, int32_t n_beams)
 {
     return do_update(h, nullptr, obs, n_beams, nullptr, nullptr, false);
+}
+
+int mcl_update_scan(mcl_engine_t *h, const double action[3], const float *ranges, int32_t n_ranges, int32_t angle_step)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!ranges || angle_step <= 0 || n_ranges <= 0) return fail(h, MCL_ERR_INVALID_ARG, "bad scan");
+    int32_t nb = (n_ranges + angle_step - 1) / angle_step;            // cpp:317: i = 0, ANGLE_STEP, ...
+    return do_update(h, action, ranges, nb, nullptr, nullptr, true, angle_step);
 }
 
 int mcl_expected_pose(mcl_engine_t *h, double out[3])
@@ -880,6 +934,7 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
                         int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
                         const double action[3], const float *obs, int32_t n_beams)
 {
+    const int obs_stride = 1;
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
     if (!d_px || !d_py || !d_pth || !d_cdf || !action || !obs || n_beams != h->B || n_parents <= 0)
@@ -914,7 +969,7 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     h->cur = nx;
     h->have_idx = true;
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
-    int rc = prepare_observation(h, obs);
+    int rc = prepare_observation(h, obs, obs_stride);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n);

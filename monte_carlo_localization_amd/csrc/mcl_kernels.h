@@ -209,6 +209,75 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
 }
 
+// lidarCB's downsampled ranges -> table row per beam, cpp:549-554, 570, 573 (NaN -> 0): one block
+__global__ void k_obs_index(const float *__restrict__ obs, int B, double res, int P, int32_t *__restrict__ obs_idx)
+{
+    for (int j = threadIdx.x; j < B; j += blockDim.x) {
+        float px = (float)((double)obs[j] / res);
+        if (px > (float)P) px = (float)P;
+        float r = roundf(px);
+        int idx;
+        if (r != r) idx = 0;
+        else if (r <= -2147483648.0f) idx = 0;
+        else idx = (int)r;
+        idx = idx > P ? P : idx;
+        idx = idx < 0 ? 0 : idx;
+        obs_idx[j] = idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Particle initialisation on the device.  Philox streams 5/6 (pose cloud) and 7 (global).
+//   pose cloud, cpp:390-398: x = pose_x + n0*0.5, y = pose_y + n1*0.5, theta = wrap(pose_t + n2*0.4)
+//   global, cpp:433-441:     cell = free[floor(u*n_free)], x = col*res + ox, y = row*res + oy, theta = u2*2pi
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_pose(double px, double py, double pt, int64_t n, int64_t first, uint32_t seed_lo,
+                                                  uint32_t seed_hi, uint32_t init_idx, double *__restrict__ x,
+                                                  double *__restrict__ y, double *__restrict__ th)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t g = (uint64_t)(first + i);
+    const double TWO_M53 = 1.0 / 9007199254740992.0;
+    const double TWO_PI = 2.0 * 3.14159265358979323846;
+    u32x4 o = philox4x32((uint32_t)g, init_idx, 5u, (uint32_t)(g >> 32), seed_lo, seed_hi);
+    double u1 = (double)(bits53(o.v[0], o.v[1]) + 1) * TWO_M53;
+    double u2 = (double)bits53(o.v[2], o.v[3]) * TWO_M53;
+    double rad = sqrt(-2.0 * log(u1));
+    double n0 = rad * cos(TWO_PI * u2), n1 = rad * sin(TWO_PI * u2);
+    o = philox4x32((uint32_t)g, init_idx, 6u, (uint32_t)(g >> 32), seed_lo, seed_hi);
+    u1 = (double)(bits53(o.v[0], o.v[1]) + 1) * TWO_M53;
+    u2 = (double)bits53(o.v[2], o.v[3]) * TWO_M53;
+    double n2 = sqrt(-2.0 * log(u1)) * cos(TWO_PI * u2);
+    x[i] = px + n0 * 0.5;
+    y[i] = py + n1 * 0.5;
+    th[i] = normalize_angle(pt + n2 * 0.4);
+}
+
+__global__ __launch_bounds__(256) void k_init_global(const uint32_t *__restrict__ free_cells, uint64_t n_free, int W, double res,
+                                                    double ox, double oy, int64_t n, int64_t first, uint32_t seed_lo,
+                                                    uint32_t seed_hi, uint32_t init_idx, double *__restrict__ x,
+                                                    double *__restrict__ y, double *__restrict__ th)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t g = (uint64_t)(first + i);
+    u32x4 o = philox4x32((uint32_t)g, init_idx, 7u, (uint32_t)(g >> 32), seed_lo, seed_hi);
+    uint64_t k = bits53(o.v[0], o.v[1]);
+    uint64_t pick = __umul64hi(k << 11, n_free);            // floor(k/2^53 * n_free)
+    uint32_t cell = free_cells[pick];
+    int row = (int)(cell / (uint32_t)W), col = (int)(cell - (uint32_t)row * (uint32_t)W);
+    x[i] = col * res + ox;                                   // cpp:438
+    y[i] = row * res + oy;                                   // cpp:439
+    th[i] = (double)bits53(o.v[2], o.v[3]) * (1.0 / 9007199254740992.0) * (2.0 * 3.14159265358979323846);
+}
+
+__global__ void k_fill(double *__restrict__ p, int64_t n, double v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // per-update transposed log table: Lt[d * bpad + j] = L[obs_idx[j] * (P+1) + d]
 __global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int bpad, int tw,
                            float *__restrict__ Lt)

@@ -26,7 +26,8 @@ EXPORTS = [
     "mcl_sensor_update", "mcl_expected_pose", "mcl_get_stage_timings", "mcl_get_resample_indices",
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
-    "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field",
+    "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
+    "mcl_update_scan",
 ]
 
 
@@ -172,6 +173,21 @@ class Engine:
         assert w.size == n
         self._chk(self.lib.mcl_set_particles(self._h, _p(p), _p(w), C.c_int64(n)), "mcl_set_particles")
         self.n = n
+
+    def init_particles_pose(self, pose, n, first_global_index=0, n_total=None):
+        p = _c(pose, np.float64)
+        self._chk(self.lib.mcl_init_particles_pose(self._h, _p(p), C.c_int64(n), C.c_int64(first_global_index),
+                                                   C.c_int64(n_total or n)), "mcl_init_particles_pose")
+        self.n = n
+
+    def init_global(self, n, first_global_index=0, n_total=None):
+        self._chk(self.lib.mcl_init_global(self._h, C.c_int64(n), C.c_int64(first_global_index), C.c_int64(n_total or n)),
+                  "mcl_init_global")
+        self.n = n
+
+    def update_scan(self, action, ranges, angle_step):
+        a, r = _c(action, np.float64), _c(ranges, np.float32)
+        self._chk(self.lib.mcl_update_scan(self._h, _p(a), _p(r), C.c_int32(r.size), C.c_int32(angle_step)), "mcl_update_scan")
 
     def get_particles(self):
         out = np.empty((3, self.n), np.float64)

@@ -580,6 +580,49 @@ void orc_eng_philox_normals(uint64_t seed, uint32_t upd, int64_t first, int64_t 
     }
 }
 
+/* device-side initialisers (engine spec): Philox streams 5/6 and 7; out is N x 3 column-major */
+void orc_eng_init_pose(uint64_t seed, uint32_t init_idx, const double pose[3], int64_t first, int64_t n, double *out)
+{
+    const double TWO_M53 = 1.0 / 9007199254740992.0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t o[4];
+        uint64_t g = (uint64_t)(first + i);
+        orc_eng_philox4x32((uint32_t)g, init_idx, 5u, (uint32_t)(g >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        double u1 = (double)(bits53(o[0], o[1]) + 1) * TWO_M53, u2 = (double)bits53(o[2], o[3]) * TWO_M53;
+        double rad = sqrt(-2.0 * log(u1));
+        double n0 = rad * cos(2.0 * M_PI * u2), n1 = rad * sin(2.0 * M_PI * u2);
+        orc_eng_philox4x32((uint32_t)g, init_idx, 6u, (uint32_t)(g >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        u1 = (double)(bits53(o[0], o[1]) + 1) * TWO_M53; u2 = (double)bits53(o[2], o[3]) * TWO_M53;
+        double n2 = sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+        out[i] = pose[0] + n0 * 0.5;                      /* cpp:392 */
+        out[n + i] = pose[1] + n1 * 0.5;                  /* cpp:393 */
+        out[2 * n + i] = orc_normalize_angle(pose[2] + n2 * 0.4);   /* cpp:394-397 */
+    }
+}
+
+int orc_eng_init_global(uint64_t seed, uint32_t init_idx, const orc_map_t *m, int64_t first, int64_t n, double *out)
+{
+    /* permissible_positions in the reference's order (cpp:412-421): rows outer, columns inner, data == 0 */
+    size_t cells = (size_t)m->width * m->height, nf = 0;
+    uint32_t *fr = (uint32_t *)malloc(cells * sizeof(uint32_t));
+    for (size_t i = 0; i < cells; ++i) if (m->data[i] == 0) fr[nf++] = (uint32_t)i;
+    if (!nf) { free(fr); return -1; }
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t o[4];
+        uint64_t g = (uint64_t)(first + i);
+        orc_eng_philox4x32((uint32_t)g, init_idx, 7u, (uint32_t)(g >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        uint64_t k = bits53(o[0], o[1]);
+        uint64_t pick = (uint64_t)(((u128)(k << 11) * (u128)nf) >> 64);
+        uint32_t cell = fr[pick];
+        int row = (int)(cell / (uint32_t)m->width), col = (int)(cell % (uint32_t)m->width);
+        out[i] = col * m->resolution + m->origin_x;       /* cpp:438 */
+        out[n + i] = row * m->resolution + m->origin_y;   /* cpp:439 */
+        out[2 * n + i] = (double)bits53(o[2], o[3]) * (1.0 / 9007199254740992.0) * (2.0 * M_PI);   /* cpp:431,440 */
+    }
+    free(fr);
+    return 0;
+}
+
 /* Chebyshev distance-to-stop field on the padded grid, restated naively
  * for cross-checking the engine's host-side builder on small maps.
  * Padded grid: (W+1+pad_hi) x (H+1+pad_hi) ... see python wrapper; here we only give the

@@ -324,6 +324,20 @@ def eng_philox_normals(seed, upd, first, n):
     return out.reshape(n, 3)
 
 
+def eng_init_pose(seed, init_idx, pose, first, n):
+    out = np.empty((3, n), np.float64)
+    lib().orc_eng_init_pose(C.c_uint64(seed), C.c_uint32(init_idx), _p(_c(pose, np.float64)), C.c_int64(first), C.c_int64(n), _p(out))
+    return out
+
+
+def eng_init_global(seed, init_idx, m: OracleMap, first, n):
+    out = np.empty((3, n), np.float64)
+    rc = lib().orc_eng_init_global(C.c_uint64(seed), C.c_uint32(init_idx), m.ref, C.c_int64(first), C.c_int64(n), _p(out))
+    if rc:
+        raise RuntimeError("no free cells")
+    return out
+
+
 def eng_chebyshev_bruteforce(stop, cap):
     stop = _c(stop, np.uint8)
     Hp, Wp = stop.shape

@@ -305,3 +305,63 @@ def test_error_codes(orc, engine_mod, sibal1):
         e.ray_steps()
     with pytest.raises(engine_mod.EngineError):       # invalid resolution (cpp:236-240)
         e.set_map(sibal1.data, 0.0, 0.0, 0.0)
+
+
+# ------------------------------------------------------------------------------------------- §8(f) next rows
+def test_device_init_global_bit_exact(orc, engine_mod, spielberg, spielberg_oracle, sibal1, sibal1_oracle):
+    """initialize_global on the device (cpp:401-446 with Philox draws): cell choice, position arithmetic
+    and angle are integer/one-rounding operations -> bit-exact vs the scalar restatement, incl. a sharded
+    call (first_global_index)."""
+    for m, om in ((spielberg, spielberg_oracle), (sibal1, sibal1_oracle)):
+        n = 10000
+        e = make_engine(engine_mod, m, orc.beam_angles(angle_step=120), n, seed=31337)
+        e.init_global(n)
+        want = orc.eng_init_global(31337, 0, om, 0, n)
+        got = e.get_particles()
+        assert np.array_equal(got, want)
+        assert np.array_equal(e.get_weights(), np.full(n, 1.0 / n))
+        # every particle sits on the lower-left corner of a free cell (cpp:438-439)
+        col = np.rint((got[0] - om.origin_x) / om.resolution).astype(int)
+        row = np.rint((got[1] - om.origin_y) / om.resolution).astype(int)
+        assert (m.data[row, col] == 0).all() and (got[2] >= 0).all() and (got[2] < 2 * np.pi).all()
+        e.init_global(n // 2, first_global_index=n // 2, n_total=n)        # second call: init counter 1, upper shard
+        want2 = orc.eng_init_global(31337, 1, om, n // 2, n // 2)
+        assert np.array_equal(e.get_particles(), want2)
+        assert np.array_equal(e.get_weights(), np.full(n // 2, 2.0 / n))   # shard-normalised view of 1/n_total
+
+
+def test_device_init_pose(orc, engine_mod, sibal1):
+    n = 20000
+    e = make_engine(engine_mod, sibal1, orc.beam_angles(angle_step=120), n, seed=99)
+    pose = (2.0, 1.5, 3.0)
+    e.init_particles_pose(pose, n)
+    want = orc.eng_init_pose(99, 0, pose, 0, n)
+    got = e.get_particles()
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13)        # Box-Muller: device libm vs glibc
+    assert abs(got[0].std() - 0.5) < 0.02 and abs(got[1].std() - 0.5) < 0.02 and (np.abs(got[2]) <= np.pi).all()
+    np.testing.assert_allclose(e.expected_pose()[:2], got[:2].mean(axis=1), atol=1e-12)
+    e.update((0.05, 0.0, 0.01), np.full(e.n_beams, 2.0, np.float32))   # usable state
+
+
+def test_update_scan_downsamples_like_lidarcb(orc, engine_mod, spielberg):
+    """mcl_update_scan(raw 1081 ranges, angle_step) == mcl_update(ranges[::angle_step]) (cpp:316-320)."""
+    raw = load("scan_Spielberg_map_origin.npz")["ranges"].copy()
+    raw[5] = np.inf; raw[23] = np.nan; raw[90] = 40.0
+    rng = np.random.default_rng(8)
+    n = 3000
+    p = tracking_cloud(rng, n)
+    outs = []
+    for use_raw in (False, True):
+        e = make_engine(engine_mod, spielberg, orc.beam_angles(angle_step=18), n, seed=5)
+        e.set_particles(p, np.full(n, 1.0 / n))
+        if use_raw:
+            e.update_scan(ACTION, raw, 18)
+        else:
+            e.update(ACTION, raw[::18].copy())
+        outs.append((e.get_particles(), e.get_weights(), e.log_weights()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    e = make_engine(engine_mod, spielberg, orc.beam_angles(angle_step=18), n)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    with pytest.raises(engine_mod.EngineError):
+        e.update_scan(ACTION, raw, 17)                 # beam count mismatch
