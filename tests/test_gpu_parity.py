@@ -365,3 +365,48 @@ def test_update_scan_downsamples_like_lidarcb(orc, engine_mod, spielberg):
     e.set_particles(p, np.full(n, 1.0 / n))
     with pytest.raises(engine_mod.EngineError):
         e.update_scan(ACTION, raw, 17)                 # beam count mismatch
+
+
+@pytest.mark.parametrize("mapname", ["Spielberg_map", "sibal1", "icra_2_clean", "first_map"])
+@pytest.mark.parametrize("max_range,n_beams_step", [(12.0, 7), (5.0, 13), (3.3, 31)])
+def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_range, n_beams_step):
+    """Every fixture map, three MAX_RANGE_PX values, global clouds (free cells) plus particles inside walls
+    and outside the map: steps and log-weights bit-exact vs the oracle through the default kernel."""
+    m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{mapname}.npz"))
+    om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y, max_range_m=max_range)
+    from monte_carlo_localization_amd import synth
+    ang = orc.beam_angles(angle_step=n_beams_step)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{mapname}{n_beams_step}".encode()))
+    n = 1500
+    p = synth.global_cloud(rng, m, n)
+    p[:2, :100] += rng.normal(0, 3.0, (2, 100))           # some land in walls / outside the map
+    e = make_engine(engine_mod, m, ang, n, keep_ray_steps=1, max_range_m=max_range, squash_factor=3.1)
+    assert e.max_range_px == om.max_range_px
+    e.set_particles(p, np.full(n, 1.0 / n))
+    obs = rng.uniform(0.0, max_range * 1.2, ang.size).astype(np.float32)
+    e.sensor_update(obs)
+    T = orc.sensor_table(om.max_range_px)
+    assert np.array_equal(e.sensor_table(), T)
+    L = orc.eng_log_table(T, 1.0 / 3.1)
+    logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+    assert np.array_equal(e.ray_steps(), steps)
+    assert np.array_equal(e.log_weights(), logw)
+
+
+def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle):
+    """Window partly outside the map (lower-left corner): out-of-map cells must read as stops, and the
+    truncation-toward-zero column/row (pixel coordinates in (-1,0)) must read cell 0."""
+    om = sibal1_oracle
+    ang = orc.beam_angles(angle_step=3)
+    rng = np.random.default_rng(21)
+    n = 2000
+    p = np.stack([om.origin_x + rng.uniform(-0.2, 1.0, n), om.origin_y + rng.uniform(-0.2, 1.0, n), rng.uniform(-np.pi, np.pi, n)])
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    obs = np.full(ang.size, 1.0, np.float32)
+    e.sensor_update(obs)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+    assert np.array_equal(e.ray_steps(), steps)
+    assert e.counters()["off_window_particles"] == 0
