@@ -64,6 +64,7 @@ struct mcl_engine {
     double *d_x[2]{}, *d_y[2]{}, *d_th[2]{};
     int cur = 0;
     double *d_w = nullptr, *d_logw = nullptr, *d_tmp = nullptr;   // tmp: cap*3 doubles
+    double *d_logw_acc = nullptr;       // k_rays_quad/far/fix accumulate here with atomics; k_gather_logw copies to d_logw
     uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
     int32_t *d_idx = nullptr;
     uint8_t *d_steps = nullptr;
@@ -72,7 +73,16 @@ struct mcl_engine {
     double *d_scalars = nullptr;        // 8
     unsigned long long *d_counters = nullptr;  // 4
     double *d_inject = nullptr;         // cap*4 (normals + uniforms)
-    double4 *d_pc = nullptr;            // cap: per-particle constants for k_rays_skip
+    double4 *d_pc = nullptr;            // cap: per-particle constants for k_rays_skip / k_rays_quad
+    short4 *d_qr = nullptr;             // cap: per-particle quadrant ranges (k_rays_quad)
+    bool quad_ok = false;               // beam angles monotone over less than a full turn
+    int qside = 0;                      // k_rays_quad window side (0: not usable for this map)
+    unsigned long long *d_fix_list = nullptr, *d_fix_count = nullptr, *d_fix_over = nullptr;
+    unsigned long long fix_cap = 0, fix_alloc = 0;
+    size_t fix_count_alloc = 0;
+    int fix_segments = 0;
+    uint8_t *d_far = nullptr;           // cap * 4 flags
+    bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     double h_scalars[8]{};
     uint64_t q_total = 0;
     double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
@@ -81,6 +91,7 @@ struct mcl_engine {
     double timings[6]{};
     double ray_ms = 0;
     unsigned long long h_counters[4]{};
+    unsigned long long h_fix_count = 0;
 };
 
 namespace {
@@ -278,7 +289,7 @@ int fetch_scalars(mcl_engine *h)
     return MCL_OK;
 }
 
-int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n)
+int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n, bool force_skip = false)
 {
     mcl::RayArgs a{};
     a.x = x; a.y = y; a.th = th; a.n = n;
@@ -293,12 +304,19 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.tw_cells = h->tw_cells;
     a.counters = h->d_counters;
     a.force_exact = h->cfg.debug_force_exact;
-    int mode = h->cfg.ray_kernel == MCL_RAYS_MARCH ? 1 : 2;
+    // kernel choice: QUAD needs monotone beams over less than a turn and a map whose MAX_RANGE_PX leaves room
+    // for a useful cloud extent in an 80 KB byte window (two workgroups per CU)
+    int mode = 2;
+    h->last_quad = false;
+    if (h->cfg.ray_kernel == MCL_RAYS_MARCH) mode = 1;
+    else if (h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_AUTO) mode = (h->quad_ok && h->qside > 0) ? 3 : 2;
+    if (force_skip && mode == 3) mode = 2;
+    if (h->cfg.ray_kernel == MCL_RAYS_QUAD && mode != 3) return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD not usable with this map / beam set");
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
     if (mode != 1)
         hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
-                           h->res, h->d_pc);
+                           h->res, h->d_pc, h->d_angle, h->B, mode == 3 ? h->d_qr : nullptr);
     const bool count = h->cfg.debug_count_probes != 0;
     size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
     dim3 g(grid), b(mcl::kRayThreads);
@@ -307,6 +325,60 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     if (mode == 1) {
         if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
         else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
+    } else if (mode == 3) {
+        // work list for undecided rays (~0.1 % of the rays in practice): one private segment per workgroup of
+        // k_rays_quad, 1/16 of that workgroup's rays (at least 2048 entries)
+        const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16));
+        const int nseg = (int)std::min<int64_t>(2 * (int64_t)h->num_cu, 4 * (int64_t)nsl);   // one segment per persistent workgroup
+        unsigned long long segcap = std::max<unsigned long long>(2048, ((unsigned long long)n * h->B / nseg / 16 + 7) & ~7ull);
+        if ((unsigned long long)nseg * segcap > h->fix_alloc) {
+            dfree(h->d_fix_list);
+            HIPCHK(h, hipMalloc(&h->d_fix_list, (size_t)nseg * segcap * 8));
+            h->fix_alloc = (unsigned long long)nseg * segcap;
+        }
+        if ((size_t)nseg > h->fix_count_alloc) {
+            dfree(h->d_fix_count);
+            HIPCHK(h, hipMalloc(&h->d_fix_count, (size_t)nseg * 64));
+            h->fix_count_alloc = nseg;
+        }
+        h->fix_cap = segcap;
+        h->fix_segments = nseg;
+        a.qr = h->d_qr;
+        a.qside = h->qside;
+        a.nslices = nsl;
+        a.fix_list = h->d_fix_list; a.fix_count = h->d_fix_count; a.fix_cap = h->fix_cap; a.fix_segments = nseg;
+        a.far_flags = h->d_far;
+        a.work_counter = h->d_fix_over + 1;                // second word of the 16-byte scratch block
+        a.logw = h->d_logw_acc;
+        HIPCHK(h, hipMemsetAsync(h->d_logw_acc, 0, (size_t)n * sizeof(double), h->stream));   // partial sums are added atomically
+        HIPCHK(h, hipMemsetAsync(h->d_far, 0, (size_t)n * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_fix_count, 0, (size_t)nseg * 64, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_fix_over, 0, 16, h->stream));
+        size_t qlds = (size_t)h->qside * h->qside;
+        dim3 qg((unsigned)std::min<int64_t>(2 * (int64_t)h->num_cu, 4 * (int64_t)a.nslices));   // persistent: 2 workgroups per CU
+        unsigned long long *d_dbg = nullptr;
+        const char *dbgpath = getenv("MCL_DEBUG_WG");
+        if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
+        if (count) {
+            hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_far<true>), g, b, 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
+        } else {
+            hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_far<false>), g, b, 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
+        }
+        hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
+        if (d_dbg) {
+            std::vector<unsigned long long> hd((size_t)qg.x * 4);
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipMemcpy(hd.data(), d_dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(dbgpath, "wb")) { fwrite(hd.data(), 8, hd.size(), f); fclose(f); }
+            (void)hipFree(d_dbg);
+        }
+        h->last_quad = true;
     } else if (count) {
         hipLaunchKernelGGL((mcl::k_rays_skip<1, true>), g, b, lds, h->stream, a);
     } else {
@@ -429,6 +501,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
         CRT(hipMalloc(&h->d_x[b], nb)); CRT(hipMalloc(&h->d_y[b], nb)); CRT(hipMalloc(&h->d_th[b], nb));
     }
     CRT(hipMalloc(&h->d_w, nb)); CRT(hipMalloc(&h->d_logw, nb)); CRT(hipMalloc(&h->d_tmp, nb * 3));
+    CRT(hipMalloc(&h->d_logw_acc, nb));
     CRT(hipMalloc(&h->d_q, (size_t)h->cap * 8)); CRT(hipMalloc(&h->d_cdf, (size_t)h->cap * 8));
     h->blocktot_capacity = (size_t)h->cap / mcl::kScanTile + 2;
     CRT(hipMalloc(&h->d_blocktot, h->blocktot_capacity * 8));
@@ -438,6 +511,10 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_counters, 4 * sizeof(unsigned long long)));
     CRT(hipMalloc(&h->d_inject, nb * 4));
     CRT(hipMalloc(&h->d_pc, (size_t)h->cap * sizeof(double4)));
+    CRT(hipMalloc(&h->d_qr, (size_t)h->cap * sizeof(short4)));
+    CRT(hipMalloc(&h->d_far, (size_t)h->cap * 4));
+    CRT(hipMalloc(&h->d_fix_over, 16));
+    CRT(hipMemset(h->d_fix_over, 0, 16));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
     CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -445,6 +522,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #undef CRT
     *out = h;
     return MCL_OK;
@@ -456,8 +535,8 @@ void mcl_destroy(mcl_engine_t *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
-    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc);
+    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
@@ -482,6 +561,9 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     h->Wp = h->W + 1; h->Hp = h->H + 1; h->Wps = (h->Wp + 7) & ~7;
     // LDS window: as large as 160 KiB allows (nibbles), multiple of 8 cells
     h->tw_cells = 568;
+    // k_rays_quad: byte window of side S in half the LDS (S*S <= 80 KiB, S % 8 == 0); usable when the extent
+    // budget S - (P+2) - 3 is at least 48 cells, otherwise k_rays_skip's full-LDS nibble window is used
+    { const char *qs = getenv("MCL_QSIDE"); int S = qs ? atoi(qs) : 280; h->qside = (S - (P + 2) - 3 >= 16) ? S : 0; }
     build_sensor_table(h->cfg, P, h->table);
     const int tw = P + 1;
     std::vector<float> L((size_t)tw * tw);
@@ -538,6 +620,10 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     if (!angles || n_beams <= 0 || n_beams > 65536) return fail(h, MCL_ERR_INVALID_ARG, "bad beam angles");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->B = n_beams; h->bpad = (n_beams + 63) & ~63;
+    h->quad_ok = n_beams < 16384;
+    for (int j = 1; j < n_beams && h->quad_ok; ++j)
+        if (!(angles[j] > angles[j - 1])) h->quad_ok = false;
+    if (h->quad_ok && !((double)angles[n_beams - 1] - (double)angles[0] < 2.0 * M_PI - 1e-3)) h->quad_ok = false;
     h->angles.assign(angles, angles + n_beams);
     const int ncs = (n_beams + 255) & ~255;           // padded so that k_rays_skip never clamps its beam index
     std::vector<double2> cs(ncs);
@@ -767,8 +853,23 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
     rc = fetch_scalars(h);                 // synchronises the stream
     if (rc) return rc;
+    if (h->last_quad && h->h_fix_count != 0) {
+        // more undecided rays than the work list holds (only with debug_force_exact at large sizes or a
+        // pathological map): redo the ray stage with the self-contained k_rays_skip
+        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+        rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, true);
+        if (rc) return rc;
+        rc = sensor_and_weights(h, nullptr);
+        if (rc) return rc;
+        rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        rc = fetch_scalars(h);
+        if (rc) return rc;
+    }
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
     if (resample_and_move) h->update_idx++;
@@ -979,7 +1080,18 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->last_quad && h->h_fix_count != 0) {     // see do_update
+        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+        rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
+        hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
     h->update_idx++;

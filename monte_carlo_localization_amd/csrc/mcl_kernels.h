@@ -296,6 +296,16 @@ __global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restric
 struct RayArgs {
     const double *x, *y, *th;      // particles (this launch's)
     const double4 *pc;             // per particle (cos th, sin th, (x-ox)/res, (y-oy)/res), k_particle_prep
+    const short4 *qr;              // per particle quadrant ranges of its beams (k_rays_quad), k_particle_prep
+    int qside;                     // k_rays_quad: window side in cells (1 byte per cell)
+    int nslices;                   // k_rays_quad: particle slices; grid = 4 * nslices
+    unsigned long long *fix_list;  // k_rays_quad -> k_rays_fix: (particle << 16 | beam) of undecided rays
+    unsigned long long *fix_count; // per workgroup of k_rays_quad (stride 8 words): entries appended (> fix_cap: overflow)
+    unsigned long long fix_cap;    // capacity of one workgroup's segment
+    int fix_segments;              // number of segments = workgroups of k_rays_quad
+    uint8_t *far_flags;            // [particle][quadrant]: pair does not fit its quadrant window -> k_rays_far
+    unsigned long long *work_counter;  // k_rays_quad: next (slice, quadrant) item
+    unsigned long long *dbg;       // optional [workgroup][4]: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID
     int64_t n;
     int B, bpad, P;
     const double2 *beam_cs;        // (cos a_j, sin a_j) of (double)angle_f32[j], host fp64
@@ -336,15 +346,42 @@ constexpr int kRayWaves = kRayThreads / 64;
 
 // per-particle constants of the skipping march, computed once by one lane instead of by all 64 lanes
 // of the wave that owns the particle
+// k_rays_quad assigns a ray to the quadrant floor((theta + a_j) / (pi/2)) of its direction.  Beam angles
+// increase monotonically over less than a full turn (checked at mcl_set_beam_angles), so the beams of one
+// particle fall into at most five contiguous index ranges with quadrants q0, q0+1, ..., q0+4 (mod 4).
+// qr = (start of ranges 1..4, B when absent); q0 is packed into the top two bits of .x.
+__device__ __forceinline__ int beam_turns(double th, float angle) { return (int)floor((th + (double)angle) * 0.63661977236758134308); }
+
 __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ th, int64_t n, double ox, double oy, double res,
-                                                      double4 *__restrict__ pc)
+                                                      double4 *__restrict__ pc, const float *__restrict__ beam_angle, int B,
+                                                      short4 *__restrict__ qr)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double t = th[i];
     double s, c;
-    sincos(th[i], &s, &c);
+    sincos(t, &s, &c);
     pc[i] = make_double4(c, s, (x[i] - ox) / res, (y[i] - oy) / res);
+    if (qr) {
+        short st[4];
+        int q0 = 0;
+        if (t == t && fabs(t) < 1e6) {
+            const int k0 = beam_turns(t, beam_angle[0]);
+            q0 = k0 & 3;
+            for (int k = 1; k <= 4; ++k) {
+                int lo = 0, hi = B;              // first j with turns(j) - turns(0) >= k
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (beam_turns(t, beam_angle[mid]) - k0 >= k) hi = mid; else lo = mid + 1;
+                }
+                st[k - 1] = (short)lo;
+            }
+        } else {
+            st[0] = st[1] = st[2] = st[3] = (short)B;   // garbage heading: one range, handled by the fallback paths
+        }
+        qr[i] = make_short4((short)(st[0] | (q0 << 14)), st[1], st[2], st[3]);
+    }
 }
 
 // D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
@@ -675,6 +712,358 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
             if (cnt_off) atomicAdd(&a.counters[1], cnt_off);
             if (cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
             if (cnt_l2) atomicAdd(&a.counters[3], cnt_l2);
+        }
+    }
+}
+
+// ---- K3c: quadrant windows, one byte per cell (MCL_RAYS_QUAD) -------------------------------------
+//
+// Same algorithm and the same three precision levels as k_rays_skip, with the work split by ray
+// direction: workgroup (slice, q) handles, for the particles of its slice, the beams whose direction lies
+// in quadrant q.  Those rays only ever move away from the particle in x and in y, so the window needs
+// MAX_RANGE_PX cells on ONE side of the cloud per axis: a (P + extent)^2 window with a whole byte per
+// cell fits half the LDS of a CU.  Two effects: the probe block loses the nibble decode (10 VALU
+// instead of 13) and two 1024-thread workgroups are resident per CU (8 waves per SIMD instead of 4), which
+// hides the LDS round trip of the dependent probe chain.  To run at 64 VGPRs without spills the hot
+// kernel contains level 1 only:
+//   * a ray with a sample too close to a cell boundary is appended to a device work list and resolved by
+//     k_rays_fix (levels 2 and 3 on the global field);
+//   * a (particle, quadrant) pair that does not fit the window is flagged and handled by k_rays_far
+//     (the global-field path of k_rays_skip restricted to that quadrant's beams).
+// All three kernels add their partial log-weights with fp64 atomics, which is exact and order-independent
+// here (every term is a multiple of 2^-24 and the sums stay below 2^13).
+constexpr int kQFx = 22;                 // same fixed point as k_rays_skip (|U| <= 2^22 fits v_mad_i32_i24)
+constexpr uint32_t kQG1 = 132u;          // (1 + s)/2 <= 128 units for s <= 255
+constexpr int kQLdsBase = 16;            // the window follows 16 bytes of static LDS (the work-item slot)
+
+// beams of particle i in quadrant q: range [ja, jb) and, when the first quadrant is visited twice, [ja2, B)
+__device__ __forceinline__ void quad_ranges(short4 qr, int q, int B, int &ja, int &jb, int &ja2)
+{
+    const int st1 = qr.x & 0x3FFF, st2 = qr.y, st3 = qr.z, st4 = qr.w, q0 = ((int)qr.x >> 14) & 3;
+    const int r_idx = (q - q0) & 3;
+    ja = r_idx == 0 ? 0 : (r_idx == 1 ? st1 : (r_idx == 2 ? st2 : st3));
+    jb = r_idx == 0 ? st1 : (r_idx == 1 ? st2 : (r_idx == 2 ? st3 : st4));
+    ja2 = r_idx == 0 ? st4 : B;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int item_sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long dbg_t0 = 0, cnt_probe = 0;
+    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    const int64_t per = (a.n + a.nslices - 1) / a.nslices;
+    const int nitems = 4 * a.nslices;
+    // the probe block addresses the window with raw LDS offsets (ds_read_u8 ... offset:kQLdsBase)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
+    // Persistent workgroups (2 per CU) pull (slice, quadrant) items from a device-side queue: quadrants carry
+    // very different numbers of beams (a 270-degree scan puts ~360 beams in two quadrants and ~180 in the
+    // other two), and a static grid of one workgroup per item kept only half of the slots busy (measured).
+    for (;;) {
+    __syncthreads();                                    // every wave is done with the previous window
+    if (threadIdx.x == 0) item_sh = (int)atomicAdd(a.work_counter, 1ull);
+    __syncthreads();
+    const int item = item_sh;
+    if (item >= nitems) break;
+    // heavy quadrants are not known in advance; rotate so that consecutive items differ in quadrant
+    const int slice = item >> 2;
+    const int q = ((item & 3) + (item >> 3)) & 3;
+    const int64_t p_begin = (int64_t)slice * per;
+    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
+    if (p_begin >= p_end) continue;
+    const int sxp = (q == 0 || q == 3), syp = (q == 0 || q == 1);   // rays move toward +x / +y ?
+
+    const int S = a.qside;
+    const int mlo = 3;                                  // cells kept behind the particle (truncation column + guard)
+    int wx0, wy0;
+    {
+        double *red = reinterpret_cast<double *>(lds_raw);
+        double sx = 0.0, sy = 0.0;
+        for (int64_t i = p_begin + threadIdx.x; i < p_end; i += kRayThreads) {
+            double4 c = a.pc[i];
+            double gx = c.z, gy = c.w;
+            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
+        __syncthreads();
+        double mx = 0.0, my = 0.0;
+        for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
+        int64_t cntp = p_end - p_begin;
+        mx /= (double)cntp; my /= (double)cntp;
+        // the cloud may extend E/2 on either side of its mean; the rays add P+2 cells on the forward side
+        const int E = S - (a.P + 2) - mlo;
+        const int back = E / 2 + mlo;
+        int cxm = (int)floor(mx) + 1, cym = (int)floor(my) + 1;          // padded coordinates
+        wx0 = sxp ? cxm - back : cxm + back - S;
+        wy0 = syp ? cym - back : cym + back - S;
+        wx0 &= ~7;                                       // 8-byte aligned loads of the field
+        __syncthreads();
+        uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
+        const int wpr = S >> 3;                          // 8 cells per 64-bit word
+        const int nwords = wpr * S;
+        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
+            int row = wi / wpr, cw = wi - row * wpr;
+            int gy = wy0 + row, gx = wx0 + cw * 8;
+            uint64_t b8 = 0;
+            if (gy >= 0 && gy < a.Hp && gx >= 0 && gx < a.Wps) b8 = *reinterpret_cast<const uint64_t *>(a.dist + (size_t)gy * a.Wps + gx);
+            win[wi] = b8;
+        }
+        __syncthreads();
+    }
+    uint32_t stride_v = (uint32_t)S, gbias_v = kQG1 << (32 - kQFx);
+    asm volatile("" : "+v"(stride_v), "+v"(gbias_v));
+    const unsigned char *ldsb = lds_raw;
+    const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : ((2u * kQG1) << (32 - kQFx));
+
+    for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
+        int ja, jb, ja2;
+        quad_ranges(a.qr[i], q, a.B, ja, jb, ja2);
+        if (ja >= jb && ja2 >= a.B) continue;
+        const double4 pci = a.pc[i];
+        const double wpx = pci.z - (double)(wx0 - 1);     // window-relative padded coordinate
+        const double wpy = pci.w - (double)(wy0 - 1);
+        const double fwd = (double)(a.P + 2), bwd = 2.0;
+        const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
+        const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
+        if (!(inx && iny)) {                               // not in this window (or NaN): k_rays_far does this pair
+            if (lane == 0) atomicOr(reinterpret_cast<unsigned int *>(a.far_flags) + i, 1u << (8 * q));
+            continue;
+        }
+        // the particle's own cell gives a first skip shared by all its beams; if the particle itself sits
+        // within 2^-30 px of a cell boundary all of its rays go to the fix-up list
+        const double p0x = wpx + kMagic, p0y = wpy + kMagic;
+        const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+        const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
+        const int d0 = ldsb[cy0 * S + cx0];
+        const int s0 = d0 > 1 ? d0 : 1;
+        const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
+        const uint32_t P0x = (uint32_t)rint_i32(wpx * 4194304.0 - 2147483648.0) + 0x80000000u;   // rint(wpx*2^22) mod 2^32
+        const uint32_t P0y = (uint32_t)rint_i32(wpy * 4194304.0 - 2147483648.0) + 0x80000000u;
+        const int rem_start = s0 <= a.P ? a.P - s0 : 0;
+        const double ncth = -pci.x * 4194304.0, sths = pci.y * 4194304.0;
+        double acc = 0.0;
+        for (int seg = 0; seg < 2; ++seg)
+        for (int j0 = seg ? ja2 : ja, je = seg ? a.B : jb; j0 < je; j0 += 64) {
+            const int j = j0 + lane;                       // beam_cs is padded by 256 entries
+            const bool valid = j < je;
+            const double2 cs = a.beam_cs[j];
+            const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
+            const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
+            const uint32_t Pex = mad_i24(-a.P, NUx, P0x), Pey = mad_i24(-a.P, NUy, P0y);
+            int rem = valid ? rem_start : 0;
+            uint32_t g = g0, byte;
+            bool go;
+            do {
+                uint32_t Tx, Ty, t0, t1, addr;
+                asm volatile(
+                    "v_mad_i32_i24 %[tx], %[rem], %[nux], %[pex]\n\t"
+                    "v_mad_i32_i24 %[ty], %[rem], %[nuy], %[pey]\n\t"
+                    "v_lshrrev_b32 %[t0], 22, %[tx]\n\t"                    // cx
+                    "v_lshrrev_b32 %[t1], 22, %[ty]\n\t"                    // cy
+                    "v_mad_u32_u24 %[ad], %[t1], %[str], %[t0]\n\t"         // byte offset = cy * S + cx
+                    "ds_read_u8 %[by], %[ad] offset:%[lb]\n\t"              // + LDS offset of the window
+                    "v_lshl_add_u32 %[t0], %[tx], 10, %[gb]\n\t"            // biased fractions in the top 22 bits
+                    "v_lshl_add_u32 %[t1], %[ty], 10, %[gb]\n\t"
+                    "v_min3_u32 %[g], %[g], %[t0], %[t1]\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "+v"(g)
+                    : [rem] "v"(rem), [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v),
+                      [gb] "v"(gbias_v), [lb] "n"(kQLdsBase)
+                    : "memory");
+                uint32_t nr;
+                bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);   // skip > samples left
+                go = !over && byte != 0;
+                rem = (int)nr;                                                  // unchanged on a stop
+                if (COUNT) cnt_probe += go ? 1 : 0;
+            } while (go);
+            if (COUNT && valid) ++cnt_probe;
+            const bool amb = valid && g < gthresh;
+            if (valid && !amb) {
+                const int r = (byte == 0) ? a.P - rem - 1 : a.P;
+                acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+            }
+            if (amb) {
+                // append to THIS workgroup's segment of the fix-up list (segments are private to a workgroup;
+                // counters and entries are only ever touched by device-scope atomics, which execute at the
+                // memory side and are therefore coherent across the XCDs' L2s)
+                const unsigned long long slot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
+                if (slot < a.fix_cap)
+                    atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + slot], ((unsigned long long)i << 16) | (unsigned long long)j);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(&a.logw[i], acc);
+    }
+    }   // work items
+    if (COUNT && a.counters) {
+        cnt_probe = wave_sum_u64(cnt_probe);
+        if (lane == 0 && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
+    }
+    if (a.dbg) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long *d = a.dbg + (size_t)blockIdx.x * 4;
+            d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime();
+            d[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+            d[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        }
+    }
+}
+
+// Levels 2 and 3 for the rays k_rays_quad could not decide: one thread per listed ray, fp64 positions on the
+// global byte field (padded global coordinates shifted by 2^18), then the literal march if still ambiguous.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
+{
+    unsigned long long cnt_exact = 0, cnt_probe = 0, cnt_l2 = 0;
+    // one workgroup of this kernel drains the segments seg = blockIdx.x, blockIdx.x + gridDim.x, ...
+    for (int seg = blockIdx.x; seg < a.fix_segments; seg += gridDim.x) {
+    // the counters were updated by memory-side atomics: read them the same way (a cached copy may be stale)
+    unsigned long long n = 0;
+    if (threadIdx.x == 0) n = atomicAdd(&a.fix_count[(size_t)seg * 8], 0ull);
+    n = __shfl((long long)n, 0, 64);
+    {
+        __shared__ unsigned long long n_sh;
+        if (threadIdx.x == 0) n_sh = n;
+        __syncthreads();
+        n = n_sh;
+        __syncthreads();
+    }
+    if (n > a.fix_cap) n = a.fix_cap;                      // overflow: the host re-runs the stage with k_rays_skip
+    cnt_l2 += (threadIdx.x == 0) ? n : 0;
+    const unsigned long long *list = a.fix_list + (size_t)seg * a.fix_cap;
+    for (unsigned long long k = threadIdx.x; k < n; k += blockDim.x) {
+        const unsigned long long e = atomicAdd(const_cast<unsigned long long *>(&list[k]), 0ull);
+        const int64_t i = (int64_t)(e >> 16);
+        const int j = (int)(e & 0xFFFF);
+        const double4 pci = a.pc[i];
+        const double2 cs = a.beam_cs[j];
+        const double ux = pci.x * cs.x - pci.y * cs.y, uy = pci.y * cs.x + pci.x * cs.y;
+        const bool sane = (pci.z > -200000.0) && (pci.z < 200000.0) && (pci.w > -200000.0) && (pci.w < 200000.0);
+        const double p0x = (pci.z + 1.0 + 262144.0) + kMagic, p0y = (pci.w + 1.0 + 262144.0) + kMagic;
+        const int base = kCellBase + 262144;
+        int r = a.P;
+        uint32_t amb = 0;
+        unsigned np = 0;
+        if (sane) {
+            const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+            const int cx = (__double2hiint(p0x) & 0xFFFFF) - base, cy = (__double2hiint(p0y) & 0xFFFFF) - base;
+            amb = lox < loy ? lox : loy;
+            const int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+            r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, d > 1 ? d : 1, amb, np);
+        }
+        if (!sane || amb < kGuard || a.force_exact == 1) {
+            r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
+            ++cnt_exact;
+        }
+        atomicAdd(&a.logw[i], (double)a.Lt[(size_t)r * a.bpad + j]);
+        if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+        if (COUNT) cnt_probe += np;
+    }
+    }
+    if (a.counters) {
+        if (cnt_exact) atomicAdd(&a.counters[0], cnt_exact);
+        if (COUNT && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
+        if (cnt_l2) atomicAdd(&a.counters[3], cnt_l2);
+    }
+}
+
+// log-weights accumulated with memory-side fp64 atomics must be read back the same way: a plain load may be
+// served from an L2 line cached before the atomics ran.  acc -> plain array for the rest of the pipeline.
+__global__ void k_gather_logw(double *__restrict__ acc, int64_t n, double *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = atomicAdd(&acc[i], 0.0);
+}
+
+// overflow flag of the fix-up list: *over = number of segments whose append count exceeded the capacity
+__global__ void k_fix_overflow(const unsigned long long *__restrict__ counts, int nseg, unsigned long long cap, unsigned long long *over)
+{
+    __shared__ unsigned int s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    unsigned int c = 0;
+    for (int k = threadIdx.x; k < nseg; k += blockDim.x)
+        c += atomicAdd(const_cast<unsigned long long *>(&counts[(size_t)k * 8]), 0ull) > cap ? 1u : 0u;
+    if (c) atomicAdd(&s, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *over = s;
+}
+
+// (particle, quadrant) pairs outside their quadrant window: the global-field path, one wave per particle.
+template <bool COUNT>
+__global__ __launch_bounds__(kRayThreads) void k_rays_far(RayArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
+    const int64_t p_begin = (int64_t)blockIdx.x * per;
+    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
+    unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0;
+    const uint32_t *flags32 = reinterpret_cast<const uint32_t *>(a.far_flags);
+    for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
+        const uint32_t fl = flags32[i];
+        if (fl == 0) continue;
+        if (lane == 0) ++cnt_off;
+        const double4 pci = a.pc[i];
+        const double cth = pci.x, sth = pci.y, gpx = pci.z, gpy = pci.w;
+        const bool sane = (gpx > -200000.0) && (gpx < 200000.0) && (gpy > -200000.0) && (gpy < 200000.0);
+        const double p0x = (gpx + 1.0 + 262144.0) + kMagic, p0y = (gpy + 1.0 + 262144.0) + kMagic;
+        const int base = kCellBase + 262144;
+        uint32_t amb0 = 0;
+        int s0 = 1;
+        if (sane) {
+            uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+            int cx = (__double2hiint(p0x) & 0xFFFFF) - base, cy = (__double2hiint(p0y) & 0xFFFFF) - base;
+            amb0 = lox < loy ? lox : loy;
+            int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+            s0 = d > 1 ? d : 1;
+        }
+        const short4 qr = a.qr[i];
+        double acc = 0.0;
+        for (int q = 0; q < 4; ++q) {
+            if (((fl >> (8 * q)) & 0xFFu) == 0) continue;
+            int ja, jb, ja2;
+            quad_ranges(qr, q, a.B, ja, jb, ja2);
+            for (int seg = 0; seg < 2; ++seg)
+            for (int j0 = seg ? ja2 : ja, je = seg ? a.B : jb; j0 < je; j0 += 64) {
+                int j = j0 + lane;
+                if (j < je) {
+                    int r = a.P;
+                    unsigned np = 0;
+                    uint32_t amb = amb0;
+                    if (sane) {
+                        double2 cs = a.beam_cs[j];
+                        double ux = cth * cs.x - sth * cs.y;
+                        double uy = sth * cs.x + cth * cs.y;
+                        r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, s0, amb, np);
+                    }
+                    if (!sane || amb < kGuard || a.force_exact == 1) {
+                        r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
+                        ++cnt_exact;
+                    }
+                    acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                    if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                    if (COUNT) cnt_probe += np;
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(&a.logw[i], acc);
+    }
+    if (a.counters) {
+        cnt_exact = wave_sum_u64(cnt_exact);
+        cnt_off = wave_sum_u64(cnt_off);
+        cnt_probe = wave_sum_u64(cnt_probe);
+        if (lane == 0) {
+            if (cnt_exact) atomicAdd(&a.counters[0], cnt_exact);
+            if (cnt_off) atomicAdd(&a.counters[1], cnt_off);
+            if (COUNT && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
         }
     }
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmcl_hip_engine.so")
 MCL_OK = 0
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 WEIGHT_LOG, WEIGHT_PRODUCT = 0, 1
-RAYS_AUTO, RAYS_MARCH, RAYS_SKIP = 0, 1, 2
+RAYS_AUTO, RAYS_MARCH, RAYS_SKIP, RAYS_QUAD = 0, 1, 2, 3
 BUF_X, BUF_Y, BUF_THETA, BUF_QWEIGHT, BUF_LOGW, BUF_SCALARS = range(6)
 
 EXPORTS = [

@@ -7,7 +7,8 @@ from conftest import make_engine, tracking_cloud
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kernel", ["march", "skip", "skip_forced_exact", "skip_forced_level2"])
+@pytest.mark.parametrize("kernel", ["march", "skip", "skip_forced_exact", "skip_forced_level2", "quad", "quad_forced_exact",
+                                    "quad_forced_level2"])
 def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_oracle, kernel):
     om = spielberg_oracle
     ang = orc.beam_angles(angle_step=9)       # 121 beams
@@ -16,10 +17,10 @@ def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_o
     N = 777
     p = tracking_cloud(rng, N)
     cfg = dict(keep_ray_steps=1, debug_count_probes=1)
-    cfg["ray_kernel"] = engine_mod.RAYS_MARCH if kernel == "march" else engine_mod.RAYS_SKIP
-    if kernel == "skip_forced_exact":
+    cfg["ray_kernel"] = {"m": engine_mod.RAYS_MARCH, "s": engine_mod.RAYS_SKIP, "q": engine_mod.RAYS_QUAD}[kernel[0]]
+    if kernel.endswith("forced_exact"):
         cfg["debug_force_exact"] = 1
-    if kernel == "skip_forced_level2":
+    if kernel.endswith("forced_level2"):
         cfg["debug_force_exact"] = 2
     e = make_engine(engine_mod, spielberg, ang, N, **cfg)
     e.set_particles(p, np.full(N, 1.0 / N))
@@ -31,11 +32,11 @@ def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_o
     assert np.array_equal(got, steps), f"{(got != steps).sum()} of {steps.size} ray steps differ"
     assert np.array_equal(e.log_weights(), logw)          # exact fp64 sums of fp32 entries
     c = e.counters()
-    if kernel == "skip_forced_exact":
+    if kernel.endswith("forced_exact"):
         assert c["exact_fallback_rays"] == N * ang.size
-    if kernel == "skip_forced_level2":
+    if kernel.endswith("forced_level2"):
         assert c["level2_rays"] == N * ang.size and c["exact_fallback_rays"] < N * ang.size // 1000
-    if kernel == "skip":
+    if kernel in ("skip", "quad"):
         # level 1 hands only a small fraction of rays to level 2, and level 2 almost none to level 3
         assert c["level2_rays"] < N * ang.size // 100 and c["exact_fallback_rays"] < N * ang.size // 10000
         assert 0 < c["probes"] < probes

@@ -35,14 +35,14 @@ def test_sensor_table_bit_exact(request, orc, engine_mod, mapname, P):
 
 # ------------------------------------------------------------------------------------------- C (G2)
 @pytest.mark.parametrize("name", ["Spielberg_map", "sibal1"])
-@pytest.mark.parametrize("kernel", ["march", "skip", "skip_l2"])
+@pytest.mark.parametrize("kernel", ["march", "skip", "skip_l2", "auto"])
 def test_cast_ray_golden(orc, engine_mod, maps_mod, name, kernel):
     """One particle per golden ray, a single beam at angle 0: step index == fixture (incl. rays that
     start outside the map, inside walls, within a cell of the lower/left edge, axis-aligned)."""
     m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{name}.npz"))
     z = load(f"g2_cast_ray_{name}.npz")
     n = z["x"].size
-    rk = engine_mod.RAYS_MARCH if kernel == "march" else engine_mod.RAYS_SKIP
+    rk = {"march": engine_mod.RAYS_MARCH, "auto": engine_mod.RAYS_AUTO}.get(kernel, engine_mod.RAYS_SKIP)
     e = make_engine(engine_mod, m, np.zeros(1, np.float32), n, keep_ray_steps=1, ray_kernel=rk,
                     debug_force_exact=2 if kernel == "skip_l2" else 0)
     e.set_particles(np.stack([z["x"], z["y"], z["theta"]]), np.full(n, 1.0 / n))
