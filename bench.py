@@ -181,7 +181,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_rays_skip_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -199,7 +199,7 @@ def main():
                        "particles_total": n * world, "beams": B,
                        "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_rays_skip<1,false>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": e.ray_kernel_name(),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar,
                          "note": "algorithmic (effective) bytes per SURVEY 8(d); real HBM traffic is far lower because "
                                  "the grid window lives in LDS and the kernel skips empty space; it is VALU/LDS-bound"},

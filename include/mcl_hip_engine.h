@@ -164,6 +164,8 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
 /* duration (ms) of the dominant kernel (ray cast + likelihood) in the last update, measured
  * with HIP events on the engine's own stream */
 int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
+/* which ray kernel the last update ran: 1 k_rays_march, 2 k_rays_skip, 3 k_rays_quad */
+int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel);
 
 /* ---- host-side precomputation, callable without a device (what mcl_set_map uploads) --------- */
 /* (P+1)^2 doubles, Eigen column-major (index d*(P+1)+r): the restatement of precompute_sensor_model

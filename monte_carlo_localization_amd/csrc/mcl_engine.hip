@@ -23,7 +23,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_COUNT };
+enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_K0, EV_K1, EV_COUNT };   // K0..K1 bracket the dominant kernel
 
 }  // namespace
 
@@ -83,6 +83,8 @@ struct mcl_engine {
     int fix_segments = 0;
     uint8_t *d_far = nullptr;           // cap * 4 flags
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
+    int last_mode = 0;                  // 1 march, 2 skip, 3 quad
+    bool far_heavy = false;             // last update: more than a quarter of the particles missed a window
     double h_scalars[8]{};
     uint64_t q_total = 0;
     double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
@@ -311,7 +313,11 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     if (h->cfg.ray_kernel == MCL_RAYS_MARCH) mode = 1;
     else if (h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_AUTO) mode = (h->quad_ok && h->qside > 0) ? 3 : 2;
     if (force_skip && mode == 3) mode = 2;
-    if (h->cfg.ray_kernel == MCL_RAYS_QUAD && mode != 3) return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD not usable with this map / beam set");
+    // global re-localisation: when most (particle, quadrant) pairs missed their window last time the
+    // self-contained k_rays_skip (global-field path inline) is the faster kernel
+    if (mode == 3 && h->cfg.ray_kernel == MCL_RAYS_AUTO && h->far_heavy) mode = 2;
+    if (h->cfg.ray_kernel == MCL_RAYS_QUAD && mode != 3 && !force_skip)
+        return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD not usable with this map / beam set");
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
     if (mode != 1)
@@ -322,15 +328,22 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     dim3 g(grid), b(mcl::kRayThreads);
     int R = h->cfg.rays_per_lane;
     if (R <= 0) R = 1;   // measured on MI355X: the kernel is VALU-issue-bound, extra chains per lane only add idle slots
+    if (mode != 3) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
     if (mode == 1) {
         if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
         else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
     } else if (mode == 3) {
         // work list for undecided rays (~0.1 % of the rays in practice): one private segment per workgroup of
         // k_rays_quad, 1/16 of that workgroup's rays (at least 2048 entries)
-        const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16));
+        const char *ns_env = getenv("MCL_QSLICES_PER_CU");
+        // item granularity: 32 slices per CU (measured best at 4M: 4/8/16/32/64 -> 22.1/20.2/19.7/19.6/20.2 ms), but at
+        // least 256 particles per slice so that the 78 KB window load stays amortised
+        const int spc = ns_env ? atoi(ns_env) : 32;
+        const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
         const int nseg = (int)std::min<int64_t>(2 * (int64_t)h->num_cu, 4 * (int64_t)nsl);   // one segment per persistent workgroup
-        unsigned long long segcap = std::max<unsigned long long>(2048, ((unsigned long long)n * h->B / nseg / 16 + 7) & ~7ull);
+        unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
+        unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 16 + 7) & ~7ull);
+        if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
         if ((unsigned long long)nseg * segcap > h->fix_alloc) {
             dfree(h->d_fix_list);
             HIPCHK(h, hipMalloc(&h->d_fix_list, (size_t)nseg * segcap * 8));
@@ -359,13 +372,16 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = getenv("MCL_DEBUG_WG");
         if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
+        HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
             hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
+            HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<true>), g, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         } else {
             hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
+            HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<false>), g, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
@@ -389,6 +405,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         default: hipLaunchKernelGGL((mcl::k_rays_skip<4, false>), g, b, lds, h->stream, a); break;
         }
     }
+    if (mode != 3) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+    h->last_mode = mode;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -563,7 +581,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     h->tw_cells = 568;
     // k_rays_quad: byte window of side S in half the LDS (S*S <= 80 KiB, S % 8 == 0); usable when the extent
     // budget S - (P+2) - 3 is at least 48 cells, otherwise k_rays_skip's full-LDS nibble window is used
-    { const char *qs = getenv("MCL_QSIDE"); int S = qs ? atoi(qs) : 280; h->qside = (S - (P + 2) - 3 >= 16) ? S : 0; }
+    { const char *qs = getenv("MCL_QSIDE"); int S = qs ? atoi(qs) : 280; h->qside = (S - (P + 2) - 3 >= 32) ? S : 0; }
     build_sensor_table(h->cfg, P, h->table);
     const int tw = P + 1;
     std::vector<float> L((size_t)tw * tw);
@@ -856,6 +874,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
     rc = fetch_scalars(h);                 // synchronises the stream
     if (rc) return rc;
+    h->far_heavy = h->h_counters[1] * 4 > (unsigned long long)n;
     if (h->last_quad && h->h_fix_count != 0) {
         // more undecided rays than the work list holds (only with debug_force_exact at large sizes or a
         // pathological map): redo the ray stage with the self-contained k_rays_skip
@@ -879,7 +898,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
     h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
     h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    h->ray_ms = h->timings[3];
+    h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
     return MCL_OK;
 }
 
@@ -967,6 +986,13 @@ int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms)
 {
     if (!h || !ms) return MCL_ERR_INVALID_ARG;
     *ms = h->ray_ms;
+    return MCL_OK;
+}
+
+int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel)
+{
+    if (!h || !kernel) return MCL_ERR_INVALID_ARG;
+    *kernel = h->last_mode;
     return MCL_OK;
 }
 
@@ -1082,6 +1108,7 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->far_heavy = h->h_counters[1] * 4 > (unsigned long long)n;
     if (h->last_quad && h->h_fix_count != 0) {     // see do_update
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
         rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n, true);
@@ -1099,7 +1126,7 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     h->timings[1] = 0.0;
     h->timings[2] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_QUERY]);
     h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
-    h->ray_ms = h->timings[3];
+    h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
     return MCL_OK;
 }
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
-    "mcl_update_scan",
+    "mcl_update_scan", "mcl_get_ray_kernel_id",
 ]
 
 
@@ -261,6 +261,11 @@ class Engine:
         v = C.c_double()
         self._chk(self.lib.mcl_get_ray_kernel_ms(self._h, C.byref(v)), "mcl_get_ray_kernel_ms")
         return v.value
+
+    def ray_kernel_name(self):
+        v = C.c_int32()
+        self._chk(self.lib.mcl_get_ray_kernel_id(self._h, C.byref(v)), "mcl_get_ray_kernel_id")
+        return {1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad"}.get(v.value, "?")
 
     # -- multi-GPU staging (raw device pointers as ints)
     def device_ptr(self, which) -> int:
