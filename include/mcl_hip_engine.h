@@ -174,6 +174,9 @@ int mcl_host_sensor_table(const mcl_config_t *cfg, int32_t max_range_px, double 
 /* Skip-distance field of DESIGN.md §4.2 on the padded grid: (height+1) x (width+1) bytes, row-major,
  * 0 = stop cell, otherwise how many samples the fixed-step march may advance from a sample in that cell. */
 int mcl_host_skip_field(const int8_t *data, uint32_t width, uint32_t height, uint8_t *out, size_t n);
+/* Same for rays whose direction lies in `quadrant` (0:+x+y 1:-x+y 2:-x-y 3:+x-y): only stop cells a ray of that
+ * quadrant can still reach bound the jump. */
+int mcl_host_skip_field_dir(const int8_t *data, uint32_t width, uint32_t height, int32_t quadrant, uint8_t *out, size_t n);
 
 /* ---- multi-GPU staging (one engine per rank; collectives are the host's) -- */
 /* Device pointers of engine-owned buffers so the host can hand them to RCCL without copies. */

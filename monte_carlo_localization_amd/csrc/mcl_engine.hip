@@ -41,6 +41,7 @@ struct mcl_engine {
     std::vector<double> table;          // (P+1)^2 column-major (d*(P+1)+r)
     int8_t *d_grid = nullptr;
     uint8_t *d_dist = nullptr;
+    uint8_t *d_distq[4]{};              // directional skip fields, one per quadrant (k_rays_quad / k_rays_far)
     float *d_L = nullptr;               // [r_obs][d]
     double *d_table = nullptr;          // double table (product mode)
 
@@ -225,6 +226,75 @@ void build_distance_field(const int8_t *grid, int W, int H, int Wp, int Hp, int 
     }
 }
 
+// Directional skip field for k_rays_quad, quadrant q = (sx, sy): a ray whose direction has sign sx in x and sy
+// in y can only ever enter cells t with sx*(t_x - c_x) >= 0 and sy*(t_y - c_y) >= 0, so only those stop cells
+// bound the jump: skip_q(c) = floor(min over forward stop cells t of gap(c, t)) + 1, gap as in
+// build_distance_field.  Walls beside or behind a ray no longer shorten its jumps (-30 % probes on the
+// benchmark input).  Exact integer arithmetic: per row the forward x-gap h to the next stop, then per column
+// a one-sided squared distance transform (lower envelope of parabolas, sources only ahead of the query).
+void build_directional_field(const int8_t *grid, int W, int H, int Wp, int Hp, int Wps, int sx, int sy, std::vector<uint8_t> &dist)
+{
+    const int64_t INF = (int64_t)1 << 40;
+    // stop(xf, yf) in "forward" coordinates: xf = sx > 0 ? xp : Wp-1-xp, same for y
+    auto stop_at = [&](int xf, int yf) -> bool {
+        int xp = sx > 0 ? xf : Wp - 1 - xf, yp = sy > 0 ? yf : Hp - 1 - yf;
+        int gx = std::max(xp - 1, 0), gy = std::max(yp - 1, 0);
+        return grid[(size_t)gy * W + gx] > 50;
+    };
+    // h[yf][xf]: gap in x to the nearest stop at x' >= xf in the same row (the cell just outside the grid is a stop)
+    std::vector<int32_t> h((size_t)(Hp + 1) * Wp);
+    for (int yf = 0; yf < Hp; ++yf) {
+        int nxt = Wp;
+        for (int xf = Wp - 1; xf >= 0; --xf) {
+            if (stop_at(xf, yf)) nxt = xf;
+            h[(size_t)yf * Wp + xf] = std::max(nxt - xf - 1, 0);
+        }
+    }
+    for (int xf = 0; xf < Wp; ++xf) h[(size_t)Hp * Wp + xf] = 0;      // the row beyond the grid is all stop
+    dist.assign((size_t)Hp * Wps, 0);
+    std::vector<int> vp(Hp + 2);          // envelope: source positions (in r = decreasing-y order)
+    std::vector<double> z(Hp + 3);
+    std::vector<int64_t> hg(Hp + 2);      // heights of the sources
+    for (int xf = 0; xf < Wp; ++xf) {
+        // g2(yf) = min( h(yf)^2 , min over p >= yf of (p - yf)^2 + h(p+1)^2 ): sources p = Hp-1 .. 0 arrive in
+        // decreasing p, i.e. increasing r = Hp-1-p; the query sits at the newest source's position.
+        int k = -1;
+        for (int yf = Hp - 1; yf >= 0; --yf) {
+            const int r = Hp - 1 - yf;
+            const int64_t hv = h[(size_t)(yf + 1) * Wp + xf];
+            const int64_t fh = hv * hv;
+            // insert parabola (r, fh)
+            while (true) {
+                if (k < 0) { k = 0; vp[0] = r; hg[0] = fh; z[0] = -1e30; z[1] = 1e30; break; }
+                double sI = ((double)(fh + (int64_t)r * r) - (double)(hg[k] + (int64_t)vp[k] * vp[k])) / (2.0 * r - 2.0 * vp[k]);
+                if (sI <= z[k]) { --k; continue; }
+                ++k; vp[k] = r; hg[k] = fh; z[k] = sI; z[k + 1] = 1e30;
+                break;
+            }
+            // query at r: the parabola whose interval contains r
+            int kk = k;
+            while (z[kk] > (double)r) --kk;
+            int64_t dq = (int64_t)(r - vp[kk]);
+            int64_t g2 = dq * dq + hg[kk];
+            // exactness of the envelope near interval ends: also try the neighbours
+            if (kk > 0) { int64_t d2 = (int64_t)(r - vp[kk - 1]); g2 = std::min(g2, d2 * d2 + hg[kk - 1]); }
+            if (kk < k) { int64_t d2 = (int64_t)(r - vp[kk + 1]); g2 = std::min(g2, d2 * d2 + hg[kk + 1]); }
+            const int64_t hs = h[(size_t)yf * Wp + xf];
+            g2 = std::min(g2, hs * hs);
+            int val = 0;
+            if (!stop_at(xf, yf)) {
+                int64_t rt = (int64_t)std::sqrt((double)g2);
+                while (rt * rt > g2) --rt;
+                while ((rt + 1) * (rt + 1) <= g2) ++rt;
+                val = (int)std::min<int64_t>(rt + 1, 255);
+            }
+            int xp = sx > 0 ? xf : Wp - 1 - xf, yp = sy > 0 ? yf : Hp - 1 - yf;
+            dist[(size_t)yp * Wps + xp] = (uint8_t)val;
+        }
+    }
+    (void)INF; (void)H;
+}
+
 // cpp:452-471
 void motion_scalars(const double action[3], double &dt, double &v, double &w)
 {
@@ -303,6 +373,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.grid = h->d_grid; a.W = h->W; a.H = h->H;
     a.res = h->res; a.ox = h->ox; a.oy = h->oy;
     a.dist = h->d_dist; a.Wp = h->Wp; a.Hp = h->Hp; a.Wps = h->Wps;
+    for (int q = 0; q < 4; ++q) a.distq[q] = h->d_distq[q];
     a.tw_cells = h->tw_cells;
     a.counters = h->d_counters;
     a.force_exact = h->cfg.debug_force_exact;
@@ -556,6 +627,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
+    for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
@@ -591,12 +663,22 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     std::vector<uint8_t> dist;
     build_distance_field(data, h->W, h->H, h->Wp, h->Hp, h->Wps, dist);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
+    for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     HIPCHK(h, hipMalloc(&h->d_grid, (size_t)h->W * h->H));
     HIPCHK(h, hipMalloc(&h->d_dist, dist.size()));
     HIPCHK(h, hipMalloc(&h->d_L, L.size() * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->d_table, h->table.size() * sizeof(double)));
     HIPCHK(h, hipMemcpy(h->d_grid, data, (size_t)h->W * h->H, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_dist, dist.data(), dist.size(), hipMemcpyHostToDevice));
+    if (h->qside > 0) {
+        static const int qsx[4] = {1, -1, -1, 1}, qsy[4] = {1, 1, -1, -1};
+        std::vector<uint8_t> dq;
+        for (int q = 0; q < 4; ++q) {
+            build_directional_field(data, h->W, h->H, h->Wp, h->Hp, h->Wps, qsx[q], qsy[q], dq);
+            HIPCHK(h, hipMalloc(&h->d_distq[q], dq.size()));
+            HIPCHK(h, hipMemcpy(h->d_distq[q], dq.data(), dq.size(), hipMemcpyHostToDevice));
+        }
+    }
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
     h->lt_capacity = 0; dfree(h->d_Lt);
@@ -1002,6 +1084,18 @@ int mcl_host_sensor_table(const mcl_config_t *cfg, int32_t P, double *out, size_
     std::vector<double> t;
     build_sensor_table(*cfg, P, t);
     std::memcpy(out, t.data(), n * sizeof(double));
+    return MCL_OK;
+}
+
+int mcl_host_skip_field_dir(const int8_t *data, uint32_t width, uint32_t height, int32_t quadrant, uint8_t *out, size_t n)
+{
+    if (!data || !out || width == 0 || height == 0 || quadrant < 0 || quadrant > 3 || n != (size_t)(width + 1) * (height + 1))
+        return MCL_ERR_INVALID_ARG;
+    static const int qsx[4] = {1, -1, -1, 1}, qsy[4] = {1, 1, -1, -1};
+    const int Wp = (int)width + 1, Hp = (int)height + 1, Wps = (Wp + 7) & ~7;
+    std::vector<uint8_t> d;
+    build_directional_field(data, (int)width, (int)height, Wp, Hp, Wps, qsx[quadrant], qsy[quadrant], d);
+    for (int y = 0; y < Hp; ++y) std::memcpy(out + (size_t)y * Wp, d.data() + (size_t)y * Wps, Wp);
     return MCL_OK;
 }
 

@@ -317,6 +317,7 @@ struct RayArgs {
     const int8_t *grid; int W, H;
     double res, ox, oy;
     const uint8_t *dist;           // padded distance field Hp x Wps bytes (0 = stop), cap 255
+    const uint8_t *distq[4];       // directional fields per quadrant (k_rays_quad, k_rays_far)
     int Wp, Hp, Wps;
     int tw_cells;                  // LDS window side (multiple of 8)
     unsigned long long *counters;  // [0] exact-fallback rays, [1] particles off-window, [2] probes
@@ -803,13 +804,14 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
         wx0 &= ~7;                                       // 8-byte aligned loads of the field
         __syncthreads();
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
+        const uint8_t *fieldq = a.distq[q];              // only stops a quadrant-q ray can reach bound its jumps
         const int wpr = S >> 3;                          // 8 cells per 64-bit word
         const int nwords = wpr * S;
         for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
             int row = wi / wpr, cw = wi - row * wpr;
             int gy = wy0 + row, gx = wx0 + cw * 8;
             uint64_t b8 = 0;
-            if (gy >= 0 && gy < a.Hp && gx >= 0 && gx < a.Wps) b8 = *reinterpret_cast<const uint64_t *>(a.dist + (size_t)gy * a.Wps + gx);
+            if (gy >= 0 && gy < a.Hp && gx >= 0 && gx < a.Wps) b8 = *reinterpret_cast<const uint64_t *>(fieldq + (size_t)gy * a.Wps + gx);
             win[wi] = b8;
         }
         __syncthreads();

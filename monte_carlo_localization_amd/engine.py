@@ -27,7 +27,7 @@ EXPORTS = [
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
-    "mcl_update_scan", "mcl_get_ray_kernel_id",
+    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir",
 ]
 
 
@@ -105,6 +105,17 @@ def host_skip_field(grid) -> np.ndarray:
     rc = load_library().mcl_host_skip_field(_p(g), C.c_uint32(W), C.c_uint32(H), _p(out), C.c_size_t(out.size))
     if rc != MCL_OK:
         raise EngineError(f"mcl_host_skip_field rc={rc}")
+    return out
+
+
+def host_skip_field_dir(grid, quadrant: int) -> np.ndarray:
+    """Directional skip field for rays of one direction quadrant (0:+x+y 1:-x+y 2:-x-y 3:+x-y)."""
+    g = _c(grid, np.int8)
+    H, W = g.shape
+    out = np.empty((H + 1, W + 1), np.uint8)
+    rc = load_library().mcl_host_skip_field_dir(_p(g), C.c_uint32(W), C.c_uint32(H), C.c_int32(quadrant), _p(out), C.c_size_t(out.size))
+    if rc != MCL_OK:
+        raise EngineError(f"mcl_host_skip_field_dir rc={rc}")
     return out
 
 

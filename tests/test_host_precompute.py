@@ -65,3 +65,53 @@ def test_skip_field_safety_property_bruteforce(engine_mod, orc):
     # it dominates the Chebyshev field used by the first version of the kernel
     D = ndimage.distance_transform_cdt(~np.pad(S, 1, constant_values=True), metric="chessboard")[1:-1, 1:-1]
     assert (skip >= np.minimum(D, 255)).all()
+
+
+def brute_directional(grid, q):
+    """skip_q(c) = floor(min gap(c,t)) + 1 over stop cells t a quadrant-q ray can still reach
+    (sx*(tx-cx) >= 0 and sy*(ty-cy) >= 0), everything outside the padded grid being a stop."""
+    sx, sy = [(1, 1), (-1, 1), (-1, -1), (1, -1)][q]
+    S = padded_stops(grid)
+    Hp, Wp = S.shape
+    pad = max(Hp, Wp) + 2
+    Sb = np.pad(S, pad, constant_values=True)
+    ys, xs = np.nonzero(Sb)
+    ys = ys - pad; xs = xs - pad
+    out = np.zeros((Hp, Wp), np.int64)
+    for cy in range(Hp):
+        for cx in range(Wp):
+            if S[cy, cx]:
+                continue
+            m = (sx * (xs - cx) >= 0) & (sy * (ys - cy) >= 0)
+            dx = np.maximum(np.abs(xs[m] - cx) - 1, 0)
+            dy = np.maximum(np.abs(ys[m] - cy) - 1, 0)
+            g2 = int((dx * dx + dy * dy).min())
+            r = int(np.floor(np.sqrt(g2)))
+            while r * r > g2:
+                r -= 1
+            while (r + 1) * (r + 1) <= g2:
+                r += 1
+            out[cy, cx] = min(r + 1, 255)
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_directional_skip_fields_match_bruteforce(engine_mod, seed):
+    rng = np.random.default_rng(seed)
+    g = np.where(rng.random((28, 37)) < [0.03, 0.08, 0.2][seed], 100, 0).astype(np.int8)
+    g[rng.random(g.shape) < 0.05] = -1
+    iso = engine_mod.host_skip_field(g).astype(np.int64)
+    for q in range(4):
+        got = engine_mod.host_skip_field_dir(g, q).astype(np.int64)
+        want = brute_directional(g, q)
+        assert np.array_equal(got, want), (q, np.argwhere(got != want)[:5])
+        assert (got >= iso).all()                       # fewer constraints -> never a shorter jump
+    # the isotropic field is the minimum of the four directional ones
+    allq = np.minimum.reduce([engine_mod.host_skip_field_dir(g, q).astype(np.int64) for q in range(4)])
+    assert np.array_equal(allq, iso)
+
+
+def test_directional_field_on_real_map_region(engine_mod, sibal1):
+    sub = np.ascontiguousarray(sibal1.data[60:110, 100:160])
+    for q in range(4):
+        assert np.array_equal(engine_mod.host_skip_field_dir(sub, q).astype(np.int64), brute_directional(sub, q))
