@@ -85,7 +85,6 @@ struct mcl_engine {
     uint8_t *d_far = nullptr;           // cap * 4 flags
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad
-    bool far_heavy = false;             // last update: more than a quarter of the particles missed a window
     double h_scalars[8]{};
     uint64_t q_total = 0;
     double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
@@ -384,9 +383,6 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     if (h->cfg.ray_kernel == MCL_RAYS_MARCH) mode = 1;
     else if (h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_AUTO) mode = (h->quad_ok && h->qside > 0) ? 3 : 2;
     if (force_skip && mode == 3) mode = 2;
-    // global re-localisation: when most (particle, quadrant) pairs missed their window last time the
-    // self-contained k_rays_skip (global-field path inline) is the faster kernel
-    if (mode == 3 && h->cfg.ray_kernel == MCL_RAYS_AUTO && h->far_heavy) mode = 2;
     if (h->cfg.ray_kernel == MCL_RAYS_QUAD && mode != 3 && !force_skip)
         return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD not usable with this map / beam set");
     int64_t want = (n + 15) / 16;
@@ -443,17 +439,19 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = getenv("MCL_DEBUG_WG");
         if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
+        // k_rays_far is bound by global-memory latency: 4 workgroups per CU worth of blocks (2 resident at a time)
+        dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
         HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
             hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
-            hipLaunchKernelGGL((mcl::k_rays_far<true>), g, b, 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         } else {
             hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
-            hipLaunchKernelGGL((mcl::k_rays_far<false>), g, b, 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         }
@@ -956,7 +954,6 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
     rc = fetch_scalars(h);                 // synchronises the stream
     if (rc) return rc;
-    h->far_heavy = h->h_counters[1] * 4 > (unsigned long long)n;
     if (h->last_quad && h->h_fix_count != 0) {
         // more undecided rays than the work list holds (only with debug_force_exact at large sizes or a
         // pathological map): redo the ray stage with the self-contained k_rays_skip
@@ -1202,7 +1199,6 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->far_heavy = h->h_counters[1] * 4 > (unsigned long long)n;
     if (h->last_quad && h->h_fix_count != 0) {     // see do_update
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
         rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n, true);

@@ -460,8 +460,9 @@ constexpr int kCellBase = 1 << 19;
 // fp64 skipping march of one ray, on the LDS nibble window (LDSWIN) or on the global byte field.
 template <bool LDSWIN, bool COUNT>
 __device__ __forceinline__ int trace_fp64(const RayArgs &a, const unsigned char *ldsb, int strideB, int base, double p0x, double p0y,
-                                          double ux, double uy, int s0, uint32_t &amb, unsigned &np)
+                                          double ux, double uy, int s0, uint32_t &amb, unsigned &np, const uint8_t *field = nullptr)
 {
+    const uint8_t *gf = field ? field : a.dist;
     int s = s0, r = a.P;
     if (s > a.P) return r;
     while (true) {
@@ -478,7 +479,7 @@ __device__ __forceinline__ int trace_fp64(const RayArgs &a, const unsigned char 
             uint32_t byte = ldsb[cy * strideB + (cx >> 1)];
             d = (byte >> ((cx & 1) * 4)) & 15;
         } else {
-            d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
+            d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? gf[(size_t)cy * a.Wps + cx] : 0;
         }
         if (COUNT) ++np;
         if (d == 0) { r = s - 1; break; }
@@ -999,7 +1000,7 @@ __global__ void k_fix_overflow(const unsigned long long *__restrict__ counts, in
 
 // (particle, quadrant) pairs outside their quadrant window: the global-field path, one wave per particle.
 template <bool COUNT>
-__global__ __launch_bounds__(kRayThreads) void k_rays_far(RayArgs a)
+__global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1018,18 +1019,21 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_far(RayArgs a)
         const double p0x = (gpx + 1.0 + 262144.0) + kMagic, p0y = (gpy + 1.0 + 262144.0) + kMagic;
         const int base = kCellBase + 262144;
         uint32_t amb0 = 0;
-        int s0 = 1;
+        int cx0 = 0, cy0 = 0;
+        bool in0 = false;
         if (sane) {
             uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
-            int cx = (__double2hiint(p0x) & 0xFFFFF) - base, cy = (__double2hiint(p0y) & 0xFFFFF) - base;
+            cx0 = (__double2hiint(p0x) & 0xFFFFF) - base; cy0 = (__double2hiint(p0y) & 0xFFFFF) - base;
             amb0 = lox < loy ? lox : loy;
-            int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
-            s0 = d > 1 ? d : 1;
+            in0 = (unsigned)cx0 < (unsigned)a.Wp && (unsigned)cy0 < (unsigned)a.Hp;
         }
         const short4 qr = a.qr[i];
         double acc = 0.0;
         for (int q = 0; q < 4; ++q) {
             if (((fl >> (8 * q)) & 0xFFu) == 0) continue;
+            const uint8_t *field = a.distq[q];               // directional field of this quadrant
+            const int d0 = in0 ? field[(size_t)cy0 * a.Wps + cx0] : 0;
+            const int s0 = d0 > 1 ? d0 : 1;
             int ja, jb, ja2;
             quad_ranges(qr, q, a.B, ja, jb, ja2);
             for (int seg = 0; seg < 2; ++seg)
@@ -1043,7 +1047,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_far(RayArgs a)
                         double2 cs = a.beam_cs[j];
                         double ux = cth * cs.x - sth * cs.y;
                         double uy = sth * cs.x + cth * cs.y;
-                        r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, s0, amb, np);
+                        r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, s0, amb, np, field);
                     }
                     if (!sane || amb < kGuard || a.force_exact == 1) {
                         r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
