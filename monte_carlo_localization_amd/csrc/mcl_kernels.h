@@ -802,7 +802,6 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
         int cxm = (int)floor(mx) + 1, cym = (int)floor(my) + 1;          // padded coordinates
         wx0 = sxp ? cxm - back : cxm + back - S;
         wy0 = syp ? cym - back : cym + back - S;
-        wx0 &= ~7;                                       // 8-byte aligned loads of the field
         __syncthreads();
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
         const uint8_t *fieldq = a.distq[q];              // only stops a quadrant-q ray can reach bound its jumps
@@ -812,8 +811,25 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
             int row = wi / wpr, cw = wi - row * wpr;
             int gy = wy0 + row, gx = wx0 + cw * 8;
             uint64_t b8 = 0;
-            if (gy >= 0 && gy < a.Hp && gx >= 0 && gx < a.Wps) b8 = *reinterpret_cast<const uint64_t *>(fieldq + (size_t)gy * a.Wps + gx);
-            win[wi] = b8;
+            if (gy >= 0 && gy < a.Hp) {
+                const uint8_t *rowp = fieldq + (size_t)gy * a.Wps;
+                if (gx >= 0 && gx + 8 <= a.Wps) {
+                    b8 = *reinterpret_cast<const uint64_t *>(rowp + gx);       // any byte alignment
+                } else {
+                    for (int k = 0; k < 8; ++k)
+                        if (gx + k >= 0 && gx + k < a.Wps) b8 |= (uint64_t)rowp[gx + k] << (8 * k);
+                }
+            }
+            // LDS encoding: stop (0) -> 255, skips capped at 254.  A stop then fails the single loop test
+            // "skip <= samples left" (samples left <= 254), which saves the compare with zero in the probe block.
+            uint64_t enc = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t v = (uint32_t)(b8 >> (8 * k)) & 0xFFu;
+                v = v == 0u ? 255u : (v == 255u ? 254u : v);
+                enc |= (uint64_t)v << (8 * k);
+            }
+            win[wi] = enc;
         }
         __syncthreads();
     }
@@ -841,8 +857,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
         const double p0x = wpx + kMagic, p0y = wpy + kMagic;
         const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
         const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
-        const int d0 = ldsb[cy0 * S + cx0];
-        const int s0 = d0 > 1 ? d0 : 1;
+        const int d0 = ldsb[cy0 * S + cx0];               // 255 = the particle sits in a stop cell
+        const int s0 = (d0 == 255 || d0 < 1) ? 1 : d0;
         const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
         const uint32_t P0x = (uint32_t)rint_i32(wpx * 4194304.0 - 2147483648.0) + 0x80000000u;   // rint(wpx*2^22) mod 2^32
         const uint32_t P0y = (uint32_t)rint_i32(wpy * 4194304.0 - 2147483648.0) + 0x80000000u;
@@ -854,15 +870,26 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
             const int j = j0 + lane;                       // beam_cs is padded by 256 entries
             const bool valid = j < je;
             const double2 cs = a.beam_cs[j];
-            const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
-            const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
+            // a padding lane (beam outside this range) gets a zero direction: it probes the particle's own cell,
+            // which is inside the window and never reads as 0, so it leaves the loop at once
+            const int NUx = valid ? rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y)) : 0;
+            const int NUy = valid ? rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x))) : 0;
             const uint32_t Pex = mad_i24(-a.P, NUx, P0x), Pey = mad_i24(-a.P, NUy, P0y);
             int rem = valid ? rem_start : 0;
-            uint32_t g = g0, byte;
-            bool go;
-            do {
+            uint32_t g = g0, byte = 0;
+            if (!COUNT) {
+                // The whole probe loop in one block: 9 VALU + 1 LDS read + 4 SALU per trip (the scalar unit is
+                // shared by the CU's four SIMDs and the compiler's loop bookkeeping made it the bottleneck).
+                // A lane leaves when the skip exceeds the samples left (always on a stop, encoded 255): the
+                // borrow of v_sub_co clears its exec bit; its rem/byte keep the values of its last probe.
+                // The scalar countdown only exists so that no LDS content whatsoever can make a wave spin.
                 uint32_t Tx, Ty, t0, t1, addr;
+                unsigned long long saved_exec;
+                uint32_t countdown;
                 asm volatile(
+                    "s_mov_b64 %[sv], exec\n\t"
+                    "s_movk_i32 %[cd], 300\n"
+                    "1:\n\t"
                     "v_mad_i32_i24 %[tx], %[rem], %[nux], %[pex]\n\t"
                     "v_mad_i32_i24 %[ty], %[rem], %[nuy], %[pey]\n\t"
                     "v_lshrrev_b32 %[t0], 22, %[tx]\n\t"                    // cx
@@ -872,22 +899,42 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
                     "v_lshl_add_u32 %[t0], %[tx], 10, %[gb]\n\t"            // biased fractions in the top 22 bits
                     "v_lshl_add_u32 %[t1], %[ty], 10, %[gb]\n\t"
                     "v_min3_u32 %[g], %[g], %[t0], %[t1]\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "+v"(g)
-                    : [rem] "v"(rem), [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v),
-                      [gb] "v"(gbias_v), [lb] "n"(kQLdsBase)
-                    : "memory");
-                uint32_t nr;
-                bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);   // skip > samples left
-                go = !over && byte != 0;
-                rem = (int)nr;                                                  // unchanged on a stop
-                if (COUNT) cnt_probe += go ? 1 : 0;
-            } while (go);
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_sub_co_u32 %[rem], vcc, %[rem], %[by]\n\t"           // samples left -= skip; borrow = done
+                    "s_andn2_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_execz 2f\n\t"
+                    "s_sub_u32 %[cd], %[cd], 1\n\t"
+                    "s_cbranch_scc0 1b\n"
+                    "2:\n\t"
+                    "s_mov_b64 exec, %[sv]"
+                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "+v"(byte), [g] "+v"(g),
+                      [rem] "+v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                    : [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v), [gb] "v"(gbias_v),
+                      [lb] "n"(kQLdsBase)
+                    : "memory", "vcc", "scc");
+                if (rem >= 0) g = 0u;                        // countdown expired (impossible with a well-formed window): fix-up list
+            } else {
+                bool go;
+                int trips = 0;
+                do {
+                    const uint32_t Tx = mad_i24(rem, NUx, Pex), Ty = mad_i24(rem, NUy, Pey);
+                    const uint32_t gx = (Tx << (32 - kQFx)) + gbias_v, gy = (Ty << (32 - kQFx)) + gbias_v;
+                    const uint32_t gm = gx < gy ? gx : gy;
+                    g = g < gm ? g : gm;
+                    byte = ldsb[(Ty >> kQFx) * (uint32_t)S + (Tx >> kQFx)];
+                    uint32_t nr;
+                    const bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);
+                    go = !over;
+                    rem = (int)nr;
+                    cnt_probe += go ? 1 : 0;
+                } while (go && ++trips <= 300);
+                if (go) g = 0u;
+            }
             if (COUNT && valid) ++cnt_probe;
             const bool amb = valid && g < gthresh;
             if (valid && !amb) {
-                const int r = (byte == 0) ? a.P - rem - 1 : a.P;
-                acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                const int r = (byte == 255u) ? a.P - (rem + 255) - 1 : a.P;
+                acc += (double)a.Lt[__mul24(r, a.bpad) + j];      // 32-bit index: (P+1) * bpad < 2^24
                 if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
             }
             if (amb) {
