@@ -70,6 +70,8 @@ struct mcl_engine {
     int32_t *d_idx = nullptr;
     uint8_t *d_steps = nullptr;
     size_t steps_capacity = 0, blocktot_capacity = 0;
+    const uint64_t *blocktot_for = nullptr;   // which CDF array d_blocktot currently describes
+    int64_t blocktot_n = 0;
     double *d_part = nullptr;           // kRedBlocks * 8
     double *d_scalars = nullptr;        // 8
     unsigned long long *d_counters = nullptr;  // 4
@@ -326,6 +328,7 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
     hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total);
     hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf);
     HIPCHK(h, hipGetLastError());
+    h->blocktot_for = d_cdf; h->blocktot_n = n;
     return MCL_OK;
 }
 
@@ -911,6 +914,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         mcl::ResampleArgs a{};
         a.px = h->d_x[c]; a.py = h->d_y[c]; a.pth = h->d_th[c];
         a.cdf = h->d_cdf; a.n_parents = n; a.q_total = h->q_total;
+        a.tile_excl = (h->blocktot_for == h->d_cdf && h->blocktot_n == n) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
         a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
         a.idx_out = h->d_idx;
         a.n_children = n; a.child_first = 0; a.n_children_total = n;
@@ -1164,6 +1168,7 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     const int nx = h->cur ^ 1;
     mcl::ResampleArgs a{};
     a.px = d_px; a.py = d_py; a.pth = d_pth; a.cdf = d_cdf; a.n_parents = n_parents; a.q_total = q_total;
+    a.tile_excl = (h->blocktot_for == d_cdf && h->blocktot_n == n_parents) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
     a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
     a.idx_out = h->d_idx;
     a.n_children = n; a.child_first = child_first; a.n_children_total = n_children_total;

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__r
 struct ResampleArgs {
     const double *px, *py, *pth;      // parents
     const uint64_t *cdf;              // inclusive CDF over parents
+    const uint64_t *tile_excl;        // exclusive prefix before each kScanTile-sized tile of the CDF (the scan's spine)
     int64_t n_parents;
     uint64_t q_total;
     double *cx, *cy, *cth;            // children out
@@ -158,7 +159,21 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 r0 = g * 4294967296ull + a.k0;
                 lmul = (uint64_t)a.n_children_total * 4294967296ull;
             }
+            // two-level search: first the tile (its exclusive prefixes are a small, cache-resident array left by the
+            // scan), then inside the tile's 16 KB of the CDF
             int64_t lo = 0, len = a.n_parents;
+            if (a.tile_excl) {
+                const int64_t ntiles = (a.n_parents + kScanTile - 1) / kScanTile;
+                int64_t tlo = 0, tlen = ntiles;           // first tile whose exclusive prefix exceeds the threshold
+                while (tlen > 0) {
+                    int64_t half = tlen >> 1, mid = tlo + half;
+                    if (!mul_gt(a.tile_excl[mid], lmul, r0, r1)) { tlo = mid + 1; tlen = tlen - half - 1; }
+                    else tlen = half;
+                }
+                const int64_t t = tlo > 0 ? tlo - 1 : 0;
+                lo = t * kScanTile;
+                len = (lo + kScanTile <= a.n_parents) ? kScanTile : a.n_parents - lo;
+            }
             while (len > 0) {
                 int64_t half = len >> 1, mid = lo + half;
                 if (!mul_gt(a.cdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
@@ -1056,9 +1071,15 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
     const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
     unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0;
     const uint32_t *flags32 = reinterpret_cast<const uint32_t *>(a.far_flags);
-    for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
-        const uint32_t fl = flags32[i];
-        if (fl == 0) continue;
+    // each wave scans 64 particles' flags with one coalesced load and visits only the flagged ones
+    for (int64_t i0 = p_begin + (int64_t)wave * 64; i0 < p_end; i0 += (int64_t)kRayWaves * 64) {
+      const uint32_t myfl = (i0 + lane < p_end) ? flags32[i0 + lane] : 0u;
+      unsigned long long todo = __ballot(myfl != 0u);
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t i = i0 + src;
+        const uint32_t fl = (uint32_t)__shfl((int)myfl, src, 64);
         if (lane == 0) ++cnt_off;
         const double4 pci = a.pc[i];
         const double cth = pci.x, sth = pci.y, gpx = pci.z, gpy = pci.w;
@@ -1108,6 +1129,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
         }
         acc = wave_sum(acc);
         if (lane == 0) atomicAdd(&a.logw[i], acc);
+      }
     }
     if (a.counters) {
         cnt_exact = wave_sum_u64(cnt_exact);
