@@ -403,8 +403,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
         else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
     } else if (mode == 3) {
-        // work list for undecided rays (~0.1 % of the rays in practice): one private segment per workgroup of
-        // k_rays_quad, 1/16 of that workgroup's rays (at least 2048 entries)
+        // work list for undecided rays (~0.06 % of the rays in practice): one segment per persistent workgroup of
+        // k_rays_quad with room for 1/256 of that workgroup's share of the rays (at least 2048 entries)
         const char *ns_env = getenv("MCL_QSLICES_PER_CU");
         // item granularity: 32 slices per CU (measured best at 4M: 4/8/16/32/64 -> 22.1/20.2/19.7/19.6/20.2 ms), but at
         // least 256 particles per slice so that the 78 KB window load stays amortised
@@ -412,7 +412,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
         const int nseg = (int)std::min<int64_t>(2 * (int64_t)h->num_cu, 4 * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
-        unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 16 + 7) & ~7ull);
+        unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 256 + 7) & ~7ull);
         if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
         if ((unsigned long long)nseg * segcap > h->fix_alloc) {
             dfree(h->d_fix_list);
