@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--regime", choices=["tracking", "global"], default="tracking")
     ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: gather the particle columns synchronously")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the sharded (torch.distributed/RCCL) path even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -138,7 +139,7 @@ def main():
     if use_dist:
         from monte_carlo_localization_amd.dist import ShardedFilter
         dev = torch.device("cuda", local_rank)
-        sf = ShardedFilter(e, n, dev)
+        sf = ShardedFilter(e, n, dev, overlap=not args.no_overlap)
 
         def step():
             sf.update(ACTION, scan)

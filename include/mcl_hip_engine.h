@@ -200,6 +200,16 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
                         const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
                         int64_t child_first, int64_t n_children_total,
                         const double action[3], const float *obs, int32_t n_beams);
+/* Stage 1 in two halves, so that the host can start gathering the children for the NEXT update while the
+ * ray kernel of this one runs: mcl_stage_resample returns when the children (resampled + moved) are final,
+ * mcl_stage_rays casts their rays and leaves the local max log-weight in SCALARS[0]. */
+int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth,
+                       const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
+                       int64_t child_first, int64_t n_children_total, const double action[3]);
+int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams);
+/* Leave n_cus compute units out of k_rays_quad's persistent grid (it otherwise occupies every CU for the
+ * whole kernel, which would serialise a collective launched beside it). */
+int mcl_set_reserved_cus(mcl_engine_t *h, int32_t n_cus);
 /* Stage 2: given the GLOBAL max log-weight, compute w, q and the local partial sums (SCALARS). */
 int mcl_stage_weights(mcl_engine_t *h, double global_max_logw);
 /* Stage 3: install the GLOBAL sums (sum w, wx, wy, wsin, wcos) so that get_weights /

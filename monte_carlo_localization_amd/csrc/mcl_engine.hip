@@ -87,6 +87,7 @@ struct mcl_engine {
     uint8_t *d_far = nullptr;           // cap * 4 flags
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad
+    int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
     double h_scalars[8]{};
     uint64_t q_total = 0;
     double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
@@ -410,7 +411,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // least 256 particles per slice so that the 78 KB window load stays amortised
         const int spc = ns_env ? atoi(ns_env) : 32;
         const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
-        const int nseg = (int)std::min<int64_t>(2 * (int64_t)h->num_cu, 4 * (int64_t)nsl);   // one segment per persistent workgroup
+        const int nseg = (int)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), 4 * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
         unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 256 + 7) & ~7ull);
         if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
@@ -438,7 +439,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         HIPCHK(h, hipMemsetAsync(h->d_fix_count, 0, (size_t)nseg * 64, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_fix_over, 0, 16, h->stream));
         size_t qlds = (size_t)h->qside * h->qside;
-        dim3 qg((unsigned)std::min<int64_t>(2 * (int64_t)h->num_cu, 4 * (int64_t)a.nslices));   // persistent: 2 workgroups per CU
+        dim3 qg((unsigned)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), 4 * (int64_t)a.nslices));   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = getenv("MCL_DEBUG_WG");
         if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
@@ -1152,15 +1153,12 @@ int mcl_get_scalars(mcl_engine_t *h, double out[8])
     return MCL_OK;
 }
 
-int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
-                        int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
-                        const double action[3], const float *obs, int32_t n_beams)
+int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
+                       int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total, const double action[3])
 {
-    const int obs_stride = 1;
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
-    if (!d_px || !d_py || !d_pth || !d_cdf || !action || !obs || n_beams != h->B || n_parents <= 0)
-        return fail(h, MCL_ERR_INVALID_ARG, "bad stage_propagate arguments");
+    if (!d_px || !d_py || !d_pth || !d_cdf || !action || n_parents <= 0) return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t n = h->N;
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
@@ -1191,37 +1189,62 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
     HIPCHK(h, hipGetLastError());
     h->cur = nx;
     h->have_idx = true;
+    h->have_logw = false;
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
-    int rc = prepare_observation(h, obs, obs_stride);
+    HIPCHK(h, hipStreamSynchronize(h->stream));           // the children are final: the host may export / gather them now
+    h->update_idx++;
+    return MCL_OK;
+}
+
+int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
+    if (!obs || n_beams != h->B) return fail(h, MCL_ERR_INVALID_ARG, "bad observation");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int64_t n = h->N;
+    const int c = h->cur;
+    int rc = prepare_observation(h, obs, 1);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
-    rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
-    hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
-    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->last_quad && h->h_fix_count != 0) {     // see do_update
-        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
-        rc = launch_rays(h, h->d_x[nx], h->d_y[nx], h->d_th[nx], n, true);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, attempt == 1);
         if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
         hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
         hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!(h->last_quad && h->h_fix_count != 0)) break;        // work-list overflow: once more with k_rays_skip (see do_update)
+        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
     }
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
-    h->update_idx++;
     h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
     h->timings[1] = 0.0;
-    h->timings[2] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_QUERY]);
+    h->timings[2] = 0.0;
     h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
     h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
+    return MCL_OK;
+}
+
+int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
+                        int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
+                        const double action[3], const float *obs, int32_t n_beams)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!obs || n_beams != h->B) return fail(h, MCL_ERR_INVALID_ARG, "bad observation");
+    int rc = mcl_stage_resample(h, d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action);
+    if (rc) return rc;
+    return mcl_stage_rays(h, obs, n_beams);
+}
+
+int mcl_set_reserved_cus(mcl_engine_t *h, int32_t n_cus)
+{
+    if (!h || n_cus < 0 || n_cus >= h->num_cu) return MCL_ERR_INVALID_ARG;
+    h->reserved_cus = n_cus;
     return MCL_OK;
 }
 

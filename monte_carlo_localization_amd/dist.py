@@ -16,25 +16,37 @@ gloo with an oracle-backed stand-in that lives under tests/.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 
 class ShardedFilter:
-    def __init__(self, shard, n_local: int, device: torch.device, group=None):
+    """overlap=True: the children's columns are all-gathered for the NEXT update while this update's ray
+    kernel runs (they are final right after the motion step); only the 8-byte fixed-point weights remain on the
+    critical path.  Needs `shard.set_reserved_cus` so that the persistent ray kernel leaves a few CUs to RCCL."""
+
+    def __init__(self, shard, n_local: int, device: torch.device, group=None, overlap: bool = True, reserved_cus: int = 8):
         self.shard = shard
         self.n = int(n_local)
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
+        # a single rank has nothing to overlap; MCL_FORCE_OVERLAP=1 keeps the path on for rehearsals
+        self.overlap = bool(overlap) and (self.world > 1 or os.environ.get("MCL_FORCE_OVERLAP") == "1")
+        if self.overlap and hasattr(shard, "set_reserved_cus"):
+            shard.set_reserved_cus(reserved_cus)
         f64, i64 = torch.float64, torch.int64
         n, nt = self.n, self.n * self.world
         self.n_total = nt
         self.loc = [torch.empty(n, dtype=f64, device=device) for _ in range(3)]
         self.loc_q = torch.empty(n, dtype=i64, device=device)           # uint64 bits
-        self.glob = [torch.empty(nt, dtype=f64, device=device) for _ in range(3)]
+        self.glob = [[torch.empty(nt, dtype=f64, device=device) for _ in range(3)] for _ in range(2 if self.overlap else 1)]
+        self.cur = 0
+        self.pending = None                                              # async gathers filling self.glob[self.cur]
         self.glob_q = torch.empty(nt, dtype=i64, device=device)
         self.glob_cdf = torch.empty(nt, dtype=i64, device=device)
         self.pose = np.zeros(3)
@@ -43,18 +55,41 @@ class ShardedFilter:
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
 
+    def reset(self):
+        """Call after the shard's particle state was replaced from outside (set_particles / init_*)."""
+        if self.pending is not None:
+            for w in self.pending:
+                w.wait()
+            self._sync()
+        self.pending = None
+
+    def _gather_columns(self, buf: int, async_op: bool):
+        s = self.shard
+        s.export_state(self.loc[0].data_ptr(), self.loc[1].data_ptr(), self.loc[2].data_ptr(), 0)
+        works = [dist.all_gather_into_tensor(g, l, group=self.group, async_op=async_op) for g, l in zip(self.glob[buf], self.loc)]
+        return works if async_op else None
+
     def update(self, action, obs):
         s = self.shard
-        # (1) exchange for resampling
-        s.export_state(self.loc[0].data_ptr(), self.loc[1].data_ptr(), self.loc[2].data_ptr(), self.loc_q.data_ptr())
-        for g, l in zip(self.glob, self.loc):
-            dist.all_gather_into_tensor(g, l, group=self.group)
+        # (1) exchange for resampling: particle columns (possibly gathered during the previous update) + weights
+        if self.pending is None:
+            self._gather_columns(self.cur, async_op=False)
+        else:
+            for w in self.pending:
+                w.wait()
+            self.pending = None
+        s.export_state(0, 0, 0, self.loc_q.data_ptr())
         dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
         self._sync()
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
-        s.stage_propagate(self.glob[0].data_ptr(), self.glob[1].data_ptr(), self.glob[2].data_ptr(),
-                          self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, action, obs)
+        g = self.glob[self.cur]
+        s.stage_resample(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), self.glob_cdf.data_ptr(), self.n_total, q_total,
+                         self.rank * self.n, self.n_total, action)
+        if self.overlap:
+            self.cur ^= 1
+            self.pending = self._gather_columns(self.cur, async_op=True)   # runs beside the ray kernel
+        s.stage_rays(obs)
         # (2) global max log-weight
         mx = torch.tensor([s.scalars()[0]], dtype=torch.float64, device=self.device)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
@@ -63,10 +98,10 @@ class ShardedFilter:
         sc = s.scalars()
         sums = torch.tensor([sc[1], sc[3], sc[4], sc[5], sc[6]], dtype=torch.float64, device=self.device)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
-        g = sums.cpu().numpy()
-        s.stage_finish(g)
-        k = 1.0 / g[0] if g[0] > 0 else 1.0
-        self.pose = np.array([g[1] * k, g[2] * k, np.arctan2(g[3] * k, g[4] * k)])
+        gs = sums.cpu().numpy()
+        s.stage_finish(gs)
+        k = 1.0 / gs[0] if gs[0] > 0 else 1.0
+        self.pose = np.array([gs[1] * k, gs[2] * k, np.arctan2(gs[3] * k, gs[4] * k)])
         return self.pose
 
     def expected_pose(self):

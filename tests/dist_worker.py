@@ -40,7 +40,8 @@ def main():
         shard.set_beam_angles(ang)
         shard.set_particles(p[:, mine], w)
         device = torch.device("cuda", 0)
-    sf = ShardedFilter(shard, n_local, device)
+    overlap = len(sys.argv) > 6 and sys.argv[6] == "overlap"
+    sf = ShardedFilter(shard, n_local, device, overlap=overlap)
     poses = []
     for _ in range(steps):
         poses.append(sf.update((0.05, 0.0, 0.01), obs))

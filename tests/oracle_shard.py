@@ -43,6 +43,10 @@ class OracleShard:
         _view(d_cdf, n, ctypes.c_uint64, np.uint64)[:] = np.cumsum(q, dtype=np.uint64) + np.uint64(offset)
 
     def stage_propagate(self, d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action, obs):
+        self.stage_resample(d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action)
+        self.stage_rays(obs)
+
+    def stage_resample(self, d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action):
         px = _view(d_px, n_parents, ctypes.c_double, np.float64)
         py = _view(d_py, n_parents, ctypes.c_double, np.float64)
         pth = _view(d_pth, n_parents, ctypes.c_double, np.float64)
@@ -60,10 +64,12 @@ class OracleShard:
         parents = np.stack([px[idx], py[idx], pth[idx]])
         nrm = orc.eng_philox_normals(self.seed, self.upd, child_first, n)
         self.p = orc.motion_model(parents, action, nrm)
+        self.upd += 1
+
+    def stage_rays(self, obs):
         oi = orc.obs_index(np.asarray(obs, np.float32), self.om)
         self.logw, _, _ = orc.eng_log_weights(self.om, self.p, self.angles, oi, self.L, use_omp=False)
         self._scalars[0] = self.logw.max()
-        self.upd += 1
 
     def scalars(self):
         return self._scalars.copy()

@@ -22,14 +22,14 @@ def free_port():
     return p
 
 
-def run_world(kind, out_dir, world, n_local, steps, mode):
+def run_world(kind, out_dir, world, n_local, steps, mode, overlap=False):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), kind, str(out_dir),
-                                       str(n_local), str(steps), str(mode)], env=env))
+                                       str(n_local), str(steps), str(mode), "overlap" if overlap else "sync"], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
     return [np.load(os.path.join(out_dir, f"rank{r}.npz")) for r in range(world)]
@@ -44,20 +44,20 @@ def check_equal(two, one, n_local):
     np.testing.assert_allclose(two[1]["poses"], two[0]["poses"], rtol=0, atol=0)   # every rank reports the same pose
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_two_ranks_equal_one_rank_gloo_cpu(tmp_path, mode):
+@pytest.mark.parametrize("mode,overlap", [(0, False), (1, False), (0, True)])
+def test_two_ranks_equal_one_rank_gloo_cpu(tmp_path, mode, overlap):
     d2, d1 = tmp_path / "w2", tmp_path / "w1"
     d2.mkdir(); d1.mkdir()
-    two = run_world("oracle", d2, 2, 96, 3, mode)
+    two = run_world("oracle", d2, 2, 96, 3, mode, overlap)
     one = run_world("oracle", d1, 1, 192, 3, mode)
     check_equal(two, one, 96)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1])
-def test_two_ranks_equal_one_rank_hip_engine(tmp_path, mode):
+@pytest.mark.parametrize("mode,overlap", [(0, False), (1, False), (0, True), (1, True)])
+def test_two_ranks_equal_one_rank_hip_engine(tmp_path, mode, overlap):
     d2, d1 = tmp_path / "w2", tmp_path / "w1"
     d2.mkdir(); d1.mkdir()
-    two = run_world("engine", d2, 2, 4096, 3, mode)
-    one = run_world("engine", d1, 1, 8192, 3, mode)
+    two = run_world("engine", d2, 2, 4096, 4, mode, overlap)
+    one = run_world("engine", d1, 1, 8192, 4, mode)
     check_equal(two, one, 4096)
