@@ -58,12 +58,15 @@ typedef enum {
 } mcl_weight_mode;
 
 typedef enum {
-    MCL_RAYS_AUTO = 0,            /* MCL_RAYS_QUAD when the map and beam set allow it, else MCL_RAYS_SKIP  */
+    MCL_RAYS_AUTO = 0,            /* MCL_RAYS_CELL (>= 65536 particles) or MCL_RAYS_QUAD when the map and beam
+                                     set allow them, else MCL_RAYS_SKIP                                */
     MCL_RAYS_MARCH = 1,           /* literal fixed-step fp64 march on the int8 grid (cpp:611-650)      */
     MCL_RAYS_SKIP = 2,            /* same sample lattice, empty-space skipping on an LDS-resident
                                      distance-to-obstacle window; exactness guard falls back to MARCH  */
-    MCL_RAYS_QUAD = 3             /* SKIP with the work split by ray direction: one-byte-per-cell quadrant
+    MCL_RAYS_QUAD = 3,            /* SKIP with the work split by ray direction: one-byte-per-cell quadrant
                                      windows, two workgroups per CU                                    */
+    MCL_RAYS_CELL = 4             /* QUAD on particles ordered by grid cell and heading, one particle per
+                                     lane: the lanes of a wave trace near-identical rays               */
 } mcl_ray_kernel;
 
 /* Numeric subset of the node's parameters (cpp:23-78) + engine knobs. */

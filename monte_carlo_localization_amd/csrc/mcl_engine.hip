@@ -85,8 +85,14 @@ struct mcl_engine {
     size_t fix_count_alloc = 0;
     int fix_segments = 0;
     uint8_t *d_far = nullptr;           // cap * 4 flags
+    // cell sort for k_rays_cell
+    double4 *d_pcs = nullptr;           // cap: pc in sorted order
+    short4 *d_qrs = nullptr;            // cap: qr in sorted order
+    uint32_t *d_perm = nullptr, *d_skey = nullptr, *d_srank = nullptr;   // cap each
+    uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
+    int *d_bbox = nullptr;              // 4
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
-    int last_mode = 0;                  // 1 march, 2 skip, 3 quad
+    int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
     double h_scalars[8]{};
     uint64_t q_total = 0;
@@ -385,10 +391,16 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     int mode = 2;
     h->last_quad = false;
     if (h->cfg.ray_kernel == MCL_RAYS_MARCH) mode = 1;
-    else if (h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_AUTO) mode = (h->quad_ok && h->qside > 0) ? 3 : 2;
+    else if (h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_CELL || h->cfg.ray_kernel == MCL_RAYS_AUTO)
+        mode = (h->quad_ok && h->qside > 0) ? 3 : 2;
     if (force_skip && mode == 3) mode = 2;
-    if (h->cfg.ray_kernel == MCL_RAYS_QUAD && mode != 3 && !force_skip)
-        return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD not usable with this map / beam set");
+    if ((h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_CELL) && mode != 3 && !force_skip)
+        return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD / MCL_RAYS_CELL not usable with this map / beam set");
+    // one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
+    // with 64-particle groups; below that the beams of one particle are the better source of parallelism
+    const char *cell_env = getenv("MCL_CELL_MIN");
+    const int64_t cell_min = cell_env ? atoll(cell_env) : 65536;
+    const bool cell = mode == 3 && (h->cfg.ray_kernel == MCL_RAYS_CELL || (h->cfg.ray_kernel == MCL_RAYS_AUTO && n >= cell_min));
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
     if (mode != 1)
@@ -410,7 +422,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // item granularity: 32 slices per CU (measured best at 4M: 4/8/16/32/64 -> 22.1/20.2/19.7/19.6/20.2 ms), but at
         // least 256 particles per slice so that the 78 KB window load stays amortised
         const int spc = ns_env ? atoi(ns_env) : 32;
-        const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
+        int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
+        if (cell) {
+            // k_rays_cell: a slice is a run of the sorted order; 2048 particles = two 64-particle groups per wave
+            const char *cs_env = getenv("MCL_CELL_SLICE");
+            const int64_t slice_len = cs_env ? std::max<int64_t>(64, atoll(cs_env)) : 2048;
+            nsl = (int)std::max<int64_t>(1, (n + slice_len - 1) / slice_len);
+        }
         const int nseg = (int)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), 4 * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
         unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 256 + 7) & ~7ull);
@@ -438,6 +456,25 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         HIPCHK(h, hipMemsetAsync(h->d_far, 0, (size_t)n * 4, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_fix_count, 0, (size_t)nseg * 64, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_fix_over, 0, 16, h->stream));
+        if (cell) {
+            // order the particles by (tile, cell, heading): bounding box -> bucket histogram (the atomic's return value
+            // is the rank inside the bucket) -> exclusive scan -> scatter of pc / qr / index
+            const unsigned nb256 = (unsigned)((n + 255) / 256);
+            const int nparts = (int)(mcl::kSortBuckets / mcl::kHistTile);
+            HIPCHK(h, hipMemsetAsync(h->d_bbox, 0x7f, 2 * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_bbox + 2, 0x80, 2 * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4, h->stream));
+            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>(nb256, 4 * h->num_cu)), dim3(256), 0, h->stream, h->d_pc, n,
+                               h->Wp, h->Hp, h->d_bbox);
+            hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
+                               h->d_skey, h->d_srank);
+            hipLaunchKernelGGL(mcl::k_hist_partials, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);
+            hipLaunchKernelGGL(mcl::k_hist_spine, dim3(1), dim3(1024), 0, h->stream, h->d_histpart, nparts);
+            hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);
+            hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, h->d_qr, n, h->d_skey, h->d_srank,
+                               h->d_hist, h->d_pcs, h->d_qrs, h->d_perm);
+            a.pcs = h->d_pcs; a.qrs = h->d_qrs; a.perm = h->d_perm;
+        }
         size_t qlds = (size_t)h->qside * h->qside;
         dim3 qg((unsigned)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), 4 * (int64_t)a.nslices));   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
@@ -447,13 +484,15 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
         HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
+            if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
+            else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         } else {
-            hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
+            if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
+            else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
@@ -479,7 +518,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         }
     }
     if (mode != 3) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
-    h->last_mode = mode;
+    h->last_mode = (mode == 3 && cell) ? 4 : mode;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -604,6 +643,14 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_pc, (size_t)h->cap * sizeof(double4)));
     CRT(hipMalloc(&h->d_qr, (size_t)h->cap * sizeof(short4)));
     CRT(hipMalloc(&h->d_far, (size_t)h->cap * 4));
+    CRT(hipMalloc(&h->d_pcs, (size_t)h->cap * sizeof(double4)));
+    CRT(hipMalloc(&h->d_qrs, (size_t)h->cap * sizeof(short4)));
+    CRT(hipMalloc(&h->d_perm, (size_t)h->cap * 4));
+    CRT(hipMalloc(&h->d_skey, (size_t)h->cap * 4));
+    CRT(hipMalloc(&h->d_srank, (size_t)h->cap * 4));
+    CRT(hipMalloc(&h->d_hist, (size_t)mcl::kSortBuckets * 4));
+    CRT(hipMalloc(&h->d_histpart, (size_t)(mcl::kSortBuckets / mcl::kHistTile) * 4));
+    CRT(hipMalloc(&h->d_bbox, 4 * sizeof(int)));
     CRT(hipMalloc(&h->d_fix_over, 16));
     CRT(hipMemset(h->d_fix_over, 0, 16));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
@@ -627,7 +674,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_qrs); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);

@@ -312,6 +312,9 @@ struct RayArgs {
     const double *x, *y, *th;      // particles (this launch's)
     const double4 *pc;             // per particle (cos th, sin th, (x-ox)/res, (y-oy)/res), k_particle_prep
     const short4 *qr;              // per particle quadrant ranges of its beams (k_rays_quad), k_particle_prep
+    const double4 *pcs;            // k_rays_cell: pc in cell-sorted order (k_sort_scatter)
+    const short4 *qrs;             // k_rays_cell: qr in cell-sorted order
+    const uint32_t *perm;          // k_rays_cell: sorted slot -> particle index
     int qside;                     // k_rays_quad: window side in cells (1 byte per cell)
     int nslices;                   // k_rays_quad: particle slices; grid = 4 * nslices
     unsigned long long *fix_list;  // k_rays_quad -> k_rays_fix: (particle << 16 | beam) of undecided rays
@@ -977,6 +980,362 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
             d[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
             d[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
         }
+    }
+}
+
+// ---- cell sort: particles ordered by (32x32 tile, cell in tile, heading) ---------------------------------
+//
+// k_rays_cell gives every LANE one particle and walks that particle's beams; the 64 lanes of a wave then trace
+// near-parallel rays (same beam slot of the same direction range) and, once the particles are ordered by grid cell
+// and heading, from almost the same origin: their trip counts are nearly equal and the wave no longer waits for
+// its slowest lane.  The order is a counting sort: bucket = (tile-major cell id << theta_bits) | quantised
+// heading over the bounding box of the particle set, as fine as fits kSortBuckets.  The rank inside a bucket is
+// the value returned by the histogram atomic, so the order within a bucket varies from run to run — harmless:
+// the order only decides which rays share a wave, every log-weight is an exact sum.
+constexpr int kSortBucketsLog2 = 22;
+constexpr uint32_t kSortBuckets = 1u << kSortBucketsLog2;
+constexpr int kHistTile = 4096;                     // entries per workgroup of the bucket scan
+
+__device__ __forceinline__ int cell_of(double g, int hi)
+{
+    // padded cell coordinate of a pixel coordinate, clamped into the padded grid (NaN -> 0)
+    int c = (g > -1.0) ? ((g < 1e9) ? (int)floor(g) + 1 : hi) : 0;
+    return c < 0 ? 0 : (c > hi ? hi : c);
+}
+
+// bbox[0..3] = min cx, min cy, max cx, max cy over the particle set (initialised to +big / -big by the host)
+__global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ pc, int64_t n, int Wp, int Hp, int *__restrict__ bbox)
+{
+    int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double4 c = pc[i];
+        const int cx = cell_of(c.z, Wp - 1), cy = cell_of(c.w, Hp - 1);
+        x0 = min(x0, cx); y0 = min(y0, cy); x1 = max(x1, cx); y1 = max(y1, cy);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+        atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1);
+    }
+}
+
+__device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int cx, int cy, double th)
+{
+    const int tx0 = bbox[0] >> 5, ty0 = bbox[1] >> 5;
+    const uint32_t ntx = (uint32_t)((bbox[2] >> 5) - tx0 + 1), nty = (uint32_t)((bbox[3] >> 5) - ty0 + 1);
+    const uint64_t ntiles = (uint64_t)ntx * nty;
+    int cs = 0;                                           // coarsen the in-tile resolution until the cells fit
+    while (cs < 5 && ((ntiles << (10 - 2 * cs)) > kSortBuckets)) ++cs;
+    const int inner = 5 - cs;                             // log2 of the bucket grid inside one tile
+    uint64_t ncell = ntiles << (2 * inner);
+    int tb = 0;                                           // heading bits that still fit (at most 8)
+    while (tb < 8 && (ncell << (tb + 1)) <= kSortBuckets) ++tb;
+    const uint32_t tile = (uint32_t)((cy >> 5) - ty0) * ntx + (uint32_t)((cx >> 5) - tx0);
+    const uint32_t ix = (uint32_t)(cx & 31) >> cs, iy = (uint32_t)(cy & 31) >> cs;
+    uint64_t key = ((((uint64_t)tile << inner) | iy) << inner) | ix;
+    double f = th * 0.15915494309189533577;               // heading as a fraction of a turn
+    f -= floor(f);
+    uint32_t tq = (f >= 0.0 && f < 1.0) ? (uint32_t)(f * (double)(1u << tb)) : 0u;
+    if (tq >> tb) tq = (1u << tb) - 1u;
+    key = (key << tb) | tq;
+    return key < kSortBuckets ? (uint32_t)key : kSortBuckets - 1u;    // a bounding box beyond 2^22 tiles: unsorted tail
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n, int Wp, int Hp,
+                                                  const int *__restrict__ bbox, uint32_t *__restrict__ hist,
+                                                  uint32_t *__restrict__ key_out, uint32_t *__restrict__ rank_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double4 c = pc[i];
+    const uint32_t key = sort_key(bbox, cell_of(c.z, Wp - 1), cell_of(c.w, Hp - 1), th[i]);
+    key_out[i] = key;
+    rank_out[i] = atomicAdd(&hist[key], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_hist_partials(const uint32_t *__restrict__ hist, uint32_t *__restrict__ part)
+{
+    __shared__ uint32_t ws[4];
+    const uint4 *p = reinterpret_cast<const uint4 *>(hist + (size_t)blockIdx.x * kHistTile) + threadIdx.x * 4;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { uint4 v = p[k]; s += v.x + v.y + v.z + v.w; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of the kSortBuckets / kHistTile (= 1024) workgroup totals, one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_hist_spine(uint32_t *__restrict__ part, int nparts)
+{
+    __shared__ uint32_t ws[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t v = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0u, inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int k = 0; k < w; ++k) off += ws[k];
+    if ((int)threadIdx.x < nparts) part[threadIdx.x] = off + inc - v;
+}
+
+// in-place exclusive scan of one tile of the histogram plus the tile's offset
+__global__ __launch_bounds__(256) void k_hist_final(uint32_t *__restrict__ hist, const uint32_t *__restrict__ part)
+{
+    __shared__ uint32_t ws[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint4 *p = reinterpret_cast<uint4 *>(hist + (size_t)blockIdx.x * kHistTile) + threadIdx.x * 4;
+    uint4 v[4];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = p[k]; s += v[k].x + v[k].y + v[k].z + v[k].w; }
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
+    uint32_t run = part[blockIdx.x] + inc - s;
+    for (int k = 0; k < w; ++k) run += ws[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint4 o;
+        o.x = run; run += v[k].x; o.y = run; run += v[k].y; o.z = run; run += v[k].z; o.w = run; run += v[k].w;
+        p[k] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(const double4 *__restrict__ pc, const short4 *__restrict__ qr, int64_t n,
+                                                     const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
+                                                     const uint32_t *__restrict__ start, double4 *__restrict__ pcs,
+                                                     short4 *__restrict__ qrs, uint32_t *__restrict__ perm)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = start[key[i]] + rank[i];
+    if (slot >= (uint64_t)n) return;                       // cannot happen (the counts sum to n); never write out of bounds
+    pcs[slot] = pc[i];
+    qrs[slot] = qr[i];
+    perm[slot] = (uint32_t)i;
+}
+
+// ---- K3d: one particle per lane on cell-sorted particles (MCL_RAYS_CELL) --------------------------------------
+//
+// Same windows, fields, fixed point, guard, fix-up list and far path as k_rays_quad; what changes is who does
+// what.  Work item (slice, q): the slice is a run of the CELL-SORTED particle order, each lane owns one particle
+// and walks that particle's beams of quadrant q one after the other (slot t = 0, 1, ...).  Per-particle work
+// (window-relative origin, first skip, quadrant ranges, heading rotation constants) is done once per item
+// instead of once per 64 rays, no cross-lane reduction is needed (a lane adds its particle's partial log-weight
+// with one atomic), and the lanes of a wave run near-identical rays (same slot of the same quadrant range,
+// origins within a cell or two, headings within a degree), so the probe loop runs with nearly all lanes active.
+template <bool COUNT>
+__global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int item_sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long cnt_probe = 0;
+    const int64_t per = (a.n + a.nslices - 1) / a.nslices;
+    const int nitems = 4 * a.nslices;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
+    for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) item_sh = (int)atomicAdd(a.work_counter, 1ull);
+    __syncthreads();
+    const int item = item_sh;
+    if (item >= nitems) break;
+    const int slice = item >> 2;
+    const int q = ((item & 3) + (item >> 3)) & 3;
+    const int64_t p_begin = (int64_t)slice * per;
+    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
+    if (p_begin >= p_end) continue;
+    const int sxp = (q == 0 || q == 3), syp = (q == 0 || q == 1);
+
+    const int S = a.qside;
+    const int mlo = 3;
+    int wx0, wy0;
+    {
+        double *red = reinterpret_cast<double *>(lds_raw);
+        double sx = 0.0, sy = 0.0;
+        for (int64_t s = p_begin + threadIdx.x; s < p_end; s += kRayThreads) {
+            double4 c = a.pcs[s];
+            double gx = c.z, gy = c.w;
+            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy);
+        if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
+        __syncthreads();
+        double mx = 0.0, my = 0.0;
+        for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
+        int64_t cntp = p_end - p_begin;
+        mx /= (double)cntp; my /= (double)cntp;
+        const int E = S - (a.P + 2) - mlo;
+        const int back = E / 2 + mlo;
+        int cxm = (int)floor(mx) + 1, cym = (int)floor(my) + 1;
+        wx0 = sxp ? cxm - back : cxm + back - S;
+        wy0 = syp ? cym - back : cym + back - S;
+        __syncthreads();
+        uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
+        const uint8_t *fieldq = a.distq[q];
+        const int wpr = S >> 3;
+        const int nwords = wpr * S;
+        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
+            int row = wi / wpr, cw = wi - row * wpr;
+            int gy = wy0 + row, gx = wx0 + cw * 8;
+            uint64_t b8 = 0;
+            if (gy >= 0 && gy < a.Hp) {
+                const uint8_t *rowp = fieldq + (size_t)gy * a.Wps;
+                if (gx >= 0 && gx + 8 <= a.Wps) {
+                    b8 = *reinterpret_cast<const uint64_t *>(rowp + gx);
+                } else {
+                    for (int k = 0; k < 8; ++k)
+                        if (gx + k >= 0 && gx + k < a.Wps) b8 |= (uint64_t)rowp[gx + k] << (8 * k);
+                }
+            }
+            uint64_t enc = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t v = (uint32_t)(b8 >> (8 * k)) & 0xFFu;
+                v = v == 0u ? 255u : (v == 255u ? 254u : v);      // stop -> 255, skips capped at 254 (as k_rays_quad)
+                enc |= (uint64_t)v << (8 * k);
+            }
+            win[wi] = enc;
+        }
+        __syncthreads();
+    }
+    uint32_t stride_v = (uint32_t)S, gbias_v = kQG1 << (32 - kQFx);
+    asm volatile("" : "+v"(stride_v), "+v"(gbias_v));
+    const unsigned char *ldsb = lds_raw;
+    const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : ((2u * kQG1) << (32 - kQFx));
+
+    for (int64_t s0g = p_begin + (int64_t)wave * 64; s0g < p_end; s0g += (int64_t)kRayWaves * 64) {
+        const int64_t slot = s0g + lane;
+        const bool have = slot < p_end;
+        const int64_t sl = have ? slot : p_end - 1;
+        const double4 pci = a.pcs[sl];
+        const uint32_t i = a.perm[sl];
+        int ja, jb, ja2;
+        quad_ranges(a.qrs[sl], q, a.B, ja, jb, ja2);
+        int n1 = jb > ja ? jb - ja : 0, n2 = a.B > ja2 ? a.B - ja2 : 0;
+        if (!have) { n1 = 0; n2 = 0; }
+        const double wpx = pci.z - (double)(wx0 - 1);
+        const double wpy = pci.w - (double)(wy0 - 1);
+        const double fwd = (double)(a.P + 2), bwd = 2.0;
+        const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
+        const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
+        const bool inwin = inx && iny;
+        if (!inwin && n1 + n2 > 0) {                           // not in this window (or NaN): k_rays_far does this pair
+            atomicOr(reinterpret_cast<unsigned int *>(a.far_flags) + i, 1u << (8 * q));
+            n1 = 0; n2 = 0;
+        }
+        const int total = n1 + n2;
+        // a lane without rays gets a zero direction and zero samples from the window's cell (2, 2): every probe it
+        // makes reads that cell, whose byte is never 0, and leaves the loop at once
+        const bool live = total > 0;
+        const double lpx = live ? wpx : 2.5, lpy = live ? wpy : 2.5;
+        const double p0x = lpx + kMagic, p0y = lpy + kMagic;
+        const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+        const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
+        const int d0 = ldsb[cy0 * S + cx0];
+        const int s0 = (d0 == 255 || d0 < 1) ? 1 : d0;
+        const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
+        const uint32_t P0x = (uint32_t)rint_i32(lpx * 4194304.0 - 2147483648.0) + 0x80000000u;
+        const uint32_t P0y = (uint32_t)rint_i32(lpy * 4194304.0 - 2147483648.0) + 0x80000000u;
+        const int rem_start = (live && s0 <= a.P) ? a.P - s0 : 0;
+        const double ncth = live ? -pci.x * 4194304.0 : 0.0, sths = live ? pci.y * 4194304.0 : 0.0;
+        int tmax = total;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, __shfl_xor(tmax, o, 64));
+        tmax = __builtin_amdgcn_readfirstlane(tmax);
+        // slot t of this lane is beam ja + t for t < n1, then ja2 + (t - n1); past its last slot a lane repeats
+        // its last beam (result discarded) so that it stays on a valid in-window ray
+        const int jlast = total > 0 ? (n2 > 0 ? a.B - 1 : jb - 1) : 0;
+        int j = n1 > 0 ? ja : (n2 > 0 ? ja2 : 0);
+        double acc = 0.0;
+        for (int t = 0; t < tmax; ++t) {
+            const bool valid = t < total;
+            const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
+            const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
+            const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
+            const uint32_t Pex = mad_i24(-a.P, NUx, P0x), Pey = mad_i24(-a.P, NUy, P0y);
+            int rem = rem_start;
+            uint32_t g = g0, byte = 0;
+            if (!COUNT) {
+                uint32_t Tx, Ty, t0, t1, addr;
+                unsigned long long saved_exec;
+                uint32_t countdown;
+                asm volatile(
+                    "s_mov_b64 %[sv], exec\n\t"
+                    "s_movk_i32 %[cd], 300\n"
+                    "1:\n\t"
+                    "v_mad_i32_i24 %[tx], %[rem], %[nux], %[pex]\n\t"
+                    "v_mad_i32_i24 %[ty], %[rem], %[nuy], %[pey]\n\t"
+                    "v_lshrrev_b32 %[t0], 22, %[tx]\n\t"
+                    "v_lshrrev_b32 %[t1], 22, %[ty]\n\t"
+                    "v_mad_u32_u24 %[ad], %[t1], %[str], %[t0]\n\t"
+                    "ds_read_u8 %[by], %[ad] offset:%[lb]\n\t"
+                    "v_lshl_add_u32 %[t0], %[tx], 10, %[gb]\n\t"
+                    "v_lshl_add_u32 %[t1], %[ty], 10, %[gb]\n\t"
+                    "v_min3_u32 %[g], %[g], %[t0], %[t1]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_sub_co_u32 %[rem], vcc, %[rem], %[by]\n\t"
+                    "s_andn2_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_execz 2f\n\t"
+                    "s_sub_u32 %[cd], %[cd], 1\n\t"
+                    "s_cbranch_scc0 1b\n"
+                    "2:\n\t"
+                    "s_mov_b64 exec, %[sv]"
+                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "+v"(byte), [g] "+v"(g),
+                      [rem] "+v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                    : [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v), [gb] "v"(gbias_v),
+                      [lb] "n"(kQLdsBase)
+                    : "memory", "vcc", "scc");
+                if (rem >= 0) g = 0u;
+            } else {
+                bool go;
+                int trips = 0;
+                do {
+                    const uint32_t Tx = mad_i24(rem, NUx, Pex), Ty = mad_i24(rem, NUy, Pey);
+                    const uint32_t gx = (Tx << (32 - kQFx)) + gbias_v, gy = (Ty << (32 - kQFx)) + gbias_v;
+                    const uint32_t gm = gx < gy ? gx : gy;
+                    g = g < gm ? g : gm;
+                    byte = ldsb[(Ty >> kQFx) * (uint32_t)S + (Tx >> kQFx)];
+                    uint32_t nr;
+                    const bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);
+                    go = !over;
+                    rem = (int)nr;
+                    cnt_probe += (go && valid) ? 1 : 0;
+                } while (go && ++trips <= 300);
+                if (go) g = 0u;
+            }
+            if (COUNT && valid) ++cnt_probe;
+            const bool amb = valid && g < gthresh;
+            if (valid && !amb) {
+                const int r = (byte == 255u) ? a.P - (rem + 255) - 1 : a.P;
+                acc += (double)a.Lt[__mul24(r, a.bpad) + j];
+                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+            }
+            if (amb) {
+                const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
+                if (fslot < a.fix_cap)
+                    atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)i << 16) | (unsigned long long)j);
+            }
+            int jn = j + 1;
+            if (jn == jb && n1 > 0 && t < n1) jn = ja2;        // end of the first range: continue with the second
+            j = jn > jlast ? jlast : jn;
+        }
+        if (live) atomicAdd(&a.logw[i], acc);
+    }
+    }   // work items
+    if (COUNT && a.counters) {
+        cnt_probe = wave_sum_u64(cnt_probe);
+        if (lane == 0 && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
     }
 }
 

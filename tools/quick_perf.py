@@ -14,7 +14,7 @@ def main():
     rpl = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
     ang = synth.beam_angles()
-    e = engine.Engine(max_particles=n, seed=42, ray_kernel={"march": engine.RAYS_MARCH, "skip": engine.RAYS_SKIP, "quad": engine.RAYS_QUAD}.get(kern, engine.RAYS_AUTO), rays_per_lane=rpl)
+    e = engine.Engine(max_particles=n, seed=42, ray_kernel={"march": engine.RAYS_MARCH, "skip": engine.RAYS_SKIP, "quad": engine.RAYS_QUAD, "cell": engine.RAYS_CELL}.get(kern, engine.RAYS_AUTO), rays_per_lane=rpl)
     e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
     e.set_beam_angles(ang)
     scan = synth.scan_from_pose(e, m, ang, (0.0, 0.0, 0.0))
