@@ -464,8 +464,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             HIPCHK(h, hipMemsetAsync(h->d_bbox, 0x7f, 2 * sizeof(int), h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_bbox + 2, 0x80, 2 * sizeof(int), h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4, h->stream));
-            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>(nb256, 4 * h->num_cu)), dim3(256), 0, h->stream, h->d_pc, n,
-                               h->Wp, h->Hp, h->d_bbox);
+            const int bstride = n >= (1 << 20) ? 16 : 1;
+            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 4 * h->num_cu)), dim3(256), 0,
+                               h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox);
             hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
                                h->d_skey, h->d_srank);
             hipLaunchKernelGGL(mcl::k_hist_partials, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);

@@ -9,6 +9,7 @@
 // Reference rows: R = cpp:656-665, M = cpp:449-503, Q/C/E = cpp:506-650,
 // N = cpp:678-686, P = cpp:696-716.
 #pragma once
+#include <type_traits>
 #include "mcl_device_math.h"
 
 namespace mcl {
@@ -415,6 +416,19 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad_u24_s(uint32_t a, uint32_t b_uniform, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
+// the same with a wave-uniform first factor kept in a scalar register
+__device__ __forceinline__ uint32_t mad_i24_s(int a, int b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=&v"(d) : "s"(a), "v"(b), "v"(c));
     return d;
 }
 // round-to-nearest-even double -> int32 through the 1.5*2^52 magic add (|x| < 2^31)
@@ -1003,12 +1017,15 @@ __device__ __forceinline__ int cell_of(double g, int hi)
     return c < 0 ? 0 : (c > hi ? hi : c);
 }
 
-// bbox[0..3] = min cx, min cy, max cx, max cy over the particle set (initialised to +big / -big by the host)
-__global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ pc, int64_t n, int Wp, int Hp, int *__restrict__ bbox)
+// bbox[0..3] = min cx, min cy, max cx, max cy over every `stride`-th particle (initialised to +big / -big by the
+// host).  A sample is enough: sort_key clamps cells into the box, so a particle outside it merely lands in an
+// edge bucket (the order is a performance matter only).
+__global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ pc, int64_t n, int stride, int Wp, int Hp, int *__restrict__ bbox)
 {
     int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double4 c = pc[i];
+    const int64_t ns = (n + stride - 1) / stride;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (int64_t)gridDim.x * blockDim.x) {
+        const double4 c = pc[k * stride];
         const int cx = cell_of(c.z, Wp - 1), cy = cell_of(c.w, Hp - 1);
         x0 = min(x0, cx); y0 = min(y0, cy); x1 = max(x1, cx); y1 = max(y1, cy);
     }
@@ -1024,6 +1041,8 @@ __global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ p
 
 __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int cx, int cy, double th)
 {
+    cx = cx < bbox[0] ? bbox[0] : (cx > bbox[2] ? bbox[2] : cx);
+    cy = cy < bbox[1] ? bbox[1] : (cy > bbox[3] ? bbox[3] : cy);
     const int tx0 = bbox[0] >> 5, ty0 = bbox[1] >> 5;
     const uint32_t ntx = (uint32_t)((bbox[2] >> 5) - tx0 + 1), nty = (uint32_t)((bbox[3] >> 5) - ty0 + 1);
     const uint64_t ntiles = (uint64_t)ntx * nty;
@@ -1213,6 +1232,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
     asm volatile("" : "+v"(stride_v), "+v"(gbias_v));
     const unsigned char *ldsb = lds_raw;
     const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : ((2u * kQG1) << (32 - kQFx));
+    const int negP = __builtin_amdgcn_readfirstlane(-a.P);
 
     for (int64_t s0g = p_begin + (int64_t)wave * 64; s0g < p_end; s0g += (int64_t)kRayWaves * 64) {
         const int64_t slot = s0g + lane;
@@ -1257,15 +1277,20 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         // its last beam (result discarded) so that it stays on a valid in-window ray
         const int jlast = total > 0 ? (n2 > 0 ? a.B - 1 : jb - 1) : 0;
         int j = n1 > 0 ? ja : (n2 > 0 ? ja2 : 0);
+        // a second range only exists for scans wider than three quadrants; the common case steps j by one
+        const bool wraps = __builtin_amdgcn_readfirstlane((int)(__ballot(n2 > 0 && n1 > 0) != 0ull)) != 0;
+        const uint32_t bpad4 = (uint32_t)__builtin_amdgcn_readfirstlane(a.bpad * 4);
         double acc = 0.0;
+        auto walk = [&](auto wrap_tag) {
+        constexpr bool WRAP = decltype(wrap_tag)::value;
         for (int t = 0; t < tmax; ++t) {
             const bool valid = t < total;
             const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
             const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
             const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
-            const uint32_t Pex = mad_i24(-a.P, NUx, P0x), Pey = mad_i24(-a.P, NUy, P0y);
+            const uint32_t Pex = mad_i24_s(negP, NUx, P0x), Pey = mad_i24_s(negP, NUy, P0y);
             int rem = rem_start;
-            uint32_t g = g0, byte = 0;
+            uint32_t g = g0, byte;
             if (!COUNT) {
                 uint32_t Tx, Ty, t0, t1, addr;
                 unsigned long long saved_exec;
@@ -1291,7 +1316,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                     "s_cbranch_scc0 1b\n"
                     "2:\n\t"
                     "s_mov_b64 exec, %[sv]"
-                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "+v"(byte), [g] "+v"(g),
+                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "+v"(g),
                       [rem] "+v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
                     : [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v), [gb] "v"(gbias_v),
                       [lb] "n"(kQLdsBase)
@@ -1318,7 +1343,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
             const bool amb = valid && g < gthresh;
             if (valid && !amb) {
                 const int r = (byte == 255u) ? a.P - (rem + 255) - 1 : a.P;
-                acc += (double)a.Lt[__mul24(r, a.bpad) + j];
+                acc += (double)*reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Lt) + mad_u24_s((uint32_t)r, bpad4, (uint32_t)j << 2));
                 if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
             }
             if (amb) {
@@ -1327,9 +1352,11 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                     atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)i << 16) | (unsigned long long)j);
             }
             int jn = j + 1;
-            if (jn == jb && n1 > 0 && t < n1) jn = ja2;        // end of the first range: continue with the second
+            if (WRAP && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
             j = jn > jlast ? jlast : jn;
         }
+        };
+        if (wraps) walk(std::true_type{}); else walk(std::false_type{});
         if (live) atomicAdd(&a.logw[i], acc);
     }
     }   // work items
