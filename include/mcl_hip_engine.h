@@ -180,6 +180,10 @@ int mcl_host_skip_field(const int8_t *data, uint32_t width, uint32_t height, uin
 /* Same for rays whose direction lies in `quadrant` (0:+x+y 1:-x+y 2:-x-y 3:+x-y): only stop cells a ray of that
  * quadrant can still reach bound the jump. */
 int mcl_host_skip_field_dir(const int8_t *data, uint32_t width, uint32_t height, int32_t quadrant, uint8_t *out, size_t n);
+/* Same for rays whose direction angle lies in wedge `wedge` of MCL_WEDGES equal sectors of the turn (sector k spans
+ * [2*pi*k/MCL_WEDGES, 2*pi*(k+1)/MCL_WEDGES]); the fields MCL_RAYS_CELL stages in LDS. */
+#define MCL_WEDGES 16
+int mcl_host_skip_field_wedge(const int8_t *data, uint32_t width, uint32_t height, int32_t wedge, uint8_t *out, size_t n);
 
 /* ---- multi-GPU staging (one engine per rank; collectives are the host's) -- */
 /* Device pointers of engine-owned buffers so the host can hand them to RCCL without copies. */

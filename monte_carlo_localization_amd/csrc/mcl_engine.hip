@@ -27,6 +27,8 @@ enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_K0, EV_K1, EV
 
 }  // namespace
 
+static_assert(MCL_WEDGES == mcl::kWedges, "include/mcl_hip_engine.h and csrc/mcl_wedge.h disagree");
+
 struct mcl_engine {
     mcl_config_t cfg{};
     int num_cu = 256;
@@ -87,7 +89,8 @@ struct mcl_engine {
     uint8_t *d_far = nullptr;           // cap * 4 flags
     // cell sort for k_rays_cell
     double4 *d_pcs = nullptr;           // cap: pc in sorted order
-    short4 *d_qrs = nullptr;            // cap: qr in sorted order
+    double *d_ths = nullptr;            // cap: heading in sorted order
+    uint8_t *d_distw = nullptr;         // kWedges wedge fields for k_rays_cell, each Hp x Wps bytes
     uint32_t *d_perm = nullptr, *d_skey = nullptr, *d_srank = nullptr;   // cap each
     uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
     int *d_bbox = nullptr;              // 4
@@ -322,7 +325,7 @@ int ensure_lt(mcl_engine *h)
     size_t need = (size_t)(h->P + 1) * h->bpad;
     if (need > h->lt_capacity) {
         dfree(h->d_Lt);
-        HIPCHK(h, hipMalloc(&h->d_Lt, need * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->d_Lt, 2 * need * sizeof(float)));      // [Lt | Lt with the rows reversed (k_rays_cell)]
         h->lt_capacity = need;
     }
     return MCL_OK;
@@ -377,6 +380,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.pc = h->d_pc;
     a.B = h->B; a.bpad = h->bpad; a.P = h->P;
     a.beam_cs = h->d_beam_cs; a.beam_angle = h->d_angle; a.Lt = h->d_Lt;
+    a.Ltr = h->d_Lt + (size_t)(h->P + 1) * h->bpad;
     a.logw = h->d_logw;
     a.steps = h->cfg.keep_ray_steps ? h->d_steps : nullptr;
     a.grid = h->d_grid; a.W = h->W; a.H = h->H;
@@ -429,7 +433,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const int64_t slice_len = cs_env ? std::max<int64_t>(64, atoll(cs_env)) : 2048;
             nsl = (int)std::max<int64_t>(1, (n + slice_len - 1) / slice_len);
         }
-        const int nseg = (int)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), 4 * (int64_t)nsl);   // one segment per persistent workgroup
+        const int nseg = (int)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), (cell ? mcl::kWedges : 4) * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
         unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 256 + 7) & ~7ull);
         if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
@@ -472,12 +476,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL(mcl::k_hist_partials, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);
             hipLaunchKernelGGL(mcl::k_hist_spine, dim3(1), dim3(1024), 0, h->stream, h->d_histpart, nparts);
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);
-            hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, h->d_qr, n, h->d_skey, h->d_srank,
-                               h->d_hist, h->d_pcs, h->d_qrs, h->d_perm);
-            a.pcs = h->d_pcs; a.qrs = h->d_qrs; a.perm = h->d_perm;
+            hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_skey, h->d_srank,
+                               h->d_hist, h->d_pcs, h->d_ths, h->d_perm);
+            a.pcs = h->d_pcs; a.ths = h->d_ths; a.perm = h->d_perm;
+            a.distw = h->d_distw; a.distw_stride = (size_t)h->Hp * h->Wps;
         }
         size_t qlds = (size_t)h->qside * h->qside;
-        dim3 qg((unsigned)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), 4 * (int64_t)a.nslices));   // persistent: 2 workgroups per CU
+        dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = getenv("MCL_DEBUG_WG");
         if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
@@ -533,7 +538,8 @@ int prepare_observation(mcl_engine *h, const float *obs, int stride)
     int rc = ensure_lt(h);
     if (rc) return rc;
     dim3 g((h->bpad + 255) / 256, h->P + 1);
-    hipLaunchKernelGGL(mcl::k_build_lt, g, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->bpad, h->P + 1, h->d_Lt);
+    hipLaunchKernelGGL(mcl::k_build_lt, g, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->bpad, h->P + 1, h->d_Lt,
+                       h->d_Lt + (size_t)(h->P + 1) * h->bpad);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -645,7 +651,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_qr, (size_t)h->cap * sizeof(short4)));
     CRT(hipMalloc(&h->d_far, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_pcs, (size_t)h->cap * sizeof(double4)));
-    CRT(hipMalloc(&h->d_qrs, (size_t)h->cap * sizeof(short4)));
+    CRT(hipMalloc(&h->d_ths, (size_t)h->cap * sizeof(double)));
     CRT(hipMalloc(&h->d_perm, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_skey, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_srank, (size_t)h->cap * 4));
@@ -675,7 +681,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_qrs); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
@@ -728,6 +734,31 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
             HIPCHK(h, hipMalloc(&h->d_distq[q], dq.size()));
             HIPCHK(h, hipMemcpy(h->d_distq[q], dq.data(), dq.size(), hipMemcpyHostToDevice));
         }
+    }
+    dfree(h->d_distw);
+    if (h->qside > 0) {
+        // wedge fields for k_rays_cell (mcl_wedge.h), built on the device from the isotropic field's stop cells
+        const size_t fsz = (size_t)h->Hp * h->Wps, ncell = (size_t)h->Hp * h->Wp;
+        int32_t *d_nxt = nullptr, *d_prv = nullptr;
+        mcl::WedgeRow *d_rows = nullptr;
+        std::vector<mcl::WedgeRow> rows(2 * mcl::kWedgeR + 1);
+        HIPCHK(h, hipMalloc(&h->d_distw, fsz * mcl::kWedges));
+        HIPCHK(h, hipMemset(h->d_distw, 0, fsz * mcl::kWedges));
+        HIPCHK(h, hipMalloc(&d_nxt, ncell * 4));
+        HIPCHK(h, hipMalloc(&d_prv, ncell * 4));
+        HIPCHK(h, hipMalloc(&d_rows, rows.size() * sizeof(mcl::WedgeRow)));
+        hipLaunchKernelGGL(mcl::k_row_tables, dim3((h->Hp + 63) / 64), dim3(64), 0, h->stream, h->d_dist, h->Wp, h->Hp, h->Wps, d_nxt, d_prv);
+        int rc_w = MCL_OK;
+        for (int k = 0; k < mcl::kWedges && rc_w == MCL_OK; ++k) {
+            mcl::wedge_rows(k, rows.data());
+            if (hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(mcl::WedgeRow), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { rc_w = MCL_ERR_HIP; break; }
+            hipLaunchKernelGGL(mcl::k_wedge_field, dim3((h->Wp + 255) / 256, h->Hp), dim3(256), 0, h->stream, d_nxt, d_prv, h->Wp, h->Hp, h->Wps,
+                               d_rows, h->d_distw + (size_t)k * fsz);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) rc_w = MCL_ERR_HIP;   // rows[] is reused by the next wedge
+        }
+        (void)hipFree(d_nxt); (void)hipFree(d_prv); (void)hipFree(d_rows);
+        if (rc_w != MCL_OK) return fail(h, rc_w, "building the wedge fields failed");
     }
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1146,6 +1177,26 @@ int mcl_host_skip_field_dir(const int8_t *data, uint32_t width, uint32_t height,
     std::vector<uint8_t> d;
     build_directional_field(data, (int)width, (int)height, Wp, Hp, Wps, qsx[quadrant], qsy[quadrant], d);
     for (int y = 0; y < Hp; ++y) std::memcpy(out + (size_t)y * Wp, d.data() + (size_t)y * Wps, Wp);
+    return MCL_OK;
+}
+
+int mcl_host_skip_field_wedge(const int8_t *data, uint32_t width, uint32_t height, int32_t wedge, uint8_t *out, size_t n)
+{
+    if (!data || !out || width == 0 || height == 0 || wedge < 0 || wedge >= mcl::kWedges || n != (size_t)(width + 1) * (height + 1))
+        return MCL_ERR_INVALID_ARG;
+    const int W = (int)width, H = (int)height, Wp = W + 1, Hp = H + 1;
+    std::vector<int32_t> nxt((size_t)Wp * Hp), prv((size_t)Wp * Hp);
+    for (int y = 0; y < Hp; ++y) {
+        auto stop = [&](int x) { return data[(size_t)std::max(y - 1, 0) * W + std::max(x - 1, 0)] > 50; };
+        int last = -1;
+        for (int x = 0; x < Wp; ++x) { if (stop(x)) last = x; prv[(size_t)y * Wp + x] = last; }
+        int next = Wp;
+        for (int x = Wp - 1; x >= 0; --x) { if (stop(x)) next = x; nxt[(size_t)y * Wp + x] = next; }
+    }
+    std::vector<mcl::WedgeRow> rows(2 * mcl::kWedgeR + 1);
+    mcl::wedge_rows(wedge, rows.data());
+    for (int y = 0; y < Hp; ++y)
+        for (int x = 0; x < Wp; ++x) out[(size_t)y * Wp + x] = (uint8_t)mcl::wedge_skip_cell(nxt.data(), prv.data(), Wp, Hp, x, y, rows.data());
     return MCL_OK;
 }
 

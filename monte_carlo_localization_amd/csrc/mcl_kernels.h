@@ -11,6 +11,7 @@
 #pragma once
 #include <type_traits>
 #include "mcl_device_math.h"
+#include "mcl_wedge.h"
 
 namespace mcl {
 
@@ -295,8 +296,9 @@ __global__ void k_fill(double *__restrict__ p, int64_t n, double v)
 }
 
 // per-update transposed log table: Lt[d * bpad + j] = L[obs_idx[j] * (P+1) + d]
+// Ltr holds the same rows in reverse order (row rho = P - d), the form k_rays_cell indexes with "samples left"
 __global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int bpad, int tw,
-                           float *__restrict__ Lt)
+                           float *__restrict__ Lt, float *__restrict__ Ltr)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int d = blockIdx.y;
@@ -304,6 +306,7 @@ __global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restric
     float v = 0.f;
     if (j < B) v = L[(size_t)obs_idx[j] * tw + d];
     Lt[(size_t)d * bpad + j] = v;
+    Ltr[(size_t)(tw - 1 - d) * bpad + j] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,8 +317,10 @@ struct RayArgs {
     const double4 *pc;             // per particle (cos th, sin th, (x-ox)/res, (y-oy)/res), k_particle_prep
     const short4 *qr;              // per particle quadrant ranges of its beams (k_rays_quad), k_particle_prep
     const double4 *pcs;            // k_rays_cell: pc in cell-sorted order (k_sort_scatter)
-    const short4 *qrs;             // k_rays_cell: qr in cell-sorted order
     const uint32_t *perm;          // k_rays_cell: sorted slot -> particle index
+    const double *ths;             // k_rays_cell: heading in cell-sorted order
+    const uint8_t *distw;          // k_rays_cell: kWedges wedge fields (mcl_wedge.h), field k at distw + k * distw_stride
+    size_t distw_stride;
     int qside;                     // k_rays_quad: window side in cells (1 byte per cell)
     int nslices;                   // k_rays_quad: particle slices; grid = 4 * nslices
     unsigned long long *fix_list;  // k_rays_quad -> k_rays_fix: (particle << 16 | beam) of undecided rays
@@ -330,6 +335,7 @@ struct RayArgs {
     const double2 *beam_cs;        // (cos a_j, sin a_j) of (double)angle_f32[j], host fp64
     const float *beam_angle;       // float angles (MARCH path uses theta + (double)angle)
     const float *Lt;               // (P+1) x bpad
+    const float *Ltr;              // the same with the rows reversed (row P - d)
     double *logw;                  // out
     uint8_t *steps;                // out N*B or null
     // map
@@ -370,7 +376,10 @@ constexpr int kRayWaves = kRayThreads / 64;
 // increase monotonically over less than a full turn (checked at mcl_set_beam_angles), so the beams of one
 // particle fall into at most five contiguous index ranges with quadrants q0, q0+1, ..., q0+4 (mod 4).
 // qr = (start of ranges 1..4, B when absent); q0 is packed into the top two bits of .x.
-__device__ __forceinline__ int beam_turns(double th, float angle) { return (int)floor((th + (double)angle) * 0.63661977236758134308); }
+// direction bin (wedge, unwrapped) of beam `angle` for heading th; the quadrant index is derived from it so that
+// every kernel classifies a ray the same way
+__device__ __forceinline__ int beam_wedge(double th, float angle) { return (int)floor((th + (double)angle) * (kWedges * 0.15915494309189533577)); }
+__device__ __forceinline__ int beam_turns(double th, float angle) { return beam_wedge(th, angle) >> kWedgeShift; }
 
 __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ th, int64_t n, double ox, double oy, double res,
@@ -382,11 +391,14 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     const double t = th[i];
     double s, c;
     sincos(t, &s, &c);
-    pc[i] = make_double4(c, s, (x[i] - ox) / res, (y[i] - oy) / res);
+    const bool heading_ok = t == t && fabs(t) < 1e6;
+    // a garbage heading gets a NaN pixel position: the pair fails every window test and k_rays_far marches it literally
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    pc[i] = make_double4(c, s, heading_ok ? (x[i] - ox) / res : nanv, heading_ok ? (y[i] - oy) / res : nanv);
     if (qr) {
         short st[4];
         int q0 = 0;
-        if (t == t && fabs(t) < 1e6) {
+        if (heading_ok) {
             const int k0 = beam_turns(t, beam_angle[0]);
             q0 = k0 & 3;
             for (int k = 1; k <= 4; ++k) {
@@ -997,6 +1009,29 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
     }
 }
 
+// ---- wedge fields (mcl_wedge.h) built on the device at set_map ------------------------------------------------
+// one thread per row of the padded grid: next / previous stop cell in the row (dist == 0 marks a stop)
+__global__ void k_row_tables(const uint8_t *__restrict__ dist, int Wp, int Hp, int Wps, int32_t *__restrict__ nxt, int32_t *__restrict__ prv)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= Hp) return;
+    const uint8_t *row = dist + (size_t)y * Wps;
+    int last = -1;
+    for (int x = 0; x < Wp; ++x) { if (row[x] == 0) last = x; prv[(size_t)y * Wp + x] = last; }
+    int next = Wp;
+    for (int x = Wp - 1; x >= 0; --x) { if (row[x] == 0) next = x; nxt[(size_t)y * Wp + x] = next; }
+}
+
+__global__ __launch_bounds__(256) void k_wedge_field(const int32_t *__restrict__ nxt, const int32_t *__restrict__ prv, int Wp, int Hp, int Wps,
+                                                    const WedgeRow *__restrict__ rows, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wp || y >= Hp) return;
+    // stored in k_rays_cell's LDS encoding: stop -> 0xFF (-1 as a signed byte), skips capped at 127
+    const int v = wedge_skip_cell(nxt, prv, Wp, Hp, x, y, rows);
+    out[(size_t)y * Wps + x] = (uint8_t)(v == 0 ? 255 : (v > 127 ? 127 : v));
+}
+
 // ---- cell sort: particles ordered by (32x32 tile, cell in tile, heading) ---------------------------------
 //
 // k_rays_cell gives every LANE one particle and walks that particle's beams; the 64 lanes of a wave then trace
@@ -1129,18 +1164,29 @@ __global__ __launch_bounds__(256) void k_hist_final(uint32_t *__restrict__ hist,
     }
 }
 
-__global__ __launch_bounds__(256) void k_sort_scatter(const double4 *__restrict__ pc, const short4 *__restrict__ qr, int64_t n,
+__global__ __launch_bounds__(256) void k_sort_scatter(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n,
                                                      const uint32_t *__restrict__ key, const uint32_t *__restrict__ rank,
                                                      const uint32_t *__restrict__ start, double4 *__restrict__ pcs,
-                                                     short4 *__restrict__ qrs, uint32_t *__restrict__ perm)
+                                                     double *__restrict__ ths, uint32_t *__restrict__ perm)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = start[key[i]] + rank[i];
     if (slot >= (uint64_t)n) return;                       // cannot happen (the counts sum to n); never write out of bounds
     pcs[slot] = pc[i];
-    qrs[slot] = qr[i];
+    ths[slot] = th[i];
     perm[slot] = (uint32_t)i;
+}
+
+// first beam j with beam_wedge(th, angle[j]) >= m (beam angles increase, so the wedge index is monotone)
+__device__ __forceinline__ int first_beam_in_wedge(double th, const float *__restrict__ angle, int B, int m)
+{
+    int lo = 0, hi = B;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (beam_wedge(th, angle[mid]) >= m) hi = mid; else lo = mid + 1;
+    }
+    return lo;
 }
 
 // ---- K3d: one particle per lane on cell-sorted particles (MCL_RAYS_CELL) --------------------------------------
@@ -1161,7 +1207,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long cnt_probe = 0;
     const int64_t per = (a.n + a.nslices - 1) / a.nslices;
-    const int nitems = 4 * a.nslices;
+    const int nitems = kWedges * a.nslices;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
     for (;;) {
     __syncthreads();
@@ -1169,8 +1215,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
     __syncthreads();
     const int item = item_sh;
     if (item >= nitems) break;
-    const int slice = item >> 2;
-    const int q = ((item & 3) + (item >> 3)) & 3;
+    const int slice = item / kWedges;
+    const int kbin = ((item % kWedges) + 5 * slice) % kWedges;     // consecutive items differ in direction
+    const int q = kbin >> kWedgeShift;
     const int64_t p_begin = (int64_t)slice * per;
     const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
     if (p_begin >= p_end) continue;
@@ -1201,30 +1248,24 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         wy0 = syp ? cym - back : cym + back - S;
         __syncthreads();
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
-        const uint8_t *fieldq = a.distq[q];
+        const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
         const int wpr = S >> 3;
         const int nwords = wpr * S;
         for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
             int row = wi / wpr, cw = wi - row * wpr;
             int gy = wy0 + row, gx = wx0 + cw * 8;
-            uint64_t b8 = 0;
+            // the wedge fields are stored in the LDS encoding (stop = 0xFF, skips 1..127); outside the grid is stop
+            uint64_t b8 = ~0ull;
             if (gy >= 0 && gy < a.Hp) {
                 const uint8_t *rowp = fieldq + (size_t)gy * a.Wps;
-                if (gx >= 0 && gx + 8 <= a.Wps) {
+                if (gx >= 0 && gx + 8 <= a.Wp) {
                     b8 = *reinterpret_cast<const uint64_t *>(rowp + gx);
                 } else {
                     for (int k = 0; k < 8; ++k)
-                        if (gx + k >= 0 && gx + k < a.Wps) b8 |= (uint64_t)rowp[gx + k] << (8 * k);
+                        if (gx + k >= 0 && gx + k < a.Wp) b8 = (b8 & ~(0xFFull << (8 * k))) | ((uint64_t)rowp[gx + k] << (8 * k));
                 }
             }
-            uint64_t enc = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                uint32_t v = (uint32_t)(b8 >> (8 * k)) & 0xFFu;
-                v = v == 0u ? 255u : (v == 255u ? 254u : v);      // stop -> 255, skips capped at 254 (as k_rays_quad)
-                enc |= (uint64_t)v << (8 * k);
-            }
-            win[wi] = enc;
+            win[wi] = b8;
         }
         __syncthreads();
     }
@@ -1240,8 +1281,22 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         const int64_t sl = have ? slot : p_end - 1;
         const double4 pci = a.pcs[sl];
         const uint32_t i = a.perm[sl];
-        int ja, jb, ja2;
-        quad_ranges(a.qrs[sl], q, a.B, ja, jb, ja2);
+        // beams of this particle in wedge kbin: [ja, jb) and, for scans wider than a turn minus one wedge, [ja2, B)
+        int ja = 0, jb = 0, ja2 = a.B;
+        {
+            const double th = a.ths[sl];
+            if (th == th && fabs(th) < 1e6) {
+                const int w0 = beam_wedge(th, a.beam_angle[0]), wl = beam_wedge(th, a.beam_angle[a.B - 1]);
+                const int m = w0 + ((kbin - w0) & (kWedges - 1));
+                if (m <= wl) {
+                    ja = m == w0 ? 0 : first_beam_in_wedge(th, a.beam_angle, a.B, m);
+                    jb = m == wl ? a.B : first_beam_in_wedge(th, a.beam_angle, a.B, m + 1);
+                    if (m + kWedges <= wl) ja2 = first_beam_in_wedge(th, a.beam_angle, a.B, m + kWedges);
+                }
+            } else if (kbin == 0) {
+                jb = a.B;            // garbage heading: one range in quadrant 0 like k_particle_prep (position is NaN -> far path)
+            }
+        }
         int n1 = jb > ja ? jb - ja : 0, n2 = a.B > ja2 ? a.B - ja2 : 0;
         if (!have) { n1 = 0; n2 = 0; }
         const double wpx = pci.z - (double)(wx0 - 1);
@@ -1263,7 +1318,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
         const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
         const int d0 = ldsb[cy0 * S + cx0];
-        const int s0 = (d0 == 255 || d0 < 1) ? 1 : d0;
+        const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
         const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
         const uint32_t P0x = (uint32_t)rint_i32(lpx * 4194304.0 - 2147483648.0) + 0x80000000u;
         const uint32_t P0y = (uint32_t)rint_i32(lpy * 4194304.0 - 2147483648.0) + 0x80000000u;
@@ -1289,22 +1344,40 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
             const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
             const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
             const uint32_t Pex = mad_i24_s(negP, NUx, P0x), Pey = mad_i24_s(negP, NUy, P0y);
-            int rem = rem_start;
-            uint32_t g = g0, byte;
+            int rem;
+            uint32_t g;
             if (!COUNT) {
-                uint32_t Tx, Ty, t0, t1, addr;
+                // Probe loop as in k_rays_quad with two changes.  The cell byte is read SIGNED: a stop (0xFF = -1) makes
+                // the unsigned subtraction borrow whatever rem holds and leaves rem + 1 > 0, a skip larger than the
+                // samples left leaves rem < 0, so "samples left at the hit" is max(rem, 0) and the reversed table is
+                // indexed with it directly.  The first trip is peeled so that the per-particle start values are read
+                // in place (no copies per ray).
+                uint32_t Tx, Ty, t0, t1, addr, byte;
                 unsigned long long saved_exec;
                 uint32_t countdown;
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
-                    "s_movk_i32 %[cd], 300\n"
+                    "s_movk_i32 %[cd], 300\n\t"
+                    "v_mad_i32_i24 %[tx], %[rem0], %[nux], %[pex]\n\t"
+                    "v_mad_i32_i24 %[ty], %[rem0], %[nuy], %[pey]\n\t"
+                    "v_lshrrev_b32 %[t0], 22, %[tx]\n\t"
+                    "v_lshrrev_b32 %[t1], 22, %[ty]\n\t"
+                    "v_mad_u32_u24 %[ad], %[t1], %[str], %[t0]\n\t"
+                    "ds_read_i8 %[by], %[ad] offset:%[lb]\n\t"
+                    "v_lshl_add_u32 %[t0], %[tx], 10, %[gb]\n\t"
+                    "v_lshl_add_u32 %[t1], %[ty], 10, %[gb]\n\t"
+                    "v_min3_u32 %[g], %[g0], %[t0], %[t1]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_sub_co_u32 %[rem], vcc, %[rem0], %[by]\n\t"
+                    "s_andn2_b64 exec, exec, vcc\n\t"
+                    "s_cbranch_execz 2f\n"
                     "1:\n\t"
                     "v_mad_i32_i24 %[tx], %[rem], %[nux], %[pex]\n\t"
                     "v_mad_i32_i24 %[ty], %[rem], %[nuy], %[pey]\n\t"
                     "v_lshrrev_b32 %[t0], 22, %[tx]\n\t"
                     "v_lshrrev_b32 %[t1], 22, %[ty]\n\t"
                     "v_mad_u32_u24 %[ad], %[t1], %[str], %[t0]\n\t"
-                    "ds_read_u8 %[by], %[ad] offset:%[lb]\n\t"
+                    "ds_read_i8 %[by], %[ad] offset:%[lb]\n\t"
                     "v_lshl_add_u32 %[t0], %[tx], 10, %[gb]\n\t"
                     "v_lshl_add_u32 %[t1], %[ty], 10, %[gb]\n\t"
                     "v_min3_u32 %[g], %[g], %[t0], %[t1]\n\t"
@@ -1316,21 +1389,24 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                     "s_cbranch_scc0 1b\n"
                     "2:\n\t"
                     "s_mov_b64 exec, %[sv]"
-                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "+v"(g),
-                      [rem] "+v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
-                    : [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v), [gb] "v"(gbias_v),
-                      [lb] "n"(kQLdsBase)
+                    : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
+                      [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                    : [rem0] "v"(rem_start), [g0] "v"(g0), [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v),
+                      [gb] "v"(gbias_v), [lb] "n"(kQLdsBase)
                     : "memory", "vcc", "scc");
-                if (rem >= 0) g = 0u;
+                // the countdown only expires if the window is malformed (impossible): every ray of the pass to the fix-up list
+                if (__builtin_amdgcn_readfirstlane((int)countdown) < 0) g = 0u;
             } else {
                 bool go;
                 int trips = 0;
+                rem = rem_start;
+                g = g0;
                 do {
                     const uint32_t Tx = mad_i24(rem, NUx, Pex), Ty = mad_i24(rem, NUy, Pey);
                     const uint32_t gx = (Tx << (32 - kQFx)) + gbias_v, gy = (Ty << (32 - kQFx)) + gbias_v;
                     const uint32_t gm = gx < gy ? gx : gy;
                     g = g < gm ? g : gm;
-                    byte = ldsb[(Ty >> kQFx) * (uint32_t)S + (Tx >> kQFx)];
+                    const uint32_t byte = (uint32_t)(int)(int8_t)ldsb[(Ty >> kQFx) * (uint32_t)S + (Tx >> kQFx)];
                     uint32_t nr;
                     const bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);
                     go = !over;
@@ -1342,9 +1418,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
             if (COUNT && valid) ++cnt_probe;
             const bool amb = valid && g < gthresh;
             if (valid && !amb) {
-                const int r = (byte == 255u) ? a.P - (rem + 255) - 1 : a.P;
-                acc += (double)*reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Lt) + mad_u24_s((uint32_t)r, bpad4, (uint32_t)j << 2));
-                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
+                acc += (double)*reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Ltr) + mad_u24_s((uint32_t)left, bpad4, (uint32_t)j << 2));
+                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)(a.P - left);
             }
             if (amb) {
                 const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);

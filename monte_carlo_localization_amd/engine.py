@@ -27,7 +27,7 @@ EXPORTS = [
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
-    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_stage_resample", "mcl_stage_rays",
+    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_stage_resample", "mcl_stage_rays",
     "mcl_set_reserved_cus",
 ]
 
@@ -106,6 +106,20 @@ def host_skip_field(grid) -> np.ndarray:
     rc = load_library().mcl_host_skip_field(_p(g), C.c_uint32(W), C.c_uint32(H), _p(out), C.c_size_t(out.size))
     if rc != MCL_OK:
         raise EngineError(f"mcl_host_skip_field rc={rc}")
+    return out
+
+
+WEDGES = 16
+
+
+def host_skip_field_wedge(grid, wedge: int) -> np.ndarray:
+    """Skip field for rays whose direction angle lies in sector `wedge` of WEDGES equal sectors of the turn."""
+    g = _c(grid, np.int8)
+    H, W = g.shape
+    out = np.empty((H + 1, W + 1), np.uint8)
+    rc = load_library().mcl_host_skip_field_wedge(_p(g), C.c_uint32(W), C.c_uint32(H), C.c_int32(wedge), _p(out), C.c_size_t(out.size))
+    if rc != MCL_OK:
+        raise EngineError(f"mcl_host_skip_field_wedge rc={rc}")
     return out
 
 
