@@ -1338,9 +1338,20 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         double acc = 0.0;
         auto walk = [&](auto wrap_tag) {
         constexpr bool WRAP = decltype(wrap_tag)::value;
+        // software pipeline: the direction of the next beam is requested before this beam's probe loop and the table
+        // entry of this beam is added after the next one's, so neither load is waited for where it is issued
+        double2 cs_next = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
+        float lt_pending = 0.f;
         for (int t = 0; t < tmax; ++t) {
             const bool valid = t < total;
-            const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
+            const double2 cs = cs_next;
+            const int jcur = j;
+            {
+                int jn = j + 1;
+                if (WRAP && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
+                j = jn > jlast ? jlast : jn;
+            }
+            cs_next = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
             const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
             const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
             const uint32_t Pex = mad_i24_s(negP, NUx, P0x), Pey = mad_i24_s(negP, NUy, P0y);
@@ -1417,20 +1428,20 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
             }
             if (COUNT && valid) ++cnt_probe;
             const bool amb = valid && g < gthresh;
+            acc += (double)lt_pending;
+            lt_pending = 0.f;
             if (valid && !amb) {
                 const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
-                acc += (double)*reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Ltr) + mad_u24_s((uint32_t)left, bpad4, (uint32_t)j << 2));
-                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)(a.P - left);
+                lt_pending = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Ltr) + mad_u24_s((uint32_t)left, bpad4, (uint32_t)jcur << 2));
+                if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
             }
             if (amb) {
                 const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
                 if (fslot < a.fix_cap)
-                    atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)i << 16) | (unsigned long long)j);
+                    atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)i << 16) | (unsigned long long)jcur);
             }
-            int jn = j + 1;
-            if (WRAP && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
-            j = jn > jlast ? jlast : jn;
         }
+        acc += (double)lt_pending;
         };
         if (wraps) walk(std::true_type{}); else walk(std::false_type{});
         if (live) atomicAdd(&a.logw[i], acc);

@@ -25,7 +25,7 @@ def main():
         t0 = time.perf_counter()
         e.update((0.05, 0.0, 0.01), scan)
         dt = time.perf_counter() - t0
-        print(f"update {i}: wall {dt*1e3:.2f} ms  stages {np.round(e.stage_timings(),3)}  counters {e.counters()}  pose {e.expected_pose()}", flush=True)
+        print(f"update {i}: wall {dt*1e3:.2f} ms  stages {np.round(e.stage_timings(),3)} ray_kernel {e.ray_kernel_ms():.3f}  counters {e.counters()}  pose {e.expected_pose()}", flush=True)
     print("particle*beam/s (last):", n * ang.size / dt)
 
 main()
