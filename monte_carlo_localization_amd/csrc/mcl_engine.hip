@@ -69,6 +69,10 @@ struct mcl_engine {
     double *d_w = nullptr, *d_logw = nullptr, *d_tmp = nullptr;   // tmp: cap*3 doubles
     double *d_logw_acc = nullptr;       // k_rays_quad/far/fix accumulate here with atomics; k_gather_logw copies to d_logw
     uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
+    uint64_t *d_leaders = nullptr;      // last CDF entry of every 16-entry group of the array d_blocktot describes
+    size_t leaders_capacity = 0;
+    double4 *d_pack[2]{};               // (x, y, theta, -) records of buffer 0/1, written by k_resample_motion
+    bool pack_valid[2] = {false, false};
     int32_t *d_idx = nullptr;
     uint8_t *d_steps = nullptr;
     size_t steps_capacity = 0, blocktot_capacity = 0;
@@ -336,7 +340,13 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
     int nb = (int)((n + mcl::kScanTile - 1) / mcl::kScanTile);
     hipLaunchKernelGGL(mcl::k_scan_partials, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot);
     hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total);
-    hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf);
+    const size_t nlead = (size_t)((n + 15) >> mcl::kLeaderShift) + 1;
+    if (nlead > h->leaders_capacity) {
+        dfree(h->d_leaders);
+        HIPCHK(h, hipMalloc(&h->d_leaders, nlead * 8));
+        h->leaders_capacity = nlead;
+    }
+    hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf, h->d_leaders);
     HIPCHK(h, hipGetLastError());
     h->blocktot_for = d_cdf; h->blocktot_n = n;
     return MCL_OK;
@@ -381,6 +391,11 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.B = h->B; a.bpad = h->bpad; a.P = h->P;
     a.beam_cs = h->d_beam_cs; a.beam_angle = h->d_angle; a.Lt = h->d_Lt;
     a.Ltr = h->d_Lt + (size_t)(h->P + 1) * h->bpad;
+    a.beam_a0 = h->B > 0 ? (double)h->angles[0] : 0.0;
+    {
+        const double span = h->B > 1 ? (double)h->angles[h->B - 1] - (double)h->angles[0] : 0.0;
+        a.beam_inv_inc = span > 0.0 ? (double)(h->B - 1) / span : 0.0;
+    }
     a.logw = h->d_logw;
     a.steps = h->cfg.keep_ray_steps ? h->d_steps : nullptr;
     a.grid = h->d_grid; a.W = h->W; a.H = h->H;
@@ -469,7 +484,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             HIPCHK(h, hipMemsetAsync(h->d_bbox + 2, 0x80, 2 * sizeof(int), h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4, h->stream));
             const int bstride = n >= (1 << 20) ? 16 : 1;
-            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 4 * h->num_cu)), dim3(256), 0,
+            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0,
                                h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox);
             hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
                                h->d_skey, h->d_srank);
@@ -636,6 +651,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     const size_t nb = (size_t)h->cap * sizeof(double);
     for (int b = 0; b < 2; ++b) {
         CRT(hipMalloc(&h->d_x[b], nb)); CRT(hipMalloc(&h->d_y[b], nb)); CRT(hipMalloc(&h->d_th[b], nb));
+        CRT(hipMalloc(&h->d_pack[b], (size_t)h->cap * sizeof(double4)));
     }
     CRT(hipMalloc(&h->d_w, nb)); CRT(hipMalloc(&h->d_logw, nb)); CRT(hipMalloc(&h->d_tmp, nb * 3));
     CRT(hipMalloc(&h->d_logw_acc, nb));
@@ -681,7 +697,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
@@ -852,6 +868,7 @@ int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights,
     rc = fetch_scalars(h);
     if (rc) return rc;
     h->have_particles = true;
+    h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     return MCL_OK;
 }
@@ -868,6 +885,7 @@ static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
     rc = fetch_scalars(h);
     if (rc) return rc;
     h->have_particles = true;
+    h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     h->init_idx++;
     return MCL_OK;
@@ -995,6 +1013,9 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         a.px = h->d_x[c]; a.py = h->d_y[c]; a.pth = h->d_th[c];
         a.cdf = h->d_cdf; a.n_parents = n; a.q_total = h->q_total;
         a.tile_excl = (h->blocktot_for == h->d_cdf && h->blocktot_n == n) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
+        a.leaders = a.tile_excl ? h->d_leaders : nullptr;
+        a.ppack = h->pack_valid[c] ? h->d_pack[c] : nullptr;
+        a.cpack = h->d_pack[nx];
         a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
         a.idx_out = h->d_idx;
         a.n_children = n; a.child_first = 0; a.n_children_total = n;
@@ -1020,6 +1041,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
         HIPCHK(h, hipGetLastError());
         h->cur = nx;                       // cpp:689 as a pointer swap
+        h->pack_valid[nx] = true;
         h->have_idx = true;
     }
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
@@ -1266,6 +1288,7 @@ int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, 
     mcl::ResampleArgs a{};
     a.px = d_px; a.py = d_py; a.pth = d_pth; a.cdf = d_cdf; a.n_parents = n_parents; a.q_total = q_total;
     a.tile_excl = (h->blocktot_for == d_cdf && h->blocktot_n == n_parents) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
+    a.leaders = a.tile_excl ? h->d_leaders : nullptr;
     a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
     a.idx_out = h->d_idx;
     a.n_children = n; a.child_first = child_first; a.n_children_total = n_children_total;
@@ -1287,6 +1310,7 @@ int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, 
     hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
     h->cur = nx;
+    h->pack_valid[nx] = false;        // the sharded path gathers columns, no packed records
     h->have_idx = true;
     h->have_logw = false;
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));

@@ -81,9 +81,12 @@ __global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *__restrict__ bloc
     if (threadIdx.x == 0 && grand_total) *grand_total = carry_s;
 }
 
+// `leaders` (optional) receives the last CDF entry of every 16-entry (128-byte) group: a 16x smaller copy the
+// resampling search walks instead of the CDF itself, so that it fetches one CDF line per child, not seven
+constexpr int kLeaderShift = 4;
 __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__restrict__ q, int64_t n,
                                                             const uint64_t *__restrict__ block_off,
-                                                            uint64_t *__restrict__ cdf)
+                                                            uint64_t *__restrict__ cdf, uint64_t *__restrict__ leaders)
 {
     __shared__ uint64_t sm[kScanThreads / 64];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -104,6 +107,12 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__r
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
         if (base + k < n) cdf[base + k] = off + v[k];
+    if (leaders) {
+        static_assert(kScanItems == 8 && (1 << kLeaderShift) == 16, "a leader is the last item of every second thread");
+        const int64_t last = base + kScanItems - 1;
+        if ((last & 15) == 15 && last < n) leaders[last >> kLeaderShift] = off + v[kScanItems - 1];
+        else if (base < n && n - 1 <= last && ((n - 1) & 15) != 15) leaders[(n - 1) >> kLeaderShift] = off + v[(n - 1) - base];   // ragged last group
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -118,6 +127,9 @@ struct ResampleArgs {
     const double *px, *py, *pth;      // parents
     const uint64_t *cdf;              // inclusive CDF over parents
     const uint64_t *tile_excl;        // exclusive prefix before each kScanTile-sized tile of the CDF (the scan's spine)
+    const uint64_t *leaders;          // last CDF entry of every 16-entry group (with tile_excl), or null
+    const double4 *ppack;             // parents as (x, y, theta, -) records: one fetch per gathered parent, or null
+    double4 *cpack;                   // children in the same form for the next update, or null
     int64_t n_parents;
     uint64_t q_total;
     double *cx, *cy, *cth;            // children out
@@ -175,6 +187,20 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 const int64_t t = tlo > 0 ? tlo - 1 : 0;
                 lo = t * kScanTile;
                 len = (lo + kScanTile <= a.n_parents) ? kScanTile : a.n_parents - lo;
+                if (a.leaders) {
+                    // first 16-entry group of the tile whose last entry exceeds the threshold, then only that group
+                    const int64_t g0 = lo >> kLeaderShift, ng = (len + 15) >> kLeaderShift;
+                    int64_t glo = g0, glen = ng;
+                    while (glen > 0) {
+                        int64_t half = glen >> 1, mid = glo + half;
+                        if (!mul_gt(a.leaders[mid], lmul, r0, r1)) { glo = mid + 1; glen = glen - half - 1; }
+                        else glen = half;
+                    }
+                    if (glo >= g0 + ng) glo = g0 + ng - 1;          // threshold beyond the tile (only at the very end)
+                    const int64_t end = lo + len;
+                    lo = glo << kLeaderShift;
+                    len = (lo + 16 <= end) ? 16 : end - lo;
+                }
             }
             while (len > 0) {
                 int64_t half = len >> 1, mid = lo + half;
@@ -185,7 +211,9 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
         }
     }
     if (a.idx_out) a.idx_out[m] = (int32_t)idx;
-    double x = a.px[idx], y = a.py[idx], th = a.pth[idx];
+    double x, y, th;
+    if (a.ppack) { const double4 pr = a.ppack[idx]; x = pr.x; y = pr.y; th = pr.z; }
+    else { x = a.px[idx]; y = a.py[idx]; th = a.pth[idx]; }
     if (a.do_motion) {
         double n0, n1, n2;
         if (a.normals) {
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
         x = nx; y = ny; th = nth;
     }
     a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
+    if (a.cpack) a.cpack[m] = make_double4(x, y, th, 0.0);
 }
 
 // lidarCB's downsampled ranges -> table row per beam, cpp:549-554, 570, 573 (NaN -> 0): one block
@@ -334,6 +363,7 @@ struct RayArgs {
     int B, bpad, P;
     const double2 *beam_cs;        // (cos a_j, sin a_j) of (double)angle_f32[j], host fp64
     const float *beam_angle;       // float angles (MARCH path uses theta + (double)angle)
+    double beam_a0, beam_inv_inc;  // first angle and beams per radian (k_rays_cell's guess of a wedge's first beam)
     const float *Lt;               // (P+1) x bpad
     const float *Ltr;              // the same with the rows reversed (row P - d)
     double *logw;                  // out
@@ -1069,8 +1099,14 @@ __global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ p
         x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
         x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
     }
-    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
-        atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1);
+    // one set of atomics per workgroup: same-address atomics serialise at ~12 ns each
+    __shared__ int red[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = x0; red[w][1] = y0; red[w][2] = x1; red[w][3] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { x0 = min(x0, red[k][0]); y0 = min(y0, red[k][1]); x1 = max(x1, red[k][2]); y1 = max(y1, red[k][3]); }
+        if (x1 >= 0) { atomicMin(&bbox[0], x0); atomicMin(&bbox[1], y0); atomicMax(&bbox[2], x1); atomicMax(&bbox[3], y1); }
     }
 }
 
@@ -1178,10 +1214,18 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const double4 *__restrict_
     perm[slot] = (uint32_t)i;
 }
 
-// first beam j with beam_wedge(th, angle[j]) >= m (beam angles increase, so the wedge index is monotone)
-__device__ __forceinline__ int first_beam_in_wedge(double th, const float *__restrict__ angle, int B, int m)
+// first beam j with beam_wedge(th, angle[j]) >= m (beam angles increase, so the wedge index is monotone in j).
+// For the usual evenly spaced scan the answer is within a beam or two of (m * 2pi/K - th - a0) / increment: the
+// bisection starts from a five-beam bracket around that guess when the bracket holds and from [0, B] otherwise.
+__device__ __forceinline__ int first_beam_in_wedge(double th, const float *__restrict__ angle, int B, int m, double a0, double inv_inc)
 {
     int lo = 0, hi = B;
+    const double x = ((double)m * (6.283185307179586476925286766559 / kWedges) - th - a0) * inv_inc;
+    if (x > -4.0 && x < (double)B + 4.0) {
+        const int jg = (int)ceil(x);
+        const int l = max(jg - 2, 0), h = min(jg + 2, B);
+        if (l <= h && (l == 0 || beam_wedge(th, angle[l - 1]) < m) && (h == B || beam_wedge(th, angle[h]) >= m)) { lo = l; hi = h; }
+    }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (beam_wedge(th, angle[mid]) >= m) hi = mid; else lo = mid + 1;
@@ -1289,9 +1333,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                 const int w0 = beam_wedge(th, a.beam_angle[0]), wl = beam_wedge(th, a.beam_angle[a.B - 1]);
                 const int m = w0 + ((kbin - w0) & (kWedges - 1));
                 if (m <= wl) {
-                    ja = m == w0 ? 0 : first_beam_in_wedge(th, a.beam_angle, a.B, m);
-                    jb = m == wl ? a.B : first_beam_in_wedge(th, a.beam_angle, a.B, m + 1);
-                    if (m + kWedges <= wl) ja2 = first_beam_in_wedge(th, a.beam_angle, a.B, m + kWedges);
+                    ja = m == w0 ? 0 : first_beam_in_wedge(th, a.beam_angle, a.B, m, a.beam_a0, a.beam_inv_inc);
+                    jb = m == wl ? a.B : first_beam_in_wedge(th, a.beam_angle, a.B, m + 1, a.beam_a0, a.beam_inv_inc);
+                    if (m + kWedges <= wl) ja2 = first_beam_in_wedge(th, a.beam_angle, a.B, m + kWedges, a.beam_a0, a.beam_inv_inc);
                 }
             } else if (kbin == 0) {
                 jb = a.B;            // garbage heading: one range in quadrant 0 like k_particle_prep (position is NaN -> far path)
@@ -1349,7 +1393,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
             {
                 int jn = j + 1;
                 if (WRAP && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
-                j = jn > jlast ? jlast : jn;
+                j = min(jn, jlast);
             }
             cs_next = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
             const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
