@@ -101,6 +101,8 @@ struct mcl_engine {
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
+    unsigned long long *d_result = nullptr;   // [0..7] scalars, [8..11] counters, [12..13] overflow flag + work counter: one D2H copy
+    unsigned long long *h_result = nullptr;   // pinned mirror of d_result
     double h_scalars[8]{};
     uint64_t q_total = 0;
     double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
@@ -370,8 +372,12 @@ int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override)
 
 int fetch_scalars(mcl_engine *h)
 {
-    HIPCHK(h, hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // scalars, counters and the work-list overflow flag in one copy into pinned memory
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(h->h_scalars, h->h_result, 8 * sizeof(double));
+    std::memcpy(h->h_counters, h->h_result + 8, 4 * sizeof(unsigned long long));
+    h->h_fix_count = h->h_result[12];
     uint64_t qt;
     std::memcpy(&qt, &h->h_scalars[2], 8);
     h->q_total = qt;
@@ -422,9 +428,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     const bool cell = mode == 3 && (h->cfg.ray_kernel == MCL_RAYS_CELL || (h->cfg.ray_kernel == MCL_RAYS_AUTO && n >= cell_min));
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
-    if (mode != 1)
+    if (mode == 2)
         hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
-                           h->res, h->d_pc, h->d_angle, h->B, mode == 3 ? h->d_qr : nullptr);
+                           h->res, h->d_pc, h->d_angle, h->B, (short4 *)nullptr, mcl::PrepClear{});
     const bool count = h->cfg.debug_count_probes != 0;
     size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
     dim3 g(grid), b(mcl::kRayThreads);
@@ -464,25 +470,26 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         }
         h->fix_cap = segcap;
         h->fix_segments = nseg;
-        a.qr = h->d_qr;
+        a.qr = cell ? nullptr : h->d_qr;
         a.qside = h->qside;
         a.nslices = nsl;
         a.fix_list = h->d_fix_list; a.fix_count = h->d_fix_count; a.fix_cap = h->fix_cap; a.fix_segments = nseg;
         a.far_flags = h->d_far;
         a.work_counter = h->d_fix_over + 1;                // second word of the 16-byte scratch block
         a.logw = h->d_logw_acc;
-        HIPCHK(h, hipMemsetAsync(h->d_logw_acc, 0, (size_t)n * sizeof(double), h->stream));   // partial sums are added atomically
-        HIPCHK(h, hipMemsetAsync(h->d_far, 0, (size_t)n * 4, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_fix_count, 0, (size_t)nseg * 64, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_fix_over, 0, 16, h->stream));
+        {   // per-particle constants; the same pass zeroes the stage's scratch (partial sums are added atomically)
+            mcl::PrepClear clr{};
+            clr.logw_acc = h->d_logw_acc; clr.far_flags = reinterpret_cast<uint32_t *>(h->d_far);
+            clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over;
+            if (cell) { clr.bbox = h->d_bbox; clr.hist = h->d_hist; clr.hist_n = mcl::kSortBuckets; }
+            hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
+                               h->res, h->d_pc, h->d_angle, h->B, cell ? (short4 *)nullptr : h->d_qr, clr);
+        }
         if (cell) {
             // order the particles by (tile, cell, heading): bounding box -> bucket histogram (the atomic's return value
             // is the rank inside the bucket) -> exclusive scan -> scatter of pc / qr / index
             const unsigned nb256 = (unsigned)((n + 255) / 256);
             const int nparts = (int)(mcl::kSortBuckets / mcl::kHistTile);
-            HIPCHK(h, hipMemsetAsync(h->d_bbox, 0x7f, 2 * sizeof(int), h->stream));
-            HIPCHK(h, hipMemsetAsync(h->d_bbox + 2, 0x80, 2 * sizeof(int), h->stream));
-            HIPCHK(h, hipMemsetAsync(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4, h->stream));
             const int bstride = n >= (1 << 20) ? 16 : 1;
             hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0,
                                h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox);
@@ -503,20 +510,21 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
         // k_rays_far is bound by global-memory latency: 4 workgroups per CU worth of blocks (2 resident at a time)
         dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
+        const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU
         HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
             if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
-            hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         } else {
             if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
-            hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(std::min(nseg, 2048)), dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         }
         hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
@@ -660,8 +668,11 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_blocktot, h->blocktot_capacity * 8));
     CRT(hipMalloc(&h->d_idx, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_part, (size_t)mcl::kRedBlocks * 8 * sizeof(double)));
-    CRT(hipMalloc(&h->d_scalars, 8 * sizeof(double)));
-    CRT(hipMalloc(&h->d_counters, 4 * sizeof(unsigned long long)));
+    CRT(hipMalloc(&h->d_result, 16 * 8));
+    CRT(hipHostMalloc(&h->h_result, 16 * 8));
+    h->d_scalars = reinterpret_cast<double *>(h->d_result);
+    h->d_counters = h->d_result + 8;
+    h->d_fix_over = h->d_result + 12;
     CRT(hipMalloc(&h->d_inject, nb * 4));
     CRT(hipMalloc(&h->d_pc, (size_t)h->cap * sizeof(double4)));
     CRT(hipMalloc(&h->d_qr, (size_t)h->cap * sizeof(short4)));
@@ -674,7 +685,6 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_hist, (size_t)mcl::kSortBuckets * 4));
     CRT(hipMalloc(&h->d_histpart, (size_t)(mcl::kSortBuckets / mcl::kHistTile) * 4));
     CRT(hipMalloc(&h->d_bbox, 4 * sizeof(int)));
-    CRT(hipMalloc(&h->d_fix_over, 16));
     CRT(hipMemset(h->d_fix_over, 0, 16));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
     CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
@@ -697,7 +707,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_scalars); dfree(h->d_counters); dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_fix_over);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
@@ -1056,9 +1066,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);   // CDF for the next resample / visualize
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
-    rc = fetch_scalars(h);                 // synchronises the stream
+    rc = fetch_scalars(h);                 // one D2H copy (scalars, counters, overflow flag); synchronises the stream
     if (rc) return rc;
     if (h->last_quad && h->h_fix_count != 0) {
         // more undecided rays than the work list holds (only with debug_force_exact at large sizes or a
@@ -1070,7 +1078,6 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         if (rc) return rc;
         rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
         if (rc) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         rc = fetch_scalars(h);
         if (rc) return rc;
     }
@@ -1337,9 +1344,10 @@ int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
         hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
         hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(&h->h_fix_count, h->d_fix_over, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(h->h_counters, h->h_result + 8, 4 * sizeof(unsigned long long));
+        h->h_fix_count = h->h_result[12];
         if (!(h->last_quad && h->h_fix_count != 0)) break;        // work-list overflow: once more with k_rays_skip (see do_update)
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
     }

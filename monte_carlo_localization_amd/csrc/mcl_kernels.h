@@ -411,13 +411,53 @@ constexpr int kRayWaves = kRayThreads / 64;
 __device__ __forceinline__ int beam_wedge(double th, float angle) { return (int)floor((th + (double)angle) * (kWedges * 0.15915494309189533577)); }
 __device__ __forceinline__ int beam_turns(double th, float angle) { return beam_wedge(th, angle) >> kWedgeShift; }
 
+// quadrant ranges of one particle's beams (see above); a garbage heading gets one range in quadrant 0
+__device__ __forceinline__ short4 quadrant_ranges_of(double t, bool heading_ok, const float *__restrict__ beam_angle, int B)
+{
+    short st[4];
+    int q0 = 0;
+    if (heading_ok) {
+        const int k0 = beam_turns(t, beam_angle[0]);
+        q0 = k0 & 3;
+        for (int k = 1; k <= 4; ++k) {
+            int lo = 0, hi = B;              // first j with turns(j) - turns(0) >= k
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (beam_turns(t, beam_angle[mid]) - k0 >= k) hi = mid; else lo = mid + 1;
+            }
+            st[k - 1] = (short)lo;
+        }
+    } else {
+        st[0] = st[1] = st[2] = st[3] = (short)B;   // garbage heading: one range, marched literally by k_rays_far
+    }
+    return make_short4((short)(st[0] | (q0 << 14)), st[1], st[2], st[3]);
+}
+
+// scratch the ray stage needs zeroed, cleared here instead of by one memset each (null = not used by this launch)
+struct PrepClear {
+    double *logw_acc;                  // n
+    uint32_t *far_flags;               // n
+    unsigned long long *fix_count;     // fix_words 64-bit words
+    int fix_words;
+    unsigned long long *fix_over;      // 2 words (overflow flag, work counter)
+    int *bbox;                         // 4: +big, +big, -big, -big
+    uint32_t *hist;                    // hist_n bucket counters
+    uint32_t hist_n;
+};
+
 __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ th, int64_t n, double ox, double oy, double res,
                                                       double4 *__restrict__ pc, const float *__restrict__ beam_angle, int B,
-                                                      short4 *__restrict__ qr)
+                                                      short4 *__restrict__ qr, PrepClear clr)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (clr.logw_acc) clr.logw_acc[i] = 0.0;
+    if (clr.far_flags) clr.far_flags[i] = 0u;
+    if (clr.fix_count) for (int64_t k = i; k < clr.fix_words; k += n) clr.fix_count[k] = 0ull;
+    if (clr.fix_over) for (int64_t k = i; k < 2; k += n) clr.fix_over[k] = 0ull;
+    if (clr.bbox) for (int64_t k = i; k < 4; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (int)0x80000000;
+    if (clr.hist) for (int64_t k = i; k < clr.hist_n; k += n) clr.hist[k] = 0u;
     const double t = th[i];
     double s, c;
     sincos(t, &s, &c);
@@ -425,25 +465,7 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     // a garbage heading gets a NaN pixel position: the pair fails every window test and k_rays_far marches it literally
     const double nanv = __longlong_as_double(0x7ff8000000000000ll);
     pc[i] = make_double4(c, s, heading_ok ? (x[i] - ox) / res : nanv, heading_ok ? (y[i] - oy) / res : nanv);
-    if (qr) {
-        short st[4];
-        int q0 = 0;
-        if (heading_ok) {
-            const int k0 = beam_turns(t, beam_angle[0]);
-            q0 = k0 & 3;
-            for (int k = 1; k <= 4; ++k) {
-                int lo = 0, hi = B;              // first j with turns(j) - turns(0) >= k
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if (beam_turns(t, beam_angle[mid]) - k0 >= k) hi = mid; else lo = mid + 1;
-                }
-                st[k - 1] = (short)lo;
-            }
-        } else {
-            st[0] = st[1] = st[2] = st[3] = (short)B;   // garbage heading: one range, handled by the fallback paths
-        }
-        qr[i] = make_short4((short)(st[0] | (q0 << 14)), st[1], st[2], st[3]);
-    }
+    if (qr) qr[i] = quadrant_ranges_of(t, heading_ok, beam_angle, B);
 }
 
 // D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
@@ -1071,7 +1093,13 @@ __global__ __launch_bounds__(256) void k_wedge_field(const int32_t *__restrict__
 // heading over the bounding box of the particle set, as fine as fits kSortBuckets.  The rank inside a bucket is
 // the value returned by the histogram atomic, so the order within a bucket varies from run to run — harmless:
 // the order only decides which rays share a wave, every log-weight is an exact sum.
+#ifdef MCL_EXP_SPREAD
+constexpr int kSortBucketsLog2 = 24;
+constexpr uint32_t kSortKeySpace = 1u << 22;
+#else
 constexpr int kSortBucketsLog2 = 22;
+constexpr uint32_t kSortKeySpace = 1u << kSortBucketsLog2;
+#endif
 constexpr uint32_t kSortBuckets = 1u << kSortBucketsLog2;
 constexpr int kHistTile = 4096;                     // entries per workgroup of the bucket scan
 
@@ -1118,11 +1146,11 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int c
     const uint32_t ntx = (uint32_t)((bbox[2] >> 5) - tx0 + 1), nty = (uint32_t)((bbox[3] >> 5) - ty0 + 1);
     const uint64_t ntiles = (uint64_t)ntx * nty;
     int cs = 0;                                           // coarsen the in-tile resolution until the cells fit
-    while (cs < 5 && ((ntiles << (10 - 2 * cs)) > kSortBuckets)) ++cs;
+    while (cs < 5 && ((ntiles << (10 - 2 * cs)) > kSortKeySpace)) ++cs;
     const int inner = 5 - cs;                             // log2 of the bucket grid inside one tile
     uint64_t ncell = ntiles << (2 * inner);
     int tb = 0;                                           // heading bits that still fit (at most 8)
-    while (tb < 8 && (ncell << (tb + 1)) <= kSortBuckets) ++tb;
+    while (tb < 8 && (ncell << (tb + 1)) <= kSortKeySpace) ++tb;
     const uint32_t tile = (uint32_t)((cy >> 5) - ty0) * ntx + (uint32_t)((cx >> 5) - tx0);
     const uint32_t ix = (uint32_t)(cx & 31) >> cs, iy = (uint32_t)(cy & 31) >> cs;
     uint64_t key = ((((uint64_t)tile << inner) | iy) << inner) | ix;
@@ -1131,7 +1159,7 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int c
     uint32_t tq = (f >= 0.0 && f < 1.0) ? (uint32_t)(f * (double)(1u << tb)) : 0u;
     if (tq >> tb) tq = (1u << tb) - 1u;
     key = (key << tb) | tq;
-    return key < kSortBuckets ? (uint32_t)key : kSortBuckets - 1u;    // a bounding box beyond 2^22 tiles: unsorted tail
+    return key < kSortKeySpace ? (uint32_t)key : kSortKeySpace - 1u;    // a bounding box beyond 2^22 tiles: unsorted tail
 }
 
 __global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n, int Wp, int Hp,
@@ -1141,7 +1169,10 @@ __global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ p
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double4 c = pc[i];
-    const uint32_t key = sort_key(bbox, cell_of(c.z, Wp - 1), cell_of(c.w, Hp - 1), th[i]);
+    uint32_t key = sort_key(bbox, cell_of(c.z, Wp - 1), cell_of(c.w, Hp - 1), th[i]);
+#ifdef MCL_EXP_SPREAD
+    key = (key << 2) | ((uint32_t)i & 3u);
+#endif
     key_out[i] = key;
     rank_out[i] = atomicAdd(&hist[key], 1u);
 }
@@ -1160,19 +1191,29 @@ __global__ __launch_bounds__(256) void k_hist_partials(const uint32_t *__restric
     if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// exclusive scan of the kSortBuckets / kHistTile (= 1024) workgroup totals, one workgroup of 1024 threads
+// exclusive scan of the kSortBuckets / kHistTile workgroup totals, one workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void k_hist_spine(uint32_t *__restrict__ part, int nparts)
 {
     __shared__ uint32_t ws[16];
+    __shared__ uint32_t carry_s;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t v = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0u, inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) ws[w] = inc;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    uint32_t off = 0;
-    for (int k = 0; k < w; ++k) off += ws[k];
-    if ((int)threadIdx.x < nparts) part[threadIdx.x] = off + inc - v;
+    for (int base = 0; base < nparts; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const uint32_t v = i < nparts ? part[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int k = 0; k < w; ++k) off += ws[k];
+        if (i < nparts) part[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + inc;
+        __syncthreads();
+    }
 }
 
 // in-place exclusive scan of one tile of the histogram plus the tile's offset
@@ -1503,8 +1544,11 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
 {
     unsigned long long cnt_exact = 0, cnt_probe = 0, cnt_l2 = 0;
-    // one workgroup of this kernel drains the segments seg = blockIdx.x, blockIdx.x + gridDim.x, ...
-    for (int seg = blockIdx.x; seg < a.fix_segments; seg += gridDim.x) {
+    // gridDim.x = split * fix_segments: `split` workgroups share one segment (the kernel is bound by the latency of
+    // its dependent global loads, so it wants every CU full of waves rather than one workgroup per segment)
+    const int split = max(1, (int)gridDim.x / a.fix_segments);
+    const int part = blockIdx.x % split;
+    for (int seg = blockIdx.x / split; seg < a.fix_segments; seg += gridDim.x / split) {
     // the counters were updated by memory-side atomics: read them the same way (a cached copy may be stale)
     unsigned long long n = 0;
     if (threadIdx.x == 0) n = atomicAdd(&a.fix_count[(size_t)seg * 8], 0ull);
@@ -1517,9 +1561,9 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
         __syncthreads();
     }
     if (n > a.fix_cap) n = a.fix_cap;                      // overflow: the host re-runs the stage with k_rays_skip
-    cnt_l2 += (threadIdx.x == 0) ? n : 0;
+    cnt_l2 += (threadIdx.x == 0 && part == 0) ? n : 0;
     const unsigned long long *list = a.fix_list + (size_t)seg * a.fix_cap;
-    for (unsigned long long k = threadIdx.x; k < n; k += blockDim.x) {
+    for (unsigned long long k = (unsigned long long)part * blockDim.x + threadIdx.x; k < n; k += (unsigned long long)blockDim.x * split) {
         const unsigned long long e = atomicAdd(const_cast<unsigned long long *>(&list[k]), 0ull);
         const int64_t i = (int64_t)(e >> 16);
         const int j = (int)(e & 0xFFFF);
@@ -1612,7 +1656,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
             amb0 = lox < loy ? lox : loy;
             in0 = (unsigned)cx0 < (unsigned)a.Wp && (unsigned)cy0 < (unsigned)a.Hp;
         }
-        const short4 qr = a.qr[i];
+        // k_rays_cell does not materialise the ranges: recompute them for the (few) flagged particles
+        short4 qr;
+        if (a.qr) qr = a.qr[i];
+        else { const double t = a.th[i]; qr = quadrant_ranges_of(t, t == t && fabs(t) < 1e6, a.beam_angle, a.B); }
         double acc = 0.0;
         for (int q = 0; q < 4; ++q) {
             if (((fl >> (8 * q)) & 0xFFu) == 0) continue;
