@@ -489,7 +489,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             // order the particles by (tile, cell, heading): bounding box -> bucket histogram (the atomic's return value
             // is the rank inside the bucket) -> exclusive scan -> scatter of pc / qr / index
             const unsigned nb256 = (unsigned)((n + 255) / 256);
-            const int nparts = (int)(mcl::kSortBuckets / mcl::kHistTile);
+            const int nparts = (int)(mcl::kSortKeySpace / mcl::kHistTile);
             const int bstride = n >= (1 << 20) ? 16 : 1;
             hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0,
                                h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox);
@@ -683,7 +683,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_skey, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_srank, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_hist, (size_t)mcl::kSortBuckets * 4));
-    CRT(hipMalloc(&h->d_histpart, (size_t)(mcl::kSortBuckets / mcl::kHistTile) * 4));
+    CRT(hipMalloc(&h->d_histpart, (size_t)(mcl::kSortKeySpace / mcl::kHistTile) * 4));
     CRT(hipMalloc(&h->d_bbox, 4 * sizeof(int)));
     CRT(hipMemset(h->d_fix_over, 0, 16));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
