@@ -15,6 +15,10 @@ from conftest import GOLDEN, make_engine, tracking_cloud
 
 pytestmark = pytest.mark.gpu
 
+
+def KERNELS(engine_mod):
+    return {"auto": engine_mod.RAYS_AUTO, "cell": engine_mod.RAYS_CELL}
+
 ACTION = (0.05, 0.0, 0.01)
 
 
@@ -35,14 +39,14 @@ def test_sensor_table_bit_exact(request, orc, engine_mod, mapname, P):
 
 # ------------------------------------------------------------------------------------------- C (G2)
 @pytest.mark.parametrize("name", ["Spielberg_map", "sibal1"])
-@pytest.mark.parametrize("kernel", ["march", "skip", "skip_l2", "auto"])
+@pytest.mark.parametrize("kernel", ["march", "skip", "skip_l2", "auto", "cell"])
 def test_cast_ray_golden(orc, engine_mod, maps_mod, name, kernel):
     """One particle per golden ray, a single beam at angle 0: step index == fixture (incl. rays that
     start outside the map, inside walls, within a cell of the lower/left edge, axis-aligned)."""
     m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{name}.npz"))
     z = load(f"g2_cast_ray_{name}.npz")
     n = z["x"].size
-    rk = {"march": engine_mod.RAYS_MARCH, "auto": engine_mod.RAYS_AUTO}.get(kernel, engine_mod.RAYS_SKIP)
+    rk = {"march": engine_mod.RAYS_MARCH, "auto": engine_mod.RAYS_AUTO, "cell": engine_mod.RAYS_CELL}.get(kernel, engine_mod.RAYS_SKIP)
     e = make_engine(engine_mod, m, np.zeros(1, np.float32), n, keep_ray_steps=1, ray_kernel=rk,
                     debug_force_exact=2 if kernel == "skip_l2" else 0)
     e.set_particles(np.stack([z["x"], z["y"], z["theta"]]), np.full(n, 1.0 / n))
@@ -50,14 +54,15 @@ def test_cast_ray_golden(orc, engine_mod, maps_mod, name, kernel):
     assert np.array_equal(e.ray_steps()[:, 0].astype(np.int16), z["steps"])
 
 
-def test_cast_ray_many_beams_scattered_particles(orc, engine_mod, sibal1, sibal1_oracle):
+@pytest.mark.parametrize("path", ["auto", "cell"])
+def test_cast_ray_many_beams_scattered_particles(orc, engine_mod, sibal1, sibal1_oracle, path):
     """Particles scattered over the whole (small) map and beyond it: exercises the off-window path."""
     om = sibal1_oracle
     ang = orc.beam_angles(angle_step=5)
     rng = np.random.default_rng(11)
     n = 600
     p = np.stack([om.origin_x + rng.uniform(-2, 20, n), om.origin_y + rng.uniform(-2, 11, n), rng.uniform(-np.pi, np.pi, n)])
-    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1)
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1, ray_kernel=KERNELS(engine_mod)[path])
     e.set_particles(p, np.full(n, 1.0 / n))
     obs = np.full(ang.size, 3.0, np.float32)
     e.sensor_update(obs)
@@ -67,14 +72,15 @@ def test_cast_ray_many_beams_scattered_particles(orc, engine_mod, sibal1, sibal1
     assert np.array_equal(e.log_weights(), logw)
 
 
-def test_global_regime_uses_fallback_and_stays_exact(orc, engine_mod, spielberg, spielberg_oracle):
+@pytest.mark.parametrize("path", ["auto", "cell"])
+def test_global_regime_uses_fallback_and_stays_exact(orc, engine_mod, spielberg, spielberg_oracle, path):
     from monte_carlo_localization_amd import synth
     om = spielberg_oracle
     ang = orc.beam_angles(angle_step=40)
     rng = np.random.default_rng(12)
     n = 2048
     p = synth.global_cloud(rng, spielberg, n)
-    e = make_engine(engine_mod, spielberg, ang, n, keep_ray_steps=1)
+    e = make_engine(engine_mod, spielberg, ang, n, keep_ray_steps=1, ray_kernel=KERNELS(engine_mod)[path])
     e.set_particles(p, np.full(n, 1.0 / n))
     obs = load("scan_Spielberg_map_origin.npz")["ranges"][::40].copy()
     e.sensor_update(obs)
@@ -82,18 +88,27 @@ def test_global_regime_uses_fallback_and_stays_exact(orc, engine_mod, spielberg,
     logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
     assert np.array_equal(e.ray_steps(), steps)
     assert np.array_equal(e.log_weights(), logw)
-    assert e.counters()["off_window_particles"] > 0
+    if path == "auto":       # the cell-sorted slices are compact: hardly any pair misses its window there
+        assert e.counters()["off_window_particles"] > 0
 
 
-def test_nonfinite_particles_do_not_hang_or_crash(orc, engine_mod, sibal1):
+@pytest.mark.parametrize("path", ["auto", "cell"])
+def test_nonfinite_particles_do_not_hang_or_crash(orc, engine_mod, sibal1, path):
     ang = orc.beam_angles(angle_step=60)
     n = 64
     p = np.zeros((3, n))
     p[0, 0] = np.nan; p[1, 1] = np.inf; p[0, 2] = -np.inf; p[2, 3] = np.nan; p[0, 4] = 1e300; p[2, 5] = 1e300
-    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1)
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1, ray_kernel=KERNELS(engine_mod)[path])
     e.set_particles(p, np.full(n, 1.0 / n))
     e.sensor_update(np.full(ang.size, 2.0, np.float32))
     assert e.ray_steps().shape == (n, ang.size)
+    # the finite particles are still exact, and a huge-but-finite heading is marched literally like the oracle does
+    om = orc.OracleMap(sibal1.data, sibal1.resolution, sibal1.origin_x, sibal1.origin_y)
+    fin = np.array([5] + list(range(6, n)))
+    obs = np.full(ang.size, 2.0, np.float32)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    _, steps, _ = orc.eng_log_weights(om, p[:, fin], ang, orc.obs_index(obs, om), L, want_steps=True)
+    assert np.array_equal(e.ray_steps()[fin], steps)
     e.update(ACTION, np.full(ang.size, 2.0, np.float32))     # motion + normalize_angle on garbage must terminate
 
 
@@ -369,7 +384,8 @@ def test_update_scan_downsamples_like_lidarcb(orc, engine_mod, spielberg):
 
 @pytest.mark.parametrize("mapname", ["Spielberg_map", "sibal1", "icra_2_clean", "first_map"])
 @pytest.mark.parametrize("max_range,n_beams_step", [(12.0, 7), (5.0, 13), (3.3, 31)])
-def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_range, n_beams_step):
+@pytest.mark.parametrize("path", ["auto", "cell"])
+def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_range, n_beams_step, path):
     """Every fixture map, three MAX_RANGE_PX values, global clouds (free cells) plus particles inside walls
     and outside the map: steps and log-weights bit-exact vs the oracle through the default kernel."""
     m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{mapname}.npz"))
@@ -381,7 +397,8 @@ def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_r
     n = 1500
     p = synth.global_cloud(rng, m, n)
     p[:2, :100] += rng.normal(0, 3.0, (2, 100))           # some land in walls / outside the map
-    e = make_engine(engine_mod, m, ang, n, keep_ray_steps=1, max_range_m=max_range, squash_factor=3.1)
+    e = make_engine(engine_mod, m, ang, n, keep_ray_steps=1, max_range_m=max_range, squash_factor=3.1,
+                    ray_kernel=KERNELS(engine_mod)[path])
     assert e.max_range_px == om.max_range_px
     e.set_particles(p, np.full(n, 1.0 / n))
     obs = rng.uniform(0.0, max_range * 1.2, ang.size).astype(np.float32)
@@ -394,7 +411,8 @@ def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_r
     assert np.array_equal(e.log_weights(), logw)
 
 
-def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle):
+@pytest.mark.parametrize("path", ["auto", "cell"])
+def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle, path):
     """Window partly outside the map (lower-left corner): out-of-map cells must read as stops, and the
     truncation-toward-zero column/row (pixel coordinates in (-1,0)) must read cell 0."""
     om = sibal1_oracle
@@ -402,7 +420,7 @@ def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle):
     rng = np.random.default_rng(21)
     n = 2000
     p = np.stack([om.origin_x + rng.uniform(-0.2, 1.0, n), om.origin_y + rng.uniform(-0.2, 1.0, n), rng.uniform(-np.pi, np.pi, n)])
-    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1)
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1, ray_kernel=KERNELS(engine_mod)[path])
     e.set_particles(p, np.full(n, 1.0 / n))
     obs = np.full(ang.size, 1.0, np.float32)
     e.sensor_update(obs)
@@ -410,3 +428,45 @@ def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle):
     logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
     assert np.array_equal(e.ray_steps(), steps)
     assert e.counters()["off_window_particles"] == 0
+
+
+# ------------------------------------------------------------------------------------------- cell-sorted path
+def test_cell_kernel_full_turn_scan_and_identical_particles(orc, engine_mod, sibal1, sibal1_oracle):
+    """MCL_RAYS_CELL corner cases: a scan of almost a full turn (a wedge is visited twice: two beam ranges per
+    lane), many particles in one bucket of the sort (identical poses) and a large spread of the rest."""
+    om = sibal1_oracle
+    ang = np.linspace(-np.pi, np.pi - 0.004, 720).astype(np.float32)
+    rng = np.random.default_rng(31)
+    n = 3000
+    p = np.stack([rng.uniform(-1.0, 1.0, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-np.pi, np.pi, n)])
+    p[:, :1000] = np.array([[0.3], [0.1], [0.7]])                       # one hot bucket
+    p[2, 1000:1100] = np.pi * rng.integers(-4, 5, 100) / 8.0             # headings exactly on wedge edges
+    e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1, ray_kernel=engine_mod.RAYS_CELL)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    obs = rng.uniform(0.5, 8.0, ang.size).astype(np.float32)
+    e.sensor_update(obs)
+    assert e.ray_kernel_name() == "k_rays_cell"
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+    assert np.array_equal(e.ray_steps(), steps)
+    assert np.array_equal(e.log_weights(), logw)
+
+
+def test_cell_and_quad_agree_over_updates(orc, engine_mod, spielberg):
+    """Same seed, 70k particles, five updates: the cell-sorted kernel (default at this size) and k_rays_quad give
+    the same particles, weights and pose bit for bit (the sort only changes which rays share a wave)."""
+    from monte_carlo_localization_amd import synth
+    ang = orc.beam_angles(angle_step=9)
+    obs = load("scan_Spielberg_map_origin.npz")["ranges"][::9].copy()
+    n = 70000
+    out = {}
+    for name, rk in (("auto", engine_mod.RAYS_AUTO), ("quad", engine_mod.RAYS_QUAD)):
+        e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=rk, seed=5)
+        e.init_particles_pose((0.0, 0.0, 0.0), n)
+        for _ in range(5):
+            e.update(ACTION, obs)
+        out[name] = (e.ray_kernel_name(), e.get_particles(), e.get_weights(), e.expected_pose())
+    assert out["auto"][0] == "k_rays_cell" and out["quad"][0] == "k_rays_quad"
+    assert np.array_equal(out["auto"][1], out["quad"][1])
+    assert np.array_equal(out["auto"][2], out["quad"][2])
+    assert np.array_equal(out["auto"][3], out["quad"][3])
