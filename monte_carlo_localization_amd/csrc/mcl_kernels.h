@@ -1100,6 +1100,10 @@ __global__ __launch_bounds__(256) void k_wedge_field(const int32_t *__restrict__
 // is an exact sum.
 constexpr int kSortKeyLog2 = 20;
 constexpr uint32_t kSortKeySpace = 1u << kSortKeyLog2;
+#ifndef MCL_SORT_SUB
+#define MCL_SORT_SUB 1
+#endif
+constexpr int kSortSub = MCL_SORT_SUB;               // sort cells per grid cell and axis
 constexpr int kSortXcds = 8;                        // copies of the histogram (XCC_ID & 7)
 constexpr uint32_t kSortBuckets = kSortKeySpace * kSortXcds;
 constexpr int kHistTile = 4096;                     // entries per workgroup of the bucket scan
@@ -1120,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ p
     const int64_t ns = (n + stride - 1) / stride;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (int64_t)gridDim.x * blockDim.x) {
         const double4 c = pc[k * stride];
-        const int cx = cell_of(c.z, Wp - 1), cy = cell_of(c.w, Hp - 1);
+        const int cx = cell_of(c.z * kSortSub, Wp * kSortSub - 1), cy = cell_of(c.w * kSortSub, Hp * kSortSub - 1);
         x0 = min(x0, cx); y0 = min(y0, cy); x1 = max(x1, cx); y1 = max(y1, cy);
     }
 #pragma unroll
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ p
     if (i >= n) return;
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & (kSortXcds - 1);   // HW_REG_XCC_ID[3:0]
     const double4 c = pc[i];
-    const uint32_t key = sort_key(bbox, cell_of(c.z, Wp - 1), cell_of(c.w, Hp - 1), th[i]);
+    const uint32_t key = sort_key(bbox, cell_of(c.z * kSortSub, Wp * kSortSub - 1), cell_of(c.w * kSortSub, Hp * kSortSub - 1), th[i]);
     key_out[i] = key;
     // this XCD's private copy: workgroup scope keeps the read-modify-write in the local L2
     const uint32_t r = __hip_atomic_fetch_add(&hist[(size_t)xcd * kSortKeySpace + key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1284,9 +1288,13 @@ __device__ __forceinline__ int first_beam_in_wedge(double th, const float *__res
     int lo = 0, hi = B;
     const double x = ((double)m * (6.283185307179586476925286766559 / kWedges) - th - a0) * inv_inc;
     if (x > -4.0 && x < (double)B + 4.0) {
-        const int jg = (int)ceil(x);
+        const int jg = min(max((int)ceil(x), 0), B);
+        const bool below = jg == 0 || beam_wedge(th, angle[jg - 1]) < m;      // beam jg-1 is still before wedge m
+        const bool at = jg == B || beam_wedge(th, angle[jg]) >= m;           // beam jg is in wedge m or later
+        if (below && at) return jg;                                           // the usual case: two loads
+        // off by a beam or two (float rounding of the angles): a five-beam bracket when it holds, else [0, B]
         const int l = max(jg - 2, 0), h = min(jg + 2, B);
-        if (l <= h && (l == 0 || beam_wedge(th, angle[l - 1]) < m) && (h == B || beam_wedge(th, angle[h]) >= m)) { lo = l; hi = h; }
+        if ((l == 0 || beam_wedge(th, angle[l - 1]) < m) && (h == B || beam_wedge(th, angle[h]) >= m)) { lo = l; hi = h; }
     }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
