@@ -1383,10 +1383,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         }
         __syncthreads();
     }
-    uint32_t stride_v = (uint32_t)S, gbias_v = kQG1 << (32 - kQFx);
+    // level-1 error bound: 0.5 unit for the origin + 0.5 unit per sample for the direction, s <= P samples;
+    // a sample within that (+4) of a cell boundary sends its ray to the fix-up list
+    const uint32_t guard_units = (uint32_t)(a.P + 1) / 2u + 5u;
+    uint32_t stride_v = (uint32_t)S, gbias_v = guard_units << (32 - kQFx);
     asm volatile("" : "+v"(stride_v), "+v"(gbias_v));
     const unsigned char *ldsb = lds_raw;
-    const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : ((2u * kQG1) << (32 - kQFx));
+    const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : ((2u * guard_units) << (32 - kQFx));
     const int negP = __builtin_amdgcn_readfirstlane(-a.P);
 
     for (int64_t s0g = p_begin + (int64_t)wave * 64; s0g < p_end; s0g += (int64_t)kRayWaves * 64) {
