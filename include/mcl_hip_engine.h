@@ -213,6 +213,12 @@ int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py,
 int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth,
                        const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
                        int64_t child_first, int64_t n_children_total, const double action[3]);
+/* The same with the parents as packed records {x, y, theta, unused} (4 doubles each): one all-gather instead of
+ * three and one fetch per gathered parent.  mcl_export_records copies this engine's current particles in that
+ * form to d_records (N x 32 bytes, device memory). */
+int mcl_export_records(mcl_engine_t *h, void *d_records);
+int mcl_stage_resample_records(mcl_engine_t *h, const void *d_records, const uint64_t *d_cdf, int64_t n_parents,
+                               uint64_t q_total, int64_t child_first, int64_t n_children_total, const double action[3]);
 int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams);
 /* Leave n_cus compute units out of k_rays_quad's persistent grid (it otherwise occupies every CU for the
  * whole kernel, which would serialise a collective launched beside it). */

@@ -1272,6 +1272,24 @@ int mcl_export_state(mcl_engine_t *h, double *d_x, double *d_y, double *d_theta,
     return MCL_OK;
 }
 
+int mcl_export_records(mcl_engine_t *h, void *d_records)
+{
+    if (!h || !d_records) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int c = h->cur;
+    const int64_t n = h->N;
+    if (h->pack_valid[c]) {
+        HIPCHK(h, hipMemcpyAsync(d_records, h->d_pack[c], (size_t)n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_x[c], h->d_y[c], h->d_th[c], n,
+                           reinterpret_cast<double4 *>(d_records));
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
 int mcl_get_scalars(mcl_engine_t *h, double out[8])
 {
     if (!h || !out) return MCL_ERR_INVALID_ARG;
@@ -1281,12 +1299,14 @@ int mcl_get_scalars(mcl_engine_t *h, double out[8])
     return MCL_OK;
 }
 
-int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
-                       int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total, const double action[3])
+static int stage_resample_impl(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const void *d_records,
+                               const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
+                               const double action[3])
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
-    if (!d_px || !d_py || !d_pth || !d_cdf || !action || n_parents <= 0) return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments");
+    if ((!d_records && (!d_px || !d_py || !d_pth)) || !d_cdf || !action || n_parents <= 0)
+        return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t n = h->N;
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
@@ -1294,6 +1314,8 @@ int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, 
     const int nx = h->cur ^ 1;
     mcl::ResampleArgs a{};
     a.px = d_px; a.py = d_py; a.pth = d_pth; a.cdf = d_cdf; a.n_parents = n_parents; a.q_total = q_total;
+    a.ppack = reinterpret_cast<const double4 *>(d_records);
+    a.cpack = h->d_pack[nx];
     a.tile_excl = (h->blocktot_for == d_cdf && h->blocktot_n == n_parents) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
     a.leaders = a.tile_excl ? h->d_leaders : nullptr;
     a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
@@ -1317,13 +1339,25 @@ int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, 
     hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
     h->cur = nx;
-    h->pack_valid[nx] = false;        // the sharded path gathers columns, no packed records
+    h->pack_valid[nx] = true;
     h->have_idx = true;
     h->have_logw = false;
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));           // the children are final: the host may export / gather them now
     h->update_idx++;
     return MCL_OK;
+}
+
+int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
+                       int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total, const double action[3])
+{
+    return stage_resample_impl(h, d_px, d_py, d_pth, nullptr, d_cdf, n_parents, q_total, child_first, n_children_total, action);
+}
+
+int mcl_stage_resample_records(mcl_engine_t *h, const void *d_records, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
+                               int64_t child_first, int64_t n_children_total, const double action[3])
+{
+    return stage_resample_impl(h, nullptr, nullptr, nullptr, d_records, d_cdf, n_parents, q_total, child_first, n_children_total, action);
 }
 
 int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)

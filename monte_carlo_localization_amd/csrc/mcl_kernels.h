@@ -255,6 +255,14 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     if (a.cpack) a.cpack[m] = make_double4(x, y, th, 0.0);
 }
 
+// (x, y, theta) columns -> packed records (the form k_resample_motion gathers parents from)
+__global__ void k_pack_records(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ th, int64_t n,
+                               double4 *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_double4(x[i], y[i], th[i], 0.0);
+}
+
 // lidarCB's downsampled ranges -> table row per beam, cpp:549-554, 570, 573 (NaN -> 0): one block
 __global__ void k_obs_index(const float *__restrict__ obs, int B, double res, int P, int32_t *__restrict__ obs_idx)
 {

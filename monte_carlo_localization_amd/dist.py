@@ -3,15 +3,18 @@ torch.distributed (backend "nccl" == RCCL over xGMI) for the three exchange step
 
 The reference has no distributed code.  The update couples particles only through
   (1) resampling  — children of rank g are drawn from the GLOBAL weighted set: all-gather of the
-                    particle columns and fixed-point weights (24+8 B per particle), exact integer CDF;
+                    particles as packed (x, y, theta, -) records and of the fixed-point weights
+                    (32 + 8 B per particle), exact integer CDF;
   (2) max log-weight — all-reduce(MAX) of one double;
-  (3) normalisation / pose — all-reduce(SUM) of five doubles.
+  (3) normalisation / pose — all-reduce(SUM) of five doubles (+ the two halves of the local
+                    fixed-point weight total, so that the next update knows the global total
+                    without reading it back from the device).
 Everything else (motion, ray cast, likelihood) is local to a shard.  Because the CDF is an exact
 integer scan and the log-weights are exact fp64 sums, resample indices and weights are bit-identical
 for any number of ranks.
 
-`shard` is anything with the staging interface of engine.Engine (export_state / scan_weights /
-stage_propagate / scalars / stage_weights / stage_finish); tests drive this class on CPU tensors over
+`shard` is anything with the staging interface of engine.Engine (export_state / export_records /
+scan_weights / stage_resample_records / stage_rays / scalars / stage_weights / stage_finish); tests drive this class on CPU tensors over
 gloo with an oracle-backed stand-in that lives under tests/.
 """
 from __future__ import annotations
@@ -42,11 +45,12 @@ class ShardedFilter:
         f64, i64 = torch.float64, torch.int64
         n, nt = self.n, self.n * self.world
         self.n_total = nt
-        self.loc = [torch.empty(n, dtype=f64, device=device) for _ in range(3)]
+        self.loc = torch.empty((n, 4), dtype=f64, device=device)        # (x, y, theta, -) records of this shard
         self.loc_q = torch.empty(n, dtype=i64, device=device)           # uint64 bits
-        self.glob = [[torch.empty(nt, dtype=f64, device=device) for _ in range(3)] for _ in range(2 if self.overlap else 1)]
+        self.glob = [torch.empty((nt, 4), dtype=f64, device=device) for _ in range(2 if self.overlap else 1)]
         self.cur = 0
-        self.pending = None                                              # async gathers filling self.glob[self.cur]
+        self.pending = None                                              # async gather filling self.glob[self.cur]
+        self.q_total = None                                              # global fixed-point weight total, once known
         self.glob_q = torch.empty(nt, dtype=i64, device=device)
         self.glob_cdf = torch.empty(nt, dtype=i64, device=device)
         self.pose = np.zeros(3)
@@ -58,37 +62,33 @@ class ShardedFilter:
     def reset(self):
         """Call after the shard's particle state was replaced from outside (set_particles / init_*)."""
         if self.pending is not None:
-            for w in self.pending:
-                w.wait()
+            self.pending.wait()
             self._sync()
         self.pending = None
+        self.q_total = None
 
-    def _gather_columns(self, buf: int, async_op: bool):
-        s = self.shard
-        s.export_state(self.loc[0].data_ptr(), self.loc[1].data_ptr(), self.loc[2].data_ptr(), 0)
-        works = [dist.all_gather_into_tensor(g, l, group=self.group, async_op=async_op) for g, l in zip(self.glob[buf], self.loc)]
-        return works if async_op else None
+    def _gather_records(self, buf: int, async_op: bool):
+        self.shard.export_records(self.loc.data_ptr())
+        return dist.all_gather_into_tensor(self.glob[buf], self.loc, group=self.group, async_op=async_op)
 
     def update(self, action, obs):
         s = self.shard
         # (1) exchange for resampling: particle columns (possibly gathered during the previous update) + weights
         if self.pending is None:
-            self._gather_columns(self.cur, async_op=False)
+            self._gather_records(self.cur, async_op=False)
         else:
-            for w in self.pending:
-                w.wait()
+            self.pending.wait()
             self.pending = None
         s.export_state(0, 0, 0, self.loc_q.data_ptr())
         dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
         self._sync()
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
-        q_total = int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
-        g = self.glob[self.cur]
-        s.stage_resample(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), self.glob_cdf.data_ptr(), self.n_total, q_total,
-                         self.rank * self.n, self.n_total, action)
+        q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
+        s.stage_resample_records(self.glob[self.cur].data_ptr(), self.glob_cdf.data_ptr(), self.n_total, q_total,
+                                 self.rank * self.n, self.n_total, action)
         if self.overlap:
             self.cur ^= 1
-            self.pending = self._gather_columns(self.cur, async_op=True)   # runs beside the ray kernel
+            self.pending = self._gather_records(self.cur, async_op=True)   # runs beside the ray kernel
         s.stage_rays(obs)
         # (2) global max log-weight
         mx = torch.tensor([s.scalars()[0]], dtype=torch.float64, device=self.device)
@@ -96,9 +96,13 @@ class ShardedFilter:
         s.stage_weights(float(mx.item()))
         # (3) global sums: sum w, sum wx, sum wy, sum w sin, sum w cos
         sc = s.scalars()
-        sums = torch.tensor([sc[1], sc[3], sc[4], sc[5], sc[6]], dtype=torch.float64, device=self.device)
+        ql = int(np.float64(sc[2]).view(np.uint64))                      # this shard's fixed-point weight total
+        sums = torch.tensor([sc[1], sc[3], sc[4], sc[5], sc[6], float(ql & 0xFFFFFFFF), float(ql >> 32)],
+                            dtype=torch.float64, device=self.device)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         gs = sums.cpu().numpy()
+        self.q_total = (int(gs[5]) + (int(gs[6]) << 32)) & 0xFFFFFFFFFFFFFFFF     # exact: both halves stay below 2^53
+        gs = gs[:5]
         s.stage_finish(gs)
         k = 1.0 / gs[0] if gs[0] > 0 else 1.0
         self.pose = np.array([gs[1] * k, gs[2] * k, np.arctan2(gs[3] * k, gs[4] * k)])

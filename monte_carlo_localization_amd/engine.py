@@ -27,7 +27,7 @@ EXPORTS = [
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
-    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_stage_resample", "mcl_stage_rays",
+    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
     "mcl_set_reserved_cus",
 ]
 
@@ -321,6 +321,15 @@ class Engine:
         self._chk(self.lib.mcl_stage_resample(self._h, C.c_void_p(d_px), C.c_void_p(d_py), C.c_void_p(d_pth),
                                               C.c_void_p(d_cdf), C.c_int64(n_parents), C.c_uint64(q_total),
                                               C.c_int64(child_first), C.c_int64(n_children_total), _p(a)), "mcl_stage_resample")
+
+    def export_records(self, d_records):
+        self._chk(self.lib.mcl_export_records(self._h, C.c_void_p(d_records)), "mcl_export_records")
+
+    def stage_resample_records(self, d_records, d_cdf, n_parents, q_total, child_first, n_children_total, action):
+        a = _c(action, np.float64)
+        self._chk(self.lib.mcl_stage_resample_records(self._h, C.c_void_p(d_records), C.c_void_p(d_cdf), C.c_int64(n_parents),
+                                                      C.c_uint64(q_total), C.c_int64(child_first), C.c_int64(n_children_total), _p(a)),
+                  "mcl_stage_resample_records")
 
     def stage_rays(self, obs):
         o = _c(obs, np.float32)

@@ -38,6 +38,16 @@ class OracleShard:
         if d_q:
             _view(d_q, n, ctypes.c_uint64, np.uint64)[:] = self.q
 
+    def export_records(self, d_records):
+        v = _view(d_records, 4 * self.n, ctypes.c_double, np.float64).reshape(self.n, 4)
+        v[:, 0], v[:, 1], v[:, 2], v[:, 3] = self.p[0], self.p[1], self.p[2], 0.0
+
+    def stage_resample_records(self, d_records, d_cdf, n_parents, q_total, child_first, n_children_total, action):
+        rec = _view(d_records, 4 * n_parents, ctypes.c_double, np.float64).reshape(n_parents, 4)
+        cols = [np.ascontiguousarray(rec[:, k]) for k in range(3)]
+        self.stage_resample(cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, d_cdf, n_parents, q_total, child_first,
+                            n_children_total, action)
+
     def scan_weights(self, d_q, d_cdf, n, offset=0):
         q = _view(d_q, n, ctypes.c_uint64, np.uint64)
         _view(d_cdf, n, ctypes.c_uint64, np.uint64)[:] = np.cumsum(q, dtype=np.uint64) + np.uint64(offset)
@@ -81,6 +91,7 @@ class OracleShard:
         s = self._scalars
         s[0] = global_max
         s[1] = w.sum()
+        s[2] = np.array([self.q.sum(dtype=np.uint64)], np.uint64).view(np.float64)[0]
         s[3] = (w * self.p[0]).sum(); s[4] = (w * self.p[1]).sum()
         s[5] = (w * np.sin(self.p[2])).sum(); s[6] = (w * np.cos(self.p[2])).sum()
 
