@@ -86,7 +86,11 @@ typedef struct {
                                        2: every ray takes the fp64 skipping loop (level 2)     */
     int32_t debug_count_probes;     /* !=0: tally examined grid probes (counters[2]); slower   */
     int32_t rays_per_lane;          /* SKIP kernel: independent rays in flight per lane (1..4); 0 = default */
-    int32_t reserved[5];
+    int32_t resample_neff_permille; /* 0 (default): resample on every update like the reference (cpp:656-665);
+                                       r in 1..1000: resample only when the effective sample size
+                                       (sum w)^2 / sum w^2 of the previous update is below r/1000 * N, otherwise the
+                                       particles keep their identity and their weights multiply */
+    int32_t reserved[4];
 } mcl_config_t;
 
 /* Fills *cfg with the reference's defaults (config/mcl_config.yaml:6-40, cpp:23-47). */
@@ -169,6 +173,9 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
 int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
 /* which ray kernel the last update ran: 1 k_rays_march, 2 k_rays_skip, 3 k_rays_quad */
 int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel);
+/* Effective sample size (sum w)^2 / sum w^2 of the current weights, and whether the last mcl_update resampled
+ * (always 1 with resample_neff_permille == 0). */
+int mcl_get_effective_sample_size(const mcl_engine_t *h, double *n_eff, int32_t *resampled_last_update);
 
 /* ---- host-side precomputation, callable without a device (what mcl_set_map uploads) --------- */
 /* (P+1)^2 doubles, Eigen column-major (index d*(P+1)+r): the restatement of precompute_sensor_model

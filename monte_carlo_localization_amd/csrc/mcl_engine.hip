@@ -67,6 +67,10 @@ struct mcl_engine {
     double *d_x[2]{}, *d_y[2]{}, *d_th[2]{};
     int cur = 0;
     double *d_w = nullptr, *d_logw = nullptr, *d_tmp = nullptr;   // tmp: cap*3 doubles
+    double *d_carry[2]{};               // logw - max of the last update (adaptive resampling: what a kept particle carries)
+    int carry_idx = 0;                  // d_carry[carry_idx] is current; k_weights writes the other one
+    bool carry_valid = false, carry_pending = false;
+    bool resampled_last = true;
     double *d_logw_acc = nullptr;       // k_rays_quad/far/fix accumulate here with atomics; k_gather_logw copies to d_logw
     uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
     uint64_t *d_leaders = nullptr;      // last CDF entry of every 16-entry group of the array d_blocktot describes
@@ -364,7 +368,10 @@ int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override)
         hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     }
     hipLaunchKernelGGL(mcl::k_weights, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, from_log ? 1 : 0,
-                       h->d_scalars, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, h->d_w, h->d_q, h->d_part);
+                       h->d_scalars, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, h->d_w, h->d_q, h->d_part,
+                       (from_log && h->cfg.resample_neff_permille > 0) ? h->d_carry[h->carry_idx ^ 1] : (double *)nullptr);
+    h->carry_pending = from_log && h->cfg.resample_neff_permille > 0;     // the caller commits it (commit_carry)
+    if (!from_log) h->carry_valid = false;
     hipLaunchKernelGGL(mcl::k_final_sums, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
@@ -619,6 +626,7 @@ const char *mcl_last_error(const mcl_engine_t *h) { return h ? h->err.c_str() : 
 
 int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
 {
+    if (cfg && (cfg->resample_neff_permille < 0 || cfg->resample_neff_permille > 1000)) return MCL_ERR_INVALID_ARG;
     g_create_error.clear();
     if (!cfg || !out) { g_create_error = "null argument"; return MCL_ERR_INVALID_ARG; }
     *out = nullptr;
@@ -663,6 +671,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     }
     CRT(hipMalloc(&h->d_w, nb)); CRT(hipMalloc(&h->d_logw, nb)); CRT(hipMalloc(&h->d_tmp, nb * 3));
     CRT(hipMalloc(&h->d_logw_acc, nb));
+    CRT(hipMalloc(&h->d_carry[0], nb)); CRT(hipMalloc(&h->d_carry[1], nb));
     CRT(hipMalloc(&h->d_q, (size_t)h->cap * 8)); CRT(hipMalloc(&h->d_cdf, (size_t)h->cap * 8));
     h->blocktot_capacity = (size_t)h->cap / mcl::kScanTile + 2;
     CRT(hipMalloc(&h->d_blocktot, h->blocktot_capacity * 8));
@@ -706,7 +715,7 @@ void mcl_destroy(mcl_engine_t *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
-    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
+    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
@@ -1015,6 +1024,15 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
             d_uni = h->d_inject + (size_t)3 * h->cap;
         }
     }
+    // adaptive resampling (off by default): keep the particles when the previous update left an effective sample
+    // size (sum w)^2 / sum w^2 of at least r * N; their weights then multiply, i.e. the log-weights add
+    bool keep = false;
+    if (resample_and_move && h->cfg.resample_neff_permille > 0 && h->carry_valid && !uniforms) {
+        const double sw = h->h_scalars[1], sww = h->h_scalars[7];
+        keep = sww > 0.0 && sw * sw >= ((double)h->cfg.resample_neff_permille / 1000.0) * (double)n * sww;
+    }
+    if (h->cfg.resample_neff_permille > 0 && h->cfg.weight_mode == MCL_WEIGHT_PRODUCT)
+        return fail(h, MCL_ERR_UNSUPPORTED, "resample_neff_permille needs weight_mode LOG");
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
     if (resample_and_move) {
@@ -1047,10 +1065,11 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         }
         motion_scalars(action, a.dt, a.v, a.w);
         a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
-        a.do_resample = 1; a.do_motion = 1;
+        a.do_resample = keep ? 0 : 1; a.do_motion = 1;
         hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
         HIPCHK(h, hipGetLastError());
         h->cur = nx;                       // cpp:689 as a pointer swap
+        h->resampled_last = !keep;
         h->pack_valid[nx] = true;
         h->have_idx = true;
     }
@@ -1060,6 +1079,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
     if (rc) return rc;
+    if (keep) hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     rc = sensor_and_weights(h, nullptr);
     if (rc) return rc;
@@ -1074,6 +1094,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
         rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, true);
         if (rc) return rc;
+        if (keep) hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
         rc = sensor_and_weights(h, nullptr);
         if (rc) return rc;
         rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
@@ -1081,6 +1102,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         rc = fetch_scalars(h);
         if (rc) return rc;
     }
+    if (h->carry_pending) { h->carry_idx ^= 1; h->carry_valid = true; h->carry_pending = false; }   // this update's logw - max
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
     if (resample_and_move) h->update_idx++;
@@ -1185,6 +1207,16 @@ int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel)
 {
     if (!h || !kernel) return MCL_ERR_INVALID_ARG;
     *kernel = h->last_mode;
+    return MCL_OK;
+}
+
+int mcl_get_effective_sample_size(const mcl_engine_t *h, double *n_eff, int32_t *resampled_last_update)
+{
+    if (!h || !n_eff || !resampled_last_update) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    const double sw = h->h_scalars[1], sww = h->h_scalars[7];
+    *n_eff = sww > 0.0 ? sw * sw / sww : 0.0;
+    *resampled_last_update = h->resampled_last ? 1 : 0;
     return MCL_OK;
 }
 

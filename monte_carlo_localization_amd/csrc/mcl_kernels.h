@@ -1802,15 +1802,16 @@ __global__ __launch_bounds__(kRedThreads) void k_weights(const double *__restric
                                                         const double *__restrict__ maxp, const double *__restrict__ x,
                                                         const double *__restrict__ y, const double *__restrict__ th, int64_t n,
                                                         double *__restrict__ w_out, uint64_t *__restrict__ q_out,
-                                                        double *__restrict__ part /* gridDim.x * 8 */)
+                                                        double *__restrict__ part /* gridDim.x * 8 */,
+                                                        double *__restrict__ carry_out /* logw - max, or null */)
 {
-    __shared__ double sm[kRedThreads / 64][6];
+    __shared__ double sm[kRedThreads / 64][7];
     const double mx = *maxp;
-    double sw = 0, swx = 0, swy = 0, sws = 0, swc = 0;
+    double sw = 0, swx = 0, swy = 0, sws = 0, swc = 0, sww = 0;
     uint64_t sq = 0;
     for (int64_t i = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRedThreads) {
         double w, wq;
-        if (from_log) { w = det_exp(logw_or_w[i] - mx); wq = w; }
+        if (from_log) { const double d = logw_or_w[i] - mx; w = det_exp(d); wq = w; if (carry_out) carry_out[i] = d; }
         else {
             w = logw_or_w[i];
             wq = (mx > 0.0 && w > 0.0) ? (w / mx) : 0.0;
@@ -1820,56 +1821,64 @@ __global__ __launch_bounds__(kRedThreads) void k_weights(const double *__restric
         q_out[i] = q;
         double s, c;
         sincos(th[i], &s, &c);
-        sw += w; sq += q; swx += w * x[i]; swy += w * y[i]; sws += w * s; swc += w * c;
+        sw += w; sq += q; swx += w * x[i]; swy += w * y[i]; sws += w * s; swc += w * c; sww += w * w;
     }
-    sw = wave_sum(sw); swx = wave_sum(swx); swy = wave_sum(swy); sws = wave_sum(sws); swc = wave_sum(swc);
+    sw = wave_sum(sw); swx = wave_sum(swx); swy = wave_sum(swy); sws = wave_sum(sws); swc = wave_sum(swc); sww = wave_sum(sww);
     sq = wave_sum_u64(sq);
     int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        sm[wv][0] = sw; sm[wv][1] = __longlong_as_double((long long)sq); sm[wv][2] = swx; sm[wv][3] = swy; sm[wv][4] = sws; sm[wv][5] = swc;
+        sm[wv][0] = sw; sm[wv][1] = __longlong_as_double((long long)sq); sm[wv][2] = swx; sm[wv][3] = swy; sm[wv][4] = sws; sm[wv][5] = swc; sm[wv][6] = sww;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t tq = 0;
-        double t[6] = {0, 0, 0, 0, 0, 0};
+        double t[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < kRedThreads / 64; ++k) {
             t[0] += sm[k][0]; tq += (uint64_t)__double_as_longlong(sm[k][1]);
-            t[2] += sm[k][2]; t[3] += sm[k][3]; t[4] += sm[k][4]; t[5] += sm[k][5];
+            t[2] += sm[k][2]; t[3] += sm[k][3]; t[4] += sm[k][4]; t[5] += sm[k][5]; t[6] += sm[k][6];
         }
         double *p = part + (size_t)blockIdx.x * 8;
-        p[0] = t[0]; p[1] = __longlong_as_double((long long)tq); p[2] = t[2]; p[3] = t[3]; p[4] = t[4]; p[5] = t[5];
+        p[0] = t[0]; p[1] = __longlong_as_double((long long)tq); p[2] = t[2]; p[3] = t[3]; p[4] = t[4]; p[5] = t[5]; p[6] = t[6];
     }
 }
 // scalars[1..6] = fixed-order sums of the partials (scalars[0] = max stays)
 __global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__restrict__ part, int nb, double *__restrict__ scalars)
 {
-    __shared__ double sm[kRedThreads / 64][6];
-    double t[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ double sm[kRedThreads / 64][7];
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t tq = 0;
     for (int i = threadIdx.x; i < nb; i += kRedThreads) {
         const double *p = part + (size_t)i * 8;
-        t[0] += p[0]; tq += (uint64_t)__double_as_longlong(p[1]); t[2] += p[2]; t[3] += p[3]; t[4] += p[4]; t[5] += p[5];
+        t[0] += p[0]; tq += (uint64_t)__double_as_longlong(p[1]); t[2] += p[2]; t[3] += p[3]; t[4] += p[4]; t[5] += p[5]; t[6] += p[6];
     }
-    t[0] = wave_sum(t[0]); t[2] = wave_sum(t[2]); t[3] = wave_sum(t[3]); t[4] = wave_sum(t[4]); t[5] = wave_sum(t[5]);
+    t[0] = wave_sum(t[0]); t[2] = wave_sum(t[2]); t[3] = wave_sum(t[3]); t[4] = wave_sum(t[4]); t[5] = wave_sum(t[5]); t[6] = wave_sum(t[6]);
     tq = wave_sum_u64(tq);
     int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        sm[wv][0] = t[0]; sm[wv][1] = __longlong_as_double((long long)tq); sm[wv][2] = t[2]; sm[wv][3] = t[3]; sm[wv][4] = t[4]; sm[wv][5] = t[5];
+        sm[wv][0] = t[0]; sm[wv][1] = __longlong_as_double((long long)tq); sm[wv][2] = t[2]; sm[wv][3] = t[3]; sm[wv][4] = t[4]; sm[wv][5] = t[5]; sm[wv][6] = t[6];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double r[6] = {0, 0, 0, 0, 0, 0};
+        double r[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t rq = 0;
         for (int k = 0; k < kRedThreads / 64; ++k) {
             r[0] += sm[k][0]; rq += (uint64_t)__double_as_longlong(sm[k][1]);
-            r[2] += sm[k][2]; r[3] += sm[k][3]; r[4] += sm[k][4]; r[5] += sm[k][5];
+            r[2] += sm[k][2]; r[3] += sm[k][3]; r[4] += sm[k][4]; r[5] += sm[k][5]; r[6] += sm[k][6];
         }
         scalars[1] = r[0]; scalars[2] = __longlong_as_double((long long)rq);
         scalars[3] = r[2]; scalars[4] = r[3]; scalars[5] = r[4]; scalars[6] = r[5];
+        scalars[7] = r[6];                      // sum w^2: effective sample size = (sum w)^2 / sum w^2
     }
 }
 
 // out[i] = w[i] / sum (sum > 0) else w[i]   (cpp:680-686)
+// log-weights of an update that kept its particles (no resampling): add what they carried
+__global__ void k_add_carry(double *__restrict__ logw, const double *__restrict__ carry, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) logw[i] += carry[i];
+}
+
 __global__ void k_normalized(const double *__restrict__ w, int64_t n, double sum, double *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -27,7 +27,7 @@ EXPORTS = [
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
-    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
+    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_get_effective_sample_size", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
     "mcl_set_reserved_cus",
 ]
 
@@ -40,7 +40,7 @@ class Config(C.Structure):
         ("motion_dispersion_y", C.c_double), ("motion_dispersion_theta", C.c_double), ("resample_mode", C.c_int32),
         ("weight_mode", C.c_int32), ("ray_kernel", C.c_int32), ("keep_ray_steps", C.c_int32),
         ("debug_force_exact", C.c_int32), ("debug_count_probes", C.c_int32), ("rays_per_lane", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("resample_neff_permille", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -287,6 +287,12 @@ class Engine:
         v = C.c_double()
         self._chk(self.lib.mcl_get_ray_kernel_ms(self._h, C.byref(v)), "mcl_get_ray_kernel_ms")
         return v.value
+
+    def effective_sample_size(self):
+        """(N_eff of the current weights, whether the last update resampled)"""
+        v, r = C.c_double(), C.c_int32()
+        self._chk(self.lib.mcl_get_effective_sample_size(self._h, C.byref(v), C.byref(r)), "mcl_get_effective_sample_size")
+        return v.value, bool(r.value)
 
     def ray_kernel_name(self):
         v = C.c_int32()

@@ -10,6 +10,13 @@ recorded in SURVEY.md Appendix C — "parity unpinned" for this step:
     occ   = shade/255 if negate else (255-shade)/255
     occ > occupied_thresh -> 100 ; occ < free_thresh -> 0 ; else -1
     image row 0 is the TOP of the map, grid row 0 the BOTTOM (vertical flip); data[row*W+col]
+
+The other two documented modes are provided for maps saved with them (same status: restated from the
+nav2 documentation, not pinned by anything in the reference):
+    scale:  transparent pixel -> -1; occ > occupied_thresh -> 100; occ < free_thresh -> 0;
+            else 99 * (occ - free_thresh) / (occupied_thresh - free_thresh), rounded to nearest
+    raw:    value = round(occ * 255) when that is in 0..100, else -1
+The hot path only distinguishes data > 50 (cpp:642) and data == 0 (free list, cpp:199-213).
 """
 from __future__ import annotations
 
@@ -53,15 +60,49 @@ def trinary_from_image(img: np.ndarray, negate: bool, occupied_thresh: float, fr
     return np.ascontiguousarray(grid[::-1])
 
 
+def grid_from_image(img: np.ndarray, mode: str = "trinary", negate: bool = False, occupied_thresh: float = 0.65,
+                    free_thresh: float = 0.196) -> np.ndarray:
+    """Image (grey, grey+alpha, RGB or RGBA; 8 or 16 bit) -> int8 occupancy grid, bottom row first."""
+    if mode == "trinary":
+        return trinary_from_image(img, negate, occupied_thresh, free_thresh)
+    a = np.asarray(img)
+    full = float(np.iinfo(a.dtype).max) if np.issubdtype(a.dtype, np.integer) else 1.0
+    alpha = None
+    if a.ndim == 3:
+        ch = a.shape[2]
+        if ch in (2, 4):
+            alpha = a[..., ch - 1].astype(np.float64) / full
+            a = a[..., : ch - 1]
+        shade = a.astype(np.float64).mean(axis=2) / full
+    else:
+        shade = a.astype(np.float64) / full
+    occ = shade if negate else 1.0 - shade
+    if mode == "scale":
+        ratio = (occ - free_thresh) / (occupied_thresh - free_thresh)
+        grid = np.rint(99.0 * ratio).clip(1, 99).astype(np.int8)
+        grid[occ > occupied_thresh] = 100
+        grid[occ < free_thresh] = 0
+        if alpha is not None:
+            grid[alpha < 1.0] = -1
+    elif mode == "raw":
+        v = np.rint(occ * 255.0)
+        grid = np.where((v >= 0) & (v <= 100), v, -1).astype(np.int8)
+    else:
+        raise ValueError(f"unknown map mode {mode!r} (trinary, scale, raw)")
+    return np.ascontiguousarray(grid[::-1])
+
+
 def load_map_yaml(yaml_path: str) -> OccupancyMap:
+    """<name>.yaml + PNG/PGM/BMP image as nav2 map_server reads them (image, mode, resolution, origin, negate,
+    occupied_thresh, free_thresh)."""
     import yaml
     from PIL import Image
     with open(yaml_path) as f:
         meta = yaml.safe_load(f)
-    img_path = os.path.join(os.path.dirname(yaml_path), meta["image"])
+    img_path = meta["image"] if os.path.isabs(meta["image"]) else os.path.join(os.path.dirname(yaml_path), meta["image"])
     img = np.array(Image.open(img_path))
-    grid = trinary_from_image(img, bool(int(meta.get("negate", 0))), float(meta["occupied_thresh"]),
-                              float(meta["free_thresh"]))
+    grid = grid_from_image(img, str(meta.get("mode", "trinary")), bool(int(meta.get("negate", 0))),
+                           float(meta.get("occupied_thresh", 0.65)), float(meta.get("free_thresh", 0.196)))
     org = meta["origin"]
     return OccupancyMap(grid, np.float32(meta["resolution"]), float(org[0]), float(org[1]),
                         os.path.splitext(os.path.basename(yaml_path))[0])

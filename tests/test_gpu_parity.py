@@ -470,3 +470,52 @@ def test_cell_and_quad_agree_over_updates(orc, engine_mod, spielberg):
     assert np.array_equal(out["auto"][1], out["quad"][1])
     assert np.array_equal(out["auto"][2], out["quad"][2])
     assert np.array_equal(out["auto"][3], out["quad"][3])
+
+
+# ------------------------------------------------------------------------------------------- adaptive resampling
+def test_adaptive_resampling_neff_option(orc, engine_mod, spielberg, spielberg_oracle):
+    """resample_neff_permille = 20 (the reference resamples unconditionally, cpp:656-665): an update
+    keeps its particles while the previous weights have N_eff >= 0.02 N and their log-weights add; once N_eff drops
+    below, it resamples (at 121 beams one update leaves N_eff at about 0.025 N, so the branches alternate).  Particles and total log-weights bit-exact vs the scalar restatement, both branches taken."""
+    om = spielberg_oracle
+    ang = orc.beam_angles(angle_step=9)
+    obs = load("scan_Spielberg_map_origin.npz")["ranges"][::9].copy()
+    n, seed = 3000, 11
+    rng = np.random.default_rng(4)
+    p = tracking_cloud(rng, n, sig=(0.03, 0.03, 0.01))
+    e = make_engine(engine_mod, spielberg, ang, n, seed=seed, resample_neff_permille=20)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    oi = orc.obs_index(obs, om)
+    w = np.full(n, 1.0 / n)
+    q = orc.eng_quantize_weights(w)
+    carry = None
+    kept = []
+    for upd in range(8):
+        neff = w.sum() ** 2 / (w * w).sum()
+        keep = carry is not None and neff >= 0.02 * n
+        assert carry is None or abs(neff / n - 0.02) > 1e-6            # the test input stays away from the threshold
+        if keep:
+            parents = p
+        else:
+            idx = orc.eng_resample_indices(q, 0, n_children=n, k53=orc.eng_philox_k53(seed, upd, 0, n))
+            parents = p[:, idx]
+        p_want = orc.motion_model(parents, ACTION, orc.eng_philox_normals(seed, upd, 0, n))
+        e.update(ACTION, obs)
+        got_neff, resampled = e.effective_sample_size()
+        assert resampled == (not keep), upd
+        p = e.get_particles()                    # device sin/cos differ from libm in the last ulp: continue from the engine's set
+        np.testing.assert_allclose(p, p_want, rtol=1e-12, atol=1e-12)
+        if not keep:
+            assert np.array_equal(e.resample_indices(), idx), upd
+        logw, _, _ = orc.eng_log_weights(om, p, ang, oi, L)
+        if keep:
+            logw = logw + carry
+        carry = logw - logw.max()
+        w = orc.eng_det_exp(carry)
+        q = np.floor(w * 2.0 ** 36).astype(np.uint64)
+        assert np.array_equal(e.log_weights(), logw), upd
+        np.testing.assert_allclose(e.get_weights(), w / w.sum(), rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got_neff, w.sum() ** 2 / (w * w).sum(), rtol=1e-12)
+        kept.append(keep)
+    assert any(kept) and not all(kept[1:]), kept

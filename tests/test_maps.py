@@ -44,3 +44,37 @@ def test_synthetic_levine(maps_mod):
     assert (m.data == 0).sum() > 200000 and (m.data > 50).sum() > 5000
     m2 = maps_mod.synthetic_levine()
     assert np.array_equal(m.data, m2.data)
+
+
+def test_scale_and_raw_modes(maps_mod):
+    img = np.array([[0, 100, 200, 255]], np.uint8)            # occ = 1.0, 0.608, 0.216, 0.0
+    g = maps_mod.grid_from_image(img, "scale", False, 0.65, 0.196)
+    assert g.tolist() == [[100, int(np.rint(99 * (155 / 255 - 0.196) / (0.65 - 0.196))), int(np.rint(99 * (55 / 255 - 0.196) / (0.65 - 0.196))), 0]]
+    la = np.zeros((1, 2, 2), np.uint8); la[0, 0] = (0, 255); la[0, 1] = (0, 10)     # grey + alpha
+    assert maps_mod.grid_from_image(la, "scale").tolist() == [[100, -1]]
+    g = maps_mod.grid_from_image(img, "raw")
+    assert g.tolist() == [[-1, -1, 55, 0]]
+    g = maps_mod.grid_from_image(np.array([[155, 205, 255]], np.uint8), "raw")
+    assert g.tolist() == [[100, 50, 0]]
+
+
+def test_yaml_loader_png_pgm_modes(maps_mod, tmp_path):
+    """PNG and PGM through the YAML loader: trinary default, negate, explicit mode, relative image path, flip."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    shade = rng.choice(np.array([0, 120, 254, 255], np.uint8), size=(7, 9))
+    Image.fromarray(shade).save(tmp_path / "m.png")
+    Image.fromarray(shade).save(tmp_path / "m.pgm")
+    rgb = np.stack([shade, shade, shade], axis=2)
+    Image.fromarray(rgb).save(tmp_path / "c.png")
+    for image, extra in (("m.png", ""), ("m.pgm", ""), ("c.png", ""), ("m.png", "negate: 1\n"), ("m.pgm", "mode: scale\n")):
+        y = tmp_path / "map.yaml"
+        y.write_text(f"image: {image}\nresolution: 0.05\norigin: [-1.5, 2.0, 0.0]\noccupied_thresh: 0.65\nfree_thresh: 0.196\n{extra}")
+        m = maps_mod.load_map_yaml(str(y))
+        mode = "scale" if "scale" in extra else "trinary"
+        want = maps_mod.grid_from_image(shade, mode, "negate" in extra, 0.65, 0.196)
+        assert np.array_equal(m.data, want), (image, extra)
+        assert m.data.shape == (7, 9) and m.resolution == np.float32(0.05) and (m.origin_x, m.origin_y) == (-1.5, 2.0)
+    # the bottom image row is grid row 0
+    m = maps_mod.load_map_yaml(str(y))
+    assert np.array_equal(m.data[0] > 50, maps_mod.grid_from_image(shade, "scale")[0] > 50)
