@@ -697,6 +697,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMemset(h->d_fix_over, 0, 16));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
     CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
+    CRT(hipDeviceSynchronize());        // the memsets above ran on the null stream; everything later uses h->stream
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -778,7 +779,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
         mcl::WedgeRow *d_rows = nullptr;
         std::vector<mcl::WedgeRow> rows(2 * mcl::kWedgeR + 1);
         HIPCHK(h, hipMalloc(&h->d_distw, fsz * mcl::kWedges));
-        HIPCHK(h, hipMemset(h->d_distw, 0, fsz * mcl::kWedges));
+        HIPCHK(h, hipMemsetAsync(h->d_distw, 0, fsz * mcl::kWedges, h->stream));   // same stream as the kernels that fill it
         HIPCHK(h, hipMalloc(&d_nxt, ncell * 4));
         HIPCHK(h, hipMalloc(&d_prv, ncell * 4));
         HIPCHK(h, hipMalloc(&d_rows, rows.size() * sizeof(mcl::WedgeRow)));
