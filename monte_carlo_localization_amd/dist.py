@@ -51,6 +51,7 @@ class ShardedFilter:
         self.cur = 0
         self.pending = None                                              # async gather filling self.glob[self.cur]
         self.q_total = None                                              # global fixed-point weight total, once known
+        self.pending_q = None                                            # async gather of the weights issued by the previous update
         self.glob_q = torch.empty(nt, dtype=i64, device=device)
         self.glob_cdf = torch.empty(nt, dtype=i64, device=device)
         self.pose = np.zeros(3)
@@ -64,7 +65,11 @@ class ShardedFilter:
         if self.pending is not None:
             self.pending.wait()
             self._sync()
+        if self.pending_q is not None:
+            self.pending_q.wait()
+            self._sync()
         self.pending = None
+        self.pending_q = None
         self.q_total = None
 
     def _gather_records(self, buf: int, async_op: bool):
@@ -79,8 +84,12 @@ class ShardedFilter:
         else:
             self.pending.wait()
             self.pending = None
-        s.export_state(0, 0, 0, self.loc_q.data_ptr())
-        dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
+        if self.pending_q is None:
+            s.export_state(0, 0, 0, self.loc_q.data_ptr())
+            dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
+        else:
+            self.pending_q.wait()                                        # issued at the end of the previous update
+            self.pending_q = None
         self._sync()
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
@@ -94,6 +103,11 @@ class ShardedFilter:
         mx = torch.tensor([s.scalars()[0]], dtype=torch.float64, device=self.device)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         s.stage_weights(float(mx.item()))
+        if self.overlap:
+            # this update's fixed-point weights are final: start gathering them for the next update now, beside the
+            # sums all-reduce and the host work between updates
+            s.export_state(0, 0, 0, self.loc_q.data_ptr())
+            self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
         # (3) global sums: sum w, sum wx, sum wy, sum w sin, sum w cos
         sc = s.scalars()
         ql = int(np.float64(sc[2]).view(np.uint64))                      # this shard's fixed-point weight total
