@@ -48,7 +48,7 @@ def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))
     out = {}
-    for label, thr, share in (("all", cores, 0.7), ("one", 1, 0.3)):
+    for label, thr, share in (("all", cores, 0.5), ("three", min(3, cores), 0.2), ("one", 1, 0.3)):   # 3 = stock num_threads (yaml:40)
         orc.omp_threads(thr)
         pp, ww = p.copy(), w.copy()
         times, t_start = [], time.perf_counter()
@@ -68,7 +68,7 @@ def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
     base = {"value": out["all"][0], "unit": "particle*beam/s", "cores": cores, "kind": "port",
             "sample": f"{out['all'][1]} updates of 4000 particles x {ang.size} beams (BASELINE config #1), "
                       f"Spielberg_map, tracking-regime cloud, omp schedule(dynamic) as cpp:593",
-            "single_thread_value": out["one"][0]}
+            "single_thread_value": out["one"][0], "three_thread_value": out["three"][0]}
     return base, sbar
 
 
