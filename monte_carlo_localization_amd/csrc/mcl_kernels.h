@@ -1465,23 +1465,25 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         constexpr bool WRAP = decltype(wrap_tag)::value;
         // software pipeline: the direction of the next beam is requested before this beam's probe loop and the table
         // entry of this beam is added after the next one's, so neither load is waited for where it is issued
-        double2 cs_next = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
+        double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
         float lt_pending = 0.f;
+        bool lt_has = false;                       // lt_pending holds a table entry that is not yet in acc
         for (int t = 0; t < tmax; ++t) {
             const bool valid = t < total;
-            const double2 cs = cs_next;
             const int jcur = j;
             {
                 int jn = j + 1;
                 if (WRAP && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
                 j = min(jn, jlast);
             }
-            cs_next = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
             const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
             const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
+            // cs is dead now: the next beam's direction lands in the same registers while this beam is traced
+            cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
             const uint32_t Pex = mad_i24_s(negP, NUx, P0x), Pey = mad_i24_s(negP, NUy, P0y);
             int rem;
             uint32_t g;
+            bool expired = false;
             if (!COUNT) {
                 // Probe loop as in k_rays_quad with two changes.  The cell byte is read SIGNED: a stop (0xFF = -1) makes
                 // the unsigned subtraction borrow whatever rem holds and leaves rem + 1 > 0, a skip larger than the
@@ -1531,7 +1533,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                       [gb] "v"(gbias_v), [lb] "n"(kQLdsBase)
                     : "memory", "vcc", "scc");
                 // the countdown only expires if the window is malformed (impossible): every ray of the pass to the fix-up list
-                if (__builtin_amdgcn_readfirstlane((int)countdown) < 0) g = 0u;
+                expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
             } else {
                 bool go;
                 int trips = 0;
@@ -1552,10 +1554,11 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                 if (go) g = 0u;
             }
             if (COUNT && valid) ++cnt_probe;
-            const bool amb = valid && g < gthresh;
-            acc += (double)lt_pending;
-            lt_pending = 0.f;
-            if (valid && !amb) {
+            const uint32_t thr = expired ? 0xFFFFFFFFu : gthresh;     // wave-uniform: a scalar select
+            const bool amb = valid && g < thr;
+            if (lt_has) acc += (double)lt_pending;
+            lt_has = valid && !amb;
+            if (lt_has) {
                 const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
                 lt_pending = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Ltr) + mad_u24_s((uint32_t)left, bpad4, (uint32_t)jcur << 2));
                 if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
@@ -1566,7 +1569,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                     atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)i << 16) | (unsigned long long)jcur);
             }
         }
-        acc += (double)lt_pending;
+        if (lt_has) acc += (double)lt_pending;
         };
         if (wraps) walk(std::true_type{}); else walk(std::false_type{});
         if (live) atomicAdd(&a.logw[i], acc);
