@@ -1466,9 +1466,12 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
         // software pipeline: the direction of the next beam is requested before this beam's probe loop and the table
         // entry of this beam is added after the next one's, so neither load is waited for where it is issued
         double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
-        float lt_pending = 0.f;
-        bool lt_has = false;                       // lt_pending holds a table entry that is not yet in acc
+        float lt_pending = 0.f;                    // table entry of the previous beam (0 when it had none), not yet in acc
         for (int t = 0; t < tmax; ++t) {
+            // consume the previous beam's entry first: its register is then free for this beam's load, and the wait
+            // for it sits a whole beam after its issue
+            acc += (double)lt_pending;
+            asm volatile("" : "+v"(acc));
             const bool valid = t < total;
             const int jcur = j;
             {
@@ -1556,9 +1559,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
             if (COUNT && valid) ++cnt_probe;
             const uint32_t thr = expired ? 0xFFFFFFFFu : gthresh;     // wave-uniform: a scalar select
             const bool amb = valid && g < thr;
-            if (lt_has) acc += (double)lt_pending;
-            lt_has = valid && !amb;
-            if (lt_has) {
+            lt_pending = 0.f;
+            if (valid && !amb) {
                 const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
                 lt_pending = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Ltr) + mad_u24_s((uint32_t)left, bpad4, (uint32_t)jcur << 2));
                 if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
@@ -1569,7 +1571,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
                     atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)i << 16) | (unsigned long long)jcur);
             }
         }
-        if (lt_has) acc += (double)lt_pending;
+        acc += (double)lt_pending;
         };
         if (wraps) walk(std::true_type{}); else walk(std::false_type{});
         if (live) atomicAdd(&a.logw[i], acc);
