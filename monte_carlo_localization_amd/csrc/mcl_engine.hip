@@ -456,9 +456,11 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int spc = ns_env ? atoi(ns_env) : 32;
         int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
         if (cell) {
-            // k_rays_cell: a slice is a run of the sorted order; 2048 particles = two 64-particle groups per wave
+            // k_rays_cell: a slice is a run of the sorted order; 2048 particles = two 64-particle groups per wave.  Longer
+            // slices amortise the window load better, shorter ones balance the persistent workgroups better
+            // (measured at 4M: 1024/2048/4096/8192/16384 -> 8.59/8.04/7.86/7.96/8.64 ms; at 256k: 2048/4096 -> 0.68/0.79 ms)
             const char *cs_env = getenv("MCL_CELL_SLICE");
-            const int64_t slice_len = cs_env ? std::max<int64_t>(64, atoll(cs_env)) : 2048;
+            const int64_t slice_len = cs_env ? std::max<int64_t>(64, atoll(cs_env)) : (n >= (1 << 21) ? 4096 : 2048);
             nsl = (int)std::max<int64_t>(1, (n + slice_len - 1) / slice_len);
         }
         const int nseg = (int)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), (cell ? mcl::kWedges : 4) * (int64_t)nsl);   // one segment per persistent workgroup
