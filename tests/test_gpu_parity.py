@@ -519,3 +519,24 @@ def test_adaptive_resampling_neff_option(orc, engine_mod, spielberg, spielberg_o
         np.testing.assert_allclose(got_neff, w.sum() ** 2 / (w * w).sum(), rtol=1e-12)
         kept.append(keep)
     assert any(kept) and not all(kept[1:]), kept
+
+
+def test_cell_kernel_irregular_beam_angles(orc, engine_mod, sibal1, sibal1_oracle):
+    """Beam angles that increase but are not evenly spaced (gaps, clusters, a few nearly equal): the closed-form guess
+    for a wedge's first beam is useless here and the bisection fallback has to find the ranges."""
+    om = sibal1_oracle
+    rng = np.random.default_rng(41)
+    ang = np.sort(np.concatenate([rng.uniform(-2.8, -1.0, 150), rng.uniform(-0.2, -0.19, 40), rng.uniform(0.5, 2.9, 210),
+                                  np.array([-np.pi / 2, 0.0, np.pi / 8, np.pi / 2])])).astype(np.float32)
+    ang = np.unique(ang)
+    n = 2500
+    p = np.stack([rng.uniform(-1.0, 1.0, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-np.pi, np.pi, n)])
+    for rk in (engine_mod.RAYS_CELL, engine_mod.RAYS_QUAD):
+        e = make_engine(engine_mod, sibal1, ang, n, keep_ray_steps=1, ray_kernel=rk)
+        e.set_particles(p, np.full(n, 1.0 / n))
+        obs = rng.uniform(0.5, 8.0, ang.size).astype(np.float32)
+        e.sensor_update(obs)
+        L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+        logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+        assert np.array_equal(e.ray_steps(), steps)
+        assert np.array_equal(e.log_weights(), logw)
