@@ -540,3 +540,46 @@ def test_cell_kernel_irregular_beam_angles(orc, engine_mod, sibal1, sibal1_oracl
         logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
         assert np.array_equal(e.ray_steps(), steps)
         assert np.array_equal(e.log_weights(), logw)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_maps_every_kernel(orc, engine_mod, maps_mod, seed):
+    """Randomised geometry: thin and diagonal walls, isolated occupied cells, unknown patches, obstacles on the map
+    border; random resolution, MAX_RANGE, beam set and particle spread (inside walls and outside the map included).
+    Every ray kernel returns the oracle's steps and log-weights."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(180, 330)), int(rng.integers(180, 330))
+    g = np.zeros((H, W), np.int8)
+    for _ in range(int(rng.integers(4, 14))):                      # axis-aligned and diagonal wall segments
+        x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+        L = int(rng.integers(10, 120)); dx, dy = [(1, 0), (0, 1), (1, 1), (1, -1), (2, 1), (1, 3)][int(rng.integers(0, 6))]
+        for k in range(L):
+            x, y = x0 + (k * dx) // max(abs(dx), abs(dy)), y0 + (k * dy) // max(abs(dx), abs(dy))
+            if 0 <= x < W and 0 <= y < H:
+                g[y, x] = 100
+    g[rng.random(g.shape) < 0.004] = 100                           # isolated cells
+    g[rng.random(g.shape) < 0.01] = -1                             # unknown: transparent (cpp:642 tests > 50 only)
+    if seed % 2:
+        g[0, :] = 100; g[:, -1] = 100                              # walls on two borders
+    res = np.float32([0.05, 0.05796, 0.1, 0.043][seed % 4])
+    m = maps_mod.OccupancyMap(g, res, float(rng.uniform(-20, 5)), float(rng.uniform(-20, 5)), f"rand{seed}")
+    max_range = float(rng.uniform(4.0, min(12.0, 250 * float(res))))
+    om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y, max_range_m=max_range)
+    B = int(rng.integers(40, 140))
+    ang = np.unique(np.sort(rng.uniform(-2.6, 2.6, B)).astype(np.float32))
+    n = 1500
+    cx, cy = m.origin_x + W * float(res) * rng.uniform(0.2, 0.8), m.origin_y + H * float(res) * rng.uniform(0.2, 0.8)
+    spread = float(rng.choice([0.3, 2.0, 8.0]))
+    p = np.stack([cx + rng.normal(0, spread, n), cy + rng.normal(0, spread, n), rng.uniform(-np.pi, np.pi, n)])
+    obs = rng.uniform(0.0, max_range * 1.1, ang.size).astype(np.float32)
+    T = orc.sensor_table(om.max_range_px)
+    L = orc.eng_log_table(T)
+    logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
+    for rk in (engine_mod.RAYS_CELL, engine_mod.RAYS_QUAD, engine_mod.RAYS_SKIP):
+        e = make_engine(engine_mod, m, ang, n, keep_ray_steps=1, max_range_m=max_range, ray_kernel=rk)
+        assert e.max_range_px == om.max_range_px
+        e.set_particles(p, np.full(n, 1.0 / n))
+        e.sensor_update(obs)
+        got = e.ray_steps()
+        assert np.array_equal(got, steps), (rk, int((got != steps).sum()))
+        assert np.array_equal(e.log_weights(), logw), rk
