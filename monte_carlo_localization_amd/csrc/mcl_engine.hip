@@ -102,6 +102,8 @@ struct mcl_engine {
     uint32_t *d_perm = nullptr, *d_skey = nullptr, *d_srank = nullptr;   // cap each
     uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
     int *d_bbox = nullptr;              // 4
+    double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
+    size_t slice_mean_capacity = 0;
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
@@ -509,7 +511,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);
             hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_skey, h->d_srank,
                                h->d_hist, h->d_pcs, h->d_ths, h->d_perm);
-            a.pcs = h->d_pcs; a.ths = h->d_ths; a.perm = h->d_perm;
+            if ((size_t)nsl > h->slice_mean_capacity) {
+                dfree(h->d_slice_mean);
+                HIPCHK(h, hipMalloc(&h->d_slice_mean, (size_t)nsl * sizeof(double2)));
+                h->slice_mean_capacity = nsl;
+            }
+            hipLaunchKernelGGL(mcl::k_slice_means, dim3((unsigned)nsl), dim3(256), 0, h->stream, h->d_pcs, n, (n + nsl - 1) / nsl, h->d_slice_mean);
+            a.pcs = h->d_pcs; a.ths = h->d_ths; a.perm = h->d_perm; a.slice_mean = h->d_slice_mean;
             a.distw = h->d_distw; a.distw_stride = (size_t)h->Hp * h->Wps;
         }
         size_t qlds = (size_t)h->qside * h->qside;
@@ -719,7 +727,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_fix_list); dfree(h->d_fix_count);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);

@@ -356,6 +356,7 @@ struct RayArgs {
     const double4 *pcs;            // k_rays_cell: pc in cell-sorted order (k_sort_scatter)
     const uint32_t *perm;          // k_rays_cell: sorted slot -> particle index
     const double *ths;             // k_rays_cell: heading in cell-sorted order
+    const double2 *slice_mean;     // k_rays_cell: mean pixel position of every slice of the sorted order (k_slice_means)
     const uint8_t *distw;          // k_rays_cell: kWedges wedge fields (mcl_wedge.h), field k at distw + k * distw_stride
     size_t distw_stride;
     int qside;                     // k_rays_quad: window side in cells (1 byte per cell)
@@ -1288,6 +1289,29 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const double4 *__restrict_
     perm[slot] = (uint32_t)i;
 }
 
+// mean pixel position of every slice of `per` sorted particles (non-finite positions excluded): k_rays_cell centres
+// the sixteen wedge windows of a slice on it
+__global__ __launch_bounds__(256) void k_slice_means(const double4 *__restrict__ pcs, int64_t n, int64_t per, double2 *__restrict__ out)
+{
+    __shared__ double sm[4][3];
+    const int64_t p_begin = (int64_t)blockIdx.x * per;
+    const int64_t p_end = (p_begin + per < n) ? p_begin + per : n;
+    double sx = 0.0, sy = 0.0, cnt = 0.0;
+    for (int64_t s = p_begin + threadIdx.x; s < p_end; s += blockDim.x) {
+        const double4 c = pcs[s];
+        if (c.z == c.z && c.w == c.w && fabs(c.z) < 1e9 && fabs(c.w) < 1e9) { sx += c.z; sy += c.w; cnt += 1.0; }
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = sx; sm[threadIdx.x >> 6][1] = sy; sm[threadIdx.x >> 6][2] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sx = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+        sy = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+        cnt = sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2];
+        out[blockIdx.x] = cnt > 0.0 ? make_double2(sx / cnt, sy / cnt) : make_double2(0.0, 0.0);
+    }
+}
+
 // first beam j with beam_wedge(th, angle[j]) >= m (beam angles increase, so the wedge index is monotone in j).
 // For the usual evenly spaced scan the answer is within a beam or two of (m * 2pi/K - th - a0) / increment: the
 // bisection starts from a five-beam bracket around that guess when the bracket holds and from [0, B] otherwise.
@@ -1349,32 +1373,22 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
     const int mlo = 3;
     int wx0, wy0;
     {
-        double *red = reinterpret_cast<double *>(lds_raw);
-        double sx = 0.0, sy = 0.0;
-        for (int64_t s = p_begin + threadIdx.x; s < p_end; s += kRayThreads) {
-            double4 c = a.pcs[s];
-            double gx = c.z, gy = c.w;
-            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; }
-        }
-        sx = wave_sum(sx); sy = wave_sum(sy);
-        if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
-        __syncthreads();
-        double mx = 0.0, my = 0.0;
-        for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
-        int64_t cntp = p_end - p_begin;
-        mx /= (double)cntp; my /= (double)cntp;
+        const double2 mm = a.slice_mean[slice];                          // wave-uniform: scalar loads
+        const double mx = mm.x, my = mm.y;
         const int E = S - (a.P + 2) - mlo;
         const int back = E / 2 + mlo;
         int cxm = (int)floor(mx) + 1, cym = (int)floor(my) + 1;
         wx0 = sxp ? cxm - back : cxm + back - S;
         wy0 = syp ? cym - back : cym + back - S;
-        __syncthreads();
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
         const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
         const int wpr = S >> 3;
         const int nwords = wpr * S;
-        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
-            int row = wi / wpr, cw = wi - row * wpr;
+        // thread t copies words t, t + 1024, ...: (row, word-in-row) advance by constants, no division in the loop
+        const int drow = kRayThreads / wpr, dcw = kRayThreads - drow * wpr;
+        int row = (int)threadIdx.x / wpr, cw = (int)threadIdx.x - row * wpr;
+        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads, row += drow, cw += dcw) {
+            if (cw >= wpr) { cw -= wpr; ++row; }
             int gy = wy0 + row, gx = wx0 + cw * 8;
             // the wedge fields are stored in the LDS encoding (stop = 0xFF, skips 1..127); outside the grid is stop
             uint64_t b8 = ~0ull;
