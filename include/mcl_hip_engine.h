@@ -207,6 +207,9 @@ int mcl_device_ptr(mcl_engine_t *h, int32_t which, void **dev_ptr);
 int mcl_export_state(mcl_engine_t *h, double *d_x, double *d_y, double *d_theta, uint64_t *d_q);
 /* Host copy of SCALARS (see mcl_buffer_id), valid after stage_propagate / stage_weights / update. */
 int mcl_get_scalars(mcl_engine_t *h, double out[8]);
+/* The host copy of SCALARS the last stage call already read back (valid right after mcl_stage_rays: [0] = local
+ * max log-weight; after mcl_stage_weights: the local sums): no device access, no synchronisation. */
+int mcl_get_host_scalars(const mcl_engine_t *h, double out[8]);
 /* Stage 1: resample this rank's n children [child_first, child_first+n) out of the GLOBAL parent
  * set (device pointers, n_parents entries each: columns + inclusive global CDF of q with total
  * q_total), apply motion, cast rays, leave log-weights and the local max in SCALARS[0]. */

@@ -1342,6 +1342,13 @@ int mcl_get_scalars(mcl_engine_t *h, double out[8])
     return MCL_OK;
 }
 
+int mcl_get_host_scalars(const mcl_engine_t *h, double out[8])
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    std::memcpy(out, h->h_scalars, 8 * sizeof(double));
+    return MCL_OK;
+}
+
 static int stage_resample_impl(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const void *d_records,
                                const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
                                const double action[3])
@@ -1423,6 +1430,7 @@ int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(h->h_scalars, h->h_result, 8 * sizeof(double));       // [0] = local max log-weight (mcl_get_host_scalars)
         std::memcpy(h->h_counters, h->h_result + 8, 4 * sizeof(unsigned long long));
         h->h_fix_count = h->h_result[12];
         if (!(h->last_quad && h->h_fix_count != 0)) break;        // work-list overflow: once more with k_rays_skip (see do_update)

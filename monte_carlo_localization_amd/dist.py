@@ -100,7 +100,8 @@ class ShardedFilter:
             self.pending = self._gather_records(self.cur, async_op=True)   # runs beside the ray kernel
         s.stage_rays(obs)
         # (2) global max log-weight
-        mx = torch.tensor([s.scalars()[0]], dtype=torch.float64, device=self.device)
+        read = getattr(s, "host_scalars", s.scalars)                      # the stage calls already read SCALARS back
+        mx = torch.tensor([read()[0]], dtype=torch.float64, device=self.device)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         s.stage_weights(float(mx.item()))
         if self.overlap:
@@ -109,7 +110,7 @@ class ShardedFilter:
             s.export_state(0, 0, 0, self.loc_q.data_ptr())
             self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
         # (3) global sums: sum w, sum wx, sum wy, sum w sin, sum w cos
-        sc = s.scalars()
+        sc = read()
         ql = int(np.float64(sc[2]).view(np.uint64))                      # this shard's fixed-point weight total
         sums = torch.tensor([sc[1], sc[3], sc[4], sc[5], sc[6], float(ql & 0xFFFFFFFF), float(ql >> 32)],
                             dtype=torch.float64, device=self.device)

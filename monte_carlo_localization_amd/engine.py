@@ -27,7 +27,7 @@ EXPORTS = [
     "mcl_get_ray_steps", "mcl_get_log_weights", "mcl_get_counters", "mcl_get_ray_kernel_ms", "mcl_device_ptr",
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
-    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_get_effective_sample_size", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
+    "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_get_effective_sample_size", "mcl_get_host_scalars", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
     "mcl_set_reserved_cus",
 ]
 
@@ -312,6 +312,12 @@ class Engine:
     def scalars(self):
         out = np.empty(8)
         self._chk(self.lib.mcl_get_scalars(self._h, _p(out)), "mcl_get_scalars")
+        return out
+
+    def host_scalars(self):
+        """SCALARS as the last stage call read them back (no device access)."""
+        out = np.empty(8)
+        self._chk(self.lib.mcl_get_host_scalars(self._h, _p(out)), "mcl_get_host_scalars")
         return out
 
     def stage_propagate(self, d_px, d_py, d_pth, d_cdf, n_parents, q_total, child_first, n_children_total, action, obs):
