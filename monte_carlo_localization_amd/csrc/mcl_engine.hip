@@ -715,6 +715,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #undef CRT
     *out = h;
     return MCL_OK;
