@@ -29,6 +29,8 @@ enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_K0, EV_K1, EV
 
 static_assert(MCL_WEDGES == mcl::kWedges, "include/mcl_hip_engine.h and csrc/mcl_wedge.h disagree");
 
+constexpr unsigned long long kExactCap = 1ull << 16;   // level-3 rays per launch handled by k_rays_exact (more: inline)
+
 struct mcl_engine {
     mcl_config_t cfg{};
     int num_cu = 256;
@@ -91,6 +93,7 @@ struct mcl_engine {
     bool quad_ok = false;               // beam angles monotone over less than a full turn
     int qside = 0;                      // k_rays_quad window side (0: not usable for this map)
     unsigned long long *d_fix_list = nullptr, *d_fix_count = nullptr, *d_fix_over = nullptr;
+    unsigned long long *d_exact_list = nullptr;   // level-3 rays for k_rays_exact; its counter is word 14 of d_result
     unsigned long long fix_cap = 0, fix_alloc = 0;
     size_t fix_count_alloc = 0;
     int fix_segments = 0;
@@ -485,13 +488,14 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         a.qside = h->qside;
         a.nslices = nsl;
         a.fix_list = h->d_fix_list; a.fix_count = h->d_fix_count; a.fix_cap = h->fix_cap; a.fix_segments = nseg;
+        a.exact_list = h->d_exact_list; a.exact_count = h->d_result + 14; a.exact_cap = kExactCap;
         a.far_flags = h->d_far;
         a.work_counter = h->d_fix_over + 1;                // second word of the 16-byte scratch block
         a.logw = h->d_logw_acc;
         {   // per-particle constants; the same pass zeroes the stage's scratch (partial sums are added atomically)
             mcl::PrepClear clr{};
             clr.logw_acc = h->d_logw_acc; clr.far_flags = reinterpret_cast<uint32_t *>(h->d_far);
-            clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over;
+            clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over; clr.exact_count = h->d_result + 14;
             if (cell) { clr.bbox = h->d_bbox; clr.hist = h->d_hist; clr.hist_n = mcl::kSortBuckets; }
             hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
                                h->res, h->d_pc, h->d_angle, h->B, cell ? (short4 *)nullptr : h->d_qr, clr);
@@ -535,6 +539,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         } else {
             if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
@@ -542,6 +547,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((mcl::k_rays_exact<false>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         }
         hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
@@ -692,6 +698,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     h->d_scalars = reinterpret_cast<double *>(h->d_result);
     h->d_counters = h->d_result + 8;
     h->d_fix_over = h->d_result + 12;
+    CRT(hipMalloc(&h->d_exact_list, (size_t)kExactCap * 8));
     CRT(hipMalloc(&h->d_inject, nb * 4));
     CRT(hipMalloc(&h->d_pc, (size_t)h->cap * sizeof(double4)));
     CRT(hipMalloc(&h->d_qr, (size_t)h->cap * sizeof(short4)));
@@ -729,7 +736,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);

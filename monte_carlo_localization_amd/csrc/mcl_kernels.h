@@ -365,6 +365,9 @@ struct RayArgs {
     unsigned long long *fix_count; // per workgroup of k_rays_quad (stride 8 words): entries appended (> fix_cap: overflow)
     unsigned long long fix_cap;    // capacity of one workgroup's segment
     int fix_segments;              // number of segments = workgroups of k_rays_quad
+    unsigned long long *exact_list;   // k_rays_fix -> k_rays_exact: rays that need the literal march (level 3)
+    unsigned long long *exact_count;  // entries appended (beyond exact_cap: marched inline by k_rays_fix)
+    unsigned long long exact_cap;
     uint8_t *far_flags;            // [particle][quadrant]: pair does not fit its quadrant window -> k_rays_far
     unsigned long long *work_counter;  // k_rays_quad: next (slice, quadrant) item
     unsigned long long *dbg;       // optional [workgroup][4]: start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID
@@ -449,6 +452,7 @@ struct PrepClear {
     unsigned long long *fix_count;     // fix_words 64-bit words
     int fix_words;
     unsigned long long *fix_over;      // 2 words (overflow flag, work counter)
+    unsigned long long *exact_count;   // 1 word
     int *bbox;                         // 4: +big, +big, -big, -big
     uint32_t *hist;                    // hist_n bucket counters
     uint32_t hist_n;
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     if (clr.far_flags) clr.far_flags[i] = 0u;
     if (clr.fix_count) for (int64_t k = i; k < clr.fix_words; k += n) clr.fix_count[k] = 0ull;
     if (clr.fix_over) for (int64_t k = i; k < 2; k += n) clr.fix_over[k] = 0ull;
+    if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
     if (clr.bbox) for (int64_t k = i; k < 4; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (int)0x80000000;
     if (clr.hist) for (int64_t k = i; k < clr.hist_n; k += n) clr.hist[k] = 0u;
     const double t = th[i];
@@ -1643,6 +1648,12 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
             r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, d > 1 ? d : 1, amb, np);
         }
         if (!sane || amb < kGuard || a.force_exact == 1) {
+            // level 3, the literal march: 207 dependent steps in one thread would set the duration of this kernel, so the
+            // (few) rays that need it go to k_rays_exact, which gives each of them a whole wave
+            if (a.exact_list) {
+                const unsigned long long slot = atomicAdd(a.exact_count, 1ull);
+                if (slot < a.exact_cap) { atomicExch(&a.exact_list[slot], e); continue; }
+            }
             r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
             ++cnt_exact;
         }
@@ -1656,6 +1667,51 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
         if (COUNT && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
         if (cnt_l2) atomicAdd(&a.counters[3], cnt_l2);
     }
+}
+
+// Level 3 for the rays k_rays_fix handed over: the literal march of cast_ray (cpp:611-650), one WAVE per ray.  Lane l
+// accumulates `current += d` l+1 times exactly as the reference's single accumulator does (same additions in the same
+// order, so the same bits), then the 64 lanes test 64 consecutive samples at once; the first stop wins.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_rays_exact(RayArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long wave_id = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    unsigned long long n = 0;
+    if (lane == 0) n = atomicAdd(a.exact_count, 0ull);
+    n = (unsigned long long)__shfl((long long)n, 0, 64);
+    if (n > a.exact_cap) n = a.exact_cap;
+    unsigned long long done = 0;
+    for (unsigned long long k = wave_id; k < n; k += nwaves) {
+        unsigned long long e = 0;
+        if (lane == 0) e = atomicAdd(&a.exact_list[k], 0ull);
+        e = (unsigned long long)__shfl((long long)e, 0, 64);
+        const int64_t i = (int64_t)(e >> 16);
+        const int j = (int)(e & 0xFFFF);
+        const double angle = a.th[i] + (double)a.beam_angle[j];
+        const double dx = cos(angle) * a.res, dy = sin(angle) * a.res;
+        double cx = a.x[i], cy = a.y[i];
+        for (int t = 0; t <= lane; ++t) { cx += dx; cy += dy; }        // sample lane + 1 of the sequential accumulation
+        int r = a.P;
+        for (int base = 0; base < a.P; base += 64) {
+            const int step = base + lane;
+            bool hit = false;
+            if (step < a.P) {
+                const int gx = (int)((cx - a.ox) / a.res), gy = (int)((cy - a.oy) / a.res);
+                hit = gx < 0 || gx >= a.W || gy < 0 || gy >= a.H || a.grid[(size_t)gy * a.W + gx] > 50;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) { r = base + (__ffsll((long long)m) - 1); break; }
+            for (int t = 0; t < 64; ++t) { cx += dx; cy += dy; }        // 64 samples further
+        }
+        if (lane == 0) {
+            atomicAdd(&a.logw[i], (double)a.Lt[(size_t)r * a.bpad + j]);
+            if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+            ++done;
+        }
+    }
+    if (a.counters && lane == 0 && done) atomicAdd(&a.counters[0], done);
 }
 
 // log-weights accumulated with memory-side fp64 atomics must be read back the same way: a plain load may be
