@@ -453,17 +453,18 @@ def test_cell_kernel_full_turn_scan_and_identical_particles(orc, engine_mod, sib
 
 
 def test_cell_and_quad_agree_over_updates(orc, engine_mod, spielberg):
-    """Same seed, 70k particles, five updates: the cell-sorted kernel (default at this size) and k_rays_quad give
-    the same particles, weights and pose bit for bit (the sort only changes which rays share a wave)."""
+    """Same seed, 200k particles, thirty updates: the cell-sorted kernel (default at this size) and k_rays_quad give
+    the same particles, weights and pose bit for bit (the sort only changes which rays share a wave; a lost or
+    duplicated slot of the per-XCD counting sort would show up here)."""
     from monte_carlo_localization_amd import synth
     ang = orc.beam_angles(angle_step=9)
     obs = load("scan_Spielberg_map_origin.npz")["ranges"][::9].copy()
-    n = 70000
+    n = 200000
     out = {}
     for name, rk in (("auto", engine_mod.RAYS_AUTO), ("quad", engine_mod.RAYS_QUAD)):
         e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=rk, seed=5)
         e.init_particles_pose((0.0, 0.0, 0.0), n)
-        for _ in range(5):
+        for _ in range(30):
             e.update(ACTION, obs)
         out[name] = (e.ray_kernel_name(), e.get_particles(), e.get_weights(), e.expected_pose())
     assert out["auto"][0] == "k_rays_cell" and out["quad"][0] == "k_rays_quad"
