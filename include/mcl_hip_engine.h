@@ -58,8 +58,8 @@ typedef enum {
 } mcl_weight_mode;
 
 typedef enum {
-    MCL_RAYS_AUTO = 0,            /* MCL_RAYS_CELL (>= 65536 particles) or MCL_RAYS_QUAD when the map and beam
-                                     set allow them, else MCL_RAYS_SKIP                                */
+    MCL_RAYS_AUTO = 0,            /* MCL_RAYS_CELL from 65536 particles and 2^23 rays when the map and beam set
+                                     allow it, else MCL_RAYS_SKIP                                      */
     MCL_RAYS_MARCH = 1,           /* literal fixed-step fp64 march on the int8 grid (cpp:611-650)      */
     MCL_RAYS_SKIP = 2,            /* same sample lattice, empty-space skipping on an LDS-resident
                                      distance-to-obstacle window; exactness guard falls back to MARCH  */

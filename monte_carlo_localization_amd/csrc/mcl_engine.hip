@@ -433,11 +433,15 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     if (force_skip && mode == 3) mode = 2;
     if ((h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_CELL) && mode != 3 && !force_skip)
         return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD / MCL_RAYS_CELL not usable with this map / beam set");
-    // one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
-    // with 64-particle groups; below that the beams of one particle are the better source of parallelism
+    // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
+    // with 64-particle groups and enough rays to amortise the sort (measured, wall ms skip / quad / cell:
+    // 4096 x 1081 0.16/0.28/0.40, 65536 x 1081 0.55/0.56/0.44, 65536 x 61 0.21/0.33/0.25, 262144 x 61 0.47/0.76/0.40);
+    // below that the self-contained k_rays_skip (one launch, no work lists) is the quickest
     const char *cell_env = getenv("MCL_CELL_MIN");
     const int64_t cell_min = cell_env ? atoll(cell_env) : 65536;
-    const bool cell = mode == 3 && (h->cfg.ray_kernel == MCL_RAYS_CELL || (h->cfg.ray_kernel == MCL_RAYS_AUTO && n >= cell_min));
+    const bool auto_cell = h->cfg.ray_kernel == MCL_RAYS_AUTO && n >= cell_min && n * (int64_t)h->B >= (8 << 20);
+    const bool cell = mode == 3 && (h->cfg.ray_kernel == MCL_RAYS_CELL || auto_cell);
+    if (mode == 3 && h->cfg.ray_kernel == MCL_RAYS_AUTO && !cell) mode = 2;
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
     if (mode == 2)

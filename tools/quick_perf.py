@@ -12,8 +12,9 @@ def main():
     kern = sys.argv[3] if len(sys.argv) > 3 else "skip"
     regime = sys.argv[4] if len(sys.argv) > 4 else "tracking"
     rpl = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    astep = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
-    ang = synth.beam_angles()
+    ang = synth.beam_angles()[::astep].copy()
     e = engine.Engine(max_particles=n, seed=42, ray_kernel={"march": engine.RAYS_MARCH, "skip": engine.RAYS_SKIP, "quad": engine.RAYS_QUAD, "cell": engine.RAYS_CELL}.get(kern, engine.RAYS_AUTO), rays_per_lane=rpl)
     e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
     e.set_beam_angles(ang)
