@@ -90,7 +90,10 @@ typedef struct {
                                        r in 1..1000: resample only when the effective sample size
                                        (sum w)^2 / sum w^2 of the previous update is below r/1000 * N, otherwise the
                                        particles keep their identity and their weights multiply */
-    int32_t reserved[4];
+    int32_t graph_mode;             /* small updates are launch-bound (about twenty launches): 0 (default) and 2 = replay
+                                       the part of mcl_update after the resampling kernel as one hipGraph once a first
+                                       update has run with the same sizes (k_rays_skip path only); 1 = never */
+    int32_t reserved[3];
 } mcl_config_t;
 
 /* Fills *cfg with the reference's defaults (config/mcl_config.yaml:6-40, cpp:23-47). */

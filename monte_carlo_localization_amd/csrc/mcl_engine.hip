@@ -73,6 +73,10 @@ struct mcl_engine {
     int carry_idx = 0;                  // d_carry[carry_idx] is current; k_weights writes the other one
     bool carry_valid = false, carry_pending = false;
     bool resampled_last = true;
+    // hipGraph of the update's tail (observation upload ... result read-back) for the k_rays_skip path, one per particle buffer
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    bool graph_warm = false;            // a regular update has run since the sizes / map / beams last changed
+    bool capturing = false;
     double *d_logw_acc = nullptr;       // k_rays_quad/far/fix accumulate here with atomics; k_gather_logw copies to d_logw
     uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
     uint64_t *d_leaders = nullptr;      // last CDF entry of every 16-entry group of the array d_blocktot describes
@@ -346,6 +350,8 @@ int ensure_lt(mcl_engine *h)
     return MCL_OK;
 }
 
+void graph_reset(mcl_engine *h);
+
 int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset, uint64_t *d_total)
 {
     int nb = (int)((n + mcl::kScanTile - 1) / mcl::kScanTile);
@@ -353,6 +359,7 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
     hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total);
     const size_t nlead = (size_t)((n + 15) >> mcl::kLeaderShift) + 1;
     if (nlead > h->leaders_capacity) {
+        graph_reset(h);                    // a captured update graph holds the old pointer
         dfree(h->d_leaders);
         HIPCHK(h, hipMalloc(&h->d_leaders, nlead * 8));
         h->leaders_capacity = nlead;
@@ -382,11 +389,19 @@ int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override)
     return MCL_OK;
 }
 
+void unpack_result(mcl_engine *h);
+
 int fetch_scalars(mcl_engine *h)
 {
     // scalars, counters and the work-list overflow flag in one copy into pinned memory
     HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    unpack_result(h);
+    return MCL_OK;
+}
+
+void unpack_result(mcl_engine *h)
+{
     std::memcpy(h->h_scalars, h->h_result, 8 * sizeof(double));
     std::memcpy(h->h_counters, h->h_result + 8, 4 * sizeof(unsigned long long));
     h->h_fix_count = h->h_result[12];
@@ -398,7 +413,6 @@ int fetch_scalars(mcl_engine *h)
     h->global_sums[2] = h->h_scalars[4];
     h->global_sums[3] = h->h_scalars[5];
     h->global_sums[4] = h->h_scalars[6];
-    return MCL_OK;
 }
 
 int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n, bool force_skip = false)
@@ -452,7 +466,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     dim3 g(grid), b(mcl::kRayThreads);
     int R = h->cfg.rays_per_lane;
     if (R <= 0) R = 1;   // measured on MI355X: the kernel is VALU-issue-bound, extra chains per lane only add idle slots
-    if (mode != 3) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
+    if (mode != 3 && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
     if (mode == 1) {
         if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
         else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
@@ -573,25 +587,43 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         default: hipLaunchKernelGGL((mcl::k_rays_skip<4, false>), g, b, lds, h->stream, a); break;
         }
     }
-    if (mode != 3) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+    if (mode != 3 && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
     h->last_mode = (mode == 3 && cell) ? 4 : mode;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
 
 // obs -> obs_idx upload + per-update transposed log table
-int prepare_observation(mcl_engine *h, const float *obs, int stride)
+void stage_observation(mcl_engine *h, const float *obs, int stride)
 {
     for (int j = 0; j < h->B; ++j) h->h_obs[j] = obs[(size_t)j * stride];   // cpp:316-320 when stride = ANGLE_STEP
+}
+
+// the pinned staging buffer -> obs_idx + per-update transposed log table
+int upload_observation(mcl_engine *h)
+{
     HIPCHK(h, hipMemcpyAsync(h->d_obs, h->h_obs, (size_t)h->B * sizeof(float), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(mcl::k_obs_index, dim3(1), dim3(256), 0, h->stream, h->d_obs, h->B, h->res, h->P, h->d_obs_idx);
-    int rc = ensure_lt(h);
+    int rc = h->capturing ? MCL_OK : ensure_lt(h);          // no allocation while a graph is being captured (sizes are warm)
     if (rc) return rc;
     dim3 g((h->bpad + 255) / 256, h->P + 1);
     hipLaunchKernelGGL(mcl::k_build_lt, g, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->bpad, h->P + 1, h->d_Lt,
                        h->d_Lt + (size_t)(h->P + 1) * h->bpad);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
+}
+
+int prepare_observation(mcl_engine *h, const float *obs, int stride)
+{
+    stage_observation(h, obs, stride);
+    return upload_observation(h);
+}
+
+void graph_reset(mcl_engine *h)
+{
+    for (int k = 0; k < 2; ++k)
+        if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
+    h->graph_warm = false;
 }
 
 int sensor_and_weights(mcl_engine *h, const double *d_global_max)
@@ -736,6 +768,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
 void mcl_destroy(mcl_engine_t *h)
 {
     if (!h) return;
+    graph_reset(h);
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
@@ -756,6 +789,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!data || width == 0 || height == 0 || width > 200000 || height > 200000) return fail(h, MCL_ERR_INVALID_ARG, "bad map dimensions");
+    graph_reset(h);
     if (!(resolution > 0.0f)) return fail(h, MCL_ERR_INVALID_ARG, "invalid map resolution");   // cpp:236-240
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const double res = (double)resolution;                    // cpp:191
@@ -856,6 +890,7 @@ int mcl_get_sensor_table(const mcl_engine_t *h, double *out, size_t n)
 
 int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
 {
+    if (h) graph_reset(h);
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!angles || n_beams <= 0 || n_beams > 65536) return fail(h, MCL_ERR_INVALID_ARG, "bad beam angles");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -894,6 +929,7 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
 
 int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n)
 {
+    if (h) graph_reset(h);
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!xyz || !weights || n <= 0 || n > h->cap) return fail(h, MCL_ERR_INVALID_ARG, "bad particle arrays / count");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -918,6 +954,7 @@ int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights,
 
 static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
 {
+    graph_reset(h);
     h->N = n;
     hipLaunchKernelGGL(mcl::k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_w, n, 1.0 / (double)n_total);
     HIPCHK(h, hipGetLastError());
@@ -1098,7 +1135,53 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->have_idx = true;
     }
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
-    int rc = prepare_observation(h, obs, obs_stride);
+    int rc;
+    // Small updates are launch-bound (about twenty launches for ~0.06 ms of kernels): once a regular update has run with
+    // these sizes on the k_rays_skip path, everything after the resampling kernel is replayed as one hipGraph per
+    // particle buffer (observation upload, table build, rays, weights, CDF, result read-back: all arguments are fixed).
+    const bool graph_ok = h->cfg.graph_mode != 1 && h->graph_warm && h->last_mode == 2 && !keep && !h->cfg.debug_count_probes &&
+                          h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0 &&
+                          (h->cfg.ray_kernel == MCL_RAYS_AUTO || h->cfg.ray_kernel == MCL_RAYS_SKIP);
+    if (graph_ok) {
+        stage_observation(h, obs, obs_stride);
+        const int gi = h->cur;
+        if (!h->graph_exec[gi]) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            h->capturing = true;
+            rc = upload_observation(h);
+            if (!rc) rc = launch_rays(h, h->d_x[gi], h->d_y[gi], h->d_th[gi], n);
+            if (!rc) rc = sensor_and_weights(h, nullptr);
+            if (!rc) rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+            hipError_t ce = hipSuccess;
+            if (!rc) ce = hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream);
+            h->capturing = false;
+            const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
+            if (rc || ce != hipSuccess || ee != hipSuccess || !graph || h->last_mode != 2) {
+                if (graph) (void)hipGraphDestroy(graph);
+                graph_reset(h);
+                return fail(h, rc ? rc : MCL_ERR_HIP, "capturing the update graph failed");
+            }
+            const hipError_t ie = hipGraphInstantiate(&h->graph_exec[gi], graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { h->graph_exec[gi] = nullptr; graph_reset(h); return fail(h, MCL_ERR_HIP, "hipGraphInstantiate failed"); }
+        }
+        HIPCHK(h, hipGraphLaunch(h->graph_exec[gi], h->stream));
+        HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        unpack_result(h);
+        h->carry_pending = false;
+        h->have_logw = true;
+        h->have_steps = h->cfg.keep_ray_steps != 0;
+        if (resample_and_move) h->update_idx++;
+        h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
+        h->timings[1] = 0.0; h->timings[2] = 0.0; h->timings[4] = 0.0;
+        h->timings[3] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_SENSOR]);      // the graph as a whole
+        h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        h->ray_ms = h->timings[3];
+        return MCL_OK;
+    }
+    rc = prepare_observation(h, obs, obs_stride);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
@@ -1127,6 +1210,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         if (rc) return rc;
     }
     if (h->carry_pending) { h->carry_idx ^= 1; h->carry_valid = true; h->carry_pending = false; }   // this update's logw - max
+    h->graph_warm = true;                  // every buffer this configuration needs exists now
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
     if (resample_and_move) h->update_idx++;
@@ -1502,6 +1586,7 @@ int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int6
     HIPCHK(h, hipSetDevice(h->cfg.device));
     size_t need = (size_t)n / mcl::kScanTile + 2;
     if (need > h->blocktot_capacity) {   // spine scratch is sized for cap; grow it for gathered arrays
+        graph_reset(h);
         dfree(h->d_blocktot);
         HIPCHK(h, hipMalloc(&h->d_blocktot, need * 8));
         h->blocktot_capacity = need;

@@ -40,7 +40,7 @@ class Config(C.Structure):
         ("motion_dispersion_y", C.c_double), ("motion_dispersion_theta", C.c_double), ("resample_mode", C.c_int32),
         ("weight_mode", C.c_int32), ("ray_kernel", C.c_int32), ("keep_ray_steps", C.c_int32),
         ("debug_force_exact", C.c_int32), ("debug_count_probes", C.c_int32), ("rays_per_lane", C.c_int32),
-        ("resample_neff_permille", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("resample_neff_permille", C.c_int32), ("graph_mode", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 

@@ -584,3 +584,33 @@ def test_random_maps_every_kernel(orc, engine_mod, maps_mod, seed):
         got = e.ray_steps()
         assert np.array_equal(got, steps), (rk, int((got != steps).sum()))
         assert np.array_equal(e.log_weights(), logw), rk
+
+
+def test_update_graph_replay_is_bit_identical(orc, engine_mod, spielberg):
+    """graph_mode: from the second update on the small-update path replays everything after the resampling kernel as one
+    hipGraph.  Same seed with and without it: identical particles, weights, pose and resample indices over many updates,
+    including sensor_update calls, a new scan every update and a change of the particle set in between."""
+    ang = orc.beam_angles(angle_step=18)                      # 61 beams: the stock configuration
+    base = load("scan_Spielberg_map_origin.npz")["ranges"][::18].copy()
+    rng = np.random.default_rng(8)
+    scans = [np.clip(base + rng.normal(0, 0.05, base.size), 0.0, 30.0).astype(np.float32) for _ in range(12)]
+    n = 3000
+    out = {}
+    for gm in (1, 0):
+        e = make_engine(engine_mod, spielberg, ang, n, seed=3, graph_mode=gm)
+        e.init_particles_pose((0.0, 0.0, 0.0), n)
+        rec = []
+        for k, sc in enumerate(scans):
+            if k == 5:
+                e.sensor_update(sc)
+            elif k == 8:
+                e.init_particles_pose((0.1, 0.0, 0.05), n)   # graphs are rebuilt after the particle set was replaced
+                e.update(ACTION, sc)
+            else:
+                e.update(ACTION, sc)
+            rec.append((e.get_particles(), e.get_weights(), e.expected_pose(), e.resample_indices() if k != 5 else None))
+        assert e.ray_kernel_name() == "k_rays_skip"
+        out[gm] = rec
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert (a[3] is None and b[3] is None) or np.array_equal(a[3], b[3])
