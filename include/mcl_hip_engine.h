@@ -16,8 +16,11 @@
  *   - particle matrices use the memory layout of Eigen::MatrixXd(N,3): column-major, i.e. N x's,
  *     then N y's, then N thetas (hpp:102); weights are std::vector<double> (hpp:103);
  *   - every function returns MCL_OK (0) or a negative mcl_status; nothing throws across the ABI.
- *     On failure the engine state is left as it was (the host patch then skips the tick exactly
- *     like a failed state_lock_.try_lock(), cpp:756);
+ *     MCL_ERR_INVALID_ARG / NOT_READY / UNSUPPORTED are detected before anything is touched: the engine state is left as
+ *     it was (the host patch then skips the tick exactly like a failed state_lock_.try_lock(), cpp:756).
+ *     MCL_ERR_HIP means the HIP runtime failed part-way (out of memory, a lost device): what the call was replacing is
+ *     then undefined -- after mcl_set_map / mcl_set_beam_angles the engine reports "not ready" until the call
+ *     succeeds, after mcl_update / mcl_stage_* the particle set must be set or initialised again;
  *   - calls on one handle must be serialised by the caller (they are: single-threaded executor
  *     cpp:1022 + state_lock_ cpp:756/387/408).  mcl_update() is synchronous: when it returns the
  *     new particle set, weights and pose are final (its wall time feeds delay compensation,
@@ -58,16 +61,23 @@ typedef enum {
 } mcl_weight_mode;
 
 typedef enum {
-    MCL_RAYS_AUTO = 0,            /* MCL_RAYS_CELL from 65536 particles and 2^23 rays when the map and beam set
+    MCL_RAYS_AUTO = 0,            /* MCL_RAYS_SWEEP from 65536 particles and 2^23 rays when the map and beam set
                                      allow it, else MCL_RAYS_SKIP                                      */
     MCL_RAYS_MARCH = 1,           /* literal fixed-step fp64 march on the int8 grid (cpp:611-650)      */
     MCL_RAYS_SKIP = 2,            /* same sample lattice, empty-space skipping on an LDS-resident
                                      distance-to-obstacle window; exactness guard falls back to MARCH  */
     MCL_RAYS_QUAD = 3,            /* SKIP with the work split by ray direction: one-byte-per-cell quadrant
                                      windows, two workgroups per CU                                    */
-    MCL_RAYS_CELL = 4             /* QUAD on particles ordered by grid cell and heading, one particle per
+    MCL_RAYS_CELL = 4,            /* QUAD on particles ordered by grid cell and heading, one particle per
                                      lane: the lanes of a wave trace near-identical rays               */
+    MCL_RAYS_SWEEP = 5            /* CELL with a workgroup walking several wedges of a slice (partial sums kept by
+                                     the owning lane instead of 16 atomics per particle) and the probe / per-ray
+                                     code rebuilt around gfx950's 2-cycle and 4-cycle VALU classes     */
 } mcl_ray_kernel;
+
+/* Upper bound (exclusive) on max_particles and on the particle total of a sharded set: weights are quantised to 2^-36 and
+ * their exact sum is kept in 64 bits, so N * 2^36 must stay below 2^64 with one bit to spare. */
+#define MCL_MAX_TOTAL_PARTICLES ((int64_t)1 << 27)
 
 /* Numeric subset of the node's parameters (cpp:23-78) + engine knobs. */
 typedef struct {
@@ -174,7 +184,7 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
 /* duration (ms) of the dominant kernel (ray cast + likelihood) in the last update, measured
  * with HIP events on the engine's own stream */
 int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
-/* which ray kernel the last update ran: 1 k_rays_march, 2 k_rays_skip, 3 k_rays_quad */
+/* which ray kernel the last update ran: 1 k_rays_march, 2 k_rays_skip, 3 k_rays_quad, 4 k_rays_cell, 5 k_rays_sweep */
 int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel);
 /* Effective sample size (sum w)^2 / sum w^2 of the current weights, and whether the last mcl_update resampled
  * (always 1 with resample_neff_permille == 0). */

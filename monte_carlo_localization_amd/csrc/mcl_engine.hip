@@ -62,6 +62,22 @@ struct mcl_engine {
     uint32_t init_idx = 0;
     float *d_Lt = nullptr;
     size_t lt_capacity = 0;
+    double *d_Ltd = nullptr;            // k_rays_sweep's fp64 table (mcl_rays_sweep.h), built per update when that kernel runs
+    size_t ltd_capacity = 0;
+    int ltd_cols = 0;
+    double *d_partial = nullptr;        // k_rays_sweep: [kWedges / sweep_g][cap] partial log-weights in sorted-slot order
+    size_t partial_capacity = 0;
+    bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
+    int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), rebuilt when (n, workgroups, G) change
+    size_t items_capacity = 0;
+    int nitems = 0, plan_g = 0, plan_nwg = 0;
+    int64_t plan_n = 0;
+    double4 *d_unit_sums = nullptr;     // per unit of 1024 sorted particles: (sum px, sum py, count, -)
+    size_t unit_sums_capacity = 0;
+    // environment knobs, read once at mcl_create (0 / negative = default)
+    int64_t env_cell_min = 0, env_cell_slice = 0;
+    int env_qslices_per_cu = 0, env_qside = 0, env_sweep_g = 0;
+    std::string env_debug_wg;
 
     // particles
     int64_t cap = 0, N = 0;
@@ -112,7 +128,7 @@ struct mcl_engine {
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
     size_t slice_mean_capacity = 0;
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
-    int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell
+    int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell, 5 sweep
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
     unsigned long long *d_result = nullptr;   // [0..7] scalars, [8..11] counters, [12..13] overflow flag + work counter: one D2H copy
     unsigned long long *h_result = nullptr;   // pinned mirror of d_result
@@ -123,6 +139,7 @@ struct mcl_engine {
     uint32_t update_idx = 0;
     double timings[6]{};
     double ray_ms = 0;
+    bool ray_ms_is_graph_tail = false;  // ray_ms is the whole captured tail of a small update, not one kernel
     unsigned long long h_counters[4]{};
     unsigned long long h_fix_count = 0;
 };
@@ -347,6 +364,13 @@ int ensure_lt(mcl_engine *h)
         HIPCHK(h, hipMalloc(&h->d_Lt, 2 * need * sizeof(float)));      // [Lt | Lt with the rows reversed (k_rays_cell)]
         h->lt_capacity = need;
     }
+    h->ltd_cols = (h->B + 64) & ~63;                                    // at least one all-zero column after the last beam
+    const size_t need_d = (size_t)mcl::sweep_table_rows(h->P) * h->ltd_cols;
+    if (need_d > h->ltd_capacity) {
+        dfree(h->d_Ltd);
+        HIPCHK(h, hipMalloc(&h->d_Ltd, need_d * sizeof(double)));
+        h->ltd_capacity = need_d;
+    }
     return MCL_OK;
 }
 
@@ -376,9 +400,11 @@ int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override)
     const int64_t n = h->N;
     const double *src = from_log ? h->d_logw : h->d_w;
     if (!d_max_override) {
-        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, n, h->d_part);
+        if (!(from_log && h->max_partials_ready))        // k_combine_logw already left the per-workgroup maxima in d_part
+            hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, n, h->d_part);
         hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     }
+    h->max_partials_ready = false;                       // k_weights overwrites d_part
     hipLaunchKernelGGL(mcl::k_weights, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, from_log ? 1 : 0,
                        h->d_scalars, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, h->d_w, h->d_q, h->d_part,
                        (from_log && h->cfg.resample_neff_permille > 0) ? h->d_carry[h->carry_idx ^ 1] : (double *)nullptr);
@@ -415,6 +441,53 @@ void unpack_result(mcl_engine *h)
     h->global_sums[4] = h->h_scalars[6];
 }
 
+// Work items of k_rays_sweep: (first unit, units, wedge group).  Guided schedule: runs of up to four units (4096 particles
+// share one window per wedge) while plenty of work is left, single units for the last third, every run once per wedge
+// group; the persistent workgroups take them in this order, so they finish within one single-unit item of each other.
+int build_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
+{
+    if (h->d_items && h->plan_n == n && h->plan_nwg == nwg && h->plan_g == g) return MCL_OK;
+    const int ngroups = mcl::kWedges / g;
+    const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
+    std::vector<int4> items;
+    for (int64_t u = 0; u < M;) {
+        int64_t c = ((M - u) * ngroups) / (3 * (int64_t)std::max(nwg, 1));
+        c = std::max<int64_t>(1, std::min<int64_t>(4, std::min<int64_t>(c, M - u)));
+        for (int k = 0; k < ngroups; ++k) items.push_back(make_int4((int)u, (int)c, (int)((k + u) % ngroups), 0));
+        u += c;
+    }
+    if (items.size() > h->items_capacity) {
+        dfree(h->d_items);
+        HIPCHK(h, hipMalloc(&h->d_items, items.size() * sizeof(int4)));
+        h->items_capacity = items.size();
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // `items` goes out of scope
+    h->nitems = (int)items.size(); h->plan_n = n; h->plan_nwg = nwg; h->plan_g = g;
+    return MCL_OK;
+}
+
+// Which ray kernel a launch over n particles takes: 1 march, 2 skip, 3 quad, 4 cell, 5 sweep; 0 = the configured kernel
+// cannot run with this map / beam set.  A pure function of the configuration, the map, the beam set and n, so that
+// callers (graph eligibility, table building) can ask before anything is launched.
+int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip)
+{
+    const int rk = h->cfg.ray_kernel;
+    if (rk == MCL_RAYS_MARCH) return 1;
+    if (rk == MCL_RAYS_SKIP || force_skip) return 2;
+    const bool windows_ok = h->quad_ok && h->qside > 0;      // monotone beams over less than a turn, room for a byte window
+    if (rk == MCL_RAYS_QUAD) return windows_ok ? 3 : 0;
+    if (rk == MCL_RAYS_CELL) return windows_ok ? 4 : 0;
+    if (rk == MCL_RAYS_SWEEP) return windows_ok ? 5 : 0;
+    // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
+    // with 64-particle groups and enough rays to amortise the sort (measured, wall ms skip / quad / cell:
+    // 4096 x 1081 0.16/0.28/0.40, 65536 x 1081 0.55/0.56/0.44, 65536 x 61 0.21/0.33/0.25, 262144 x 61 0.47/0.76/0.40);
+    // below that the self-contained k_rays_skip (one launch, no work lists) is the quickest
+    const int64_t cell_min = h->env_cell_min > 0 ? h->env_cell_min : 65536;
+    if (windows_ok && n >= cell_min && n * (int64_t)h->B >= (8 << 20)) return 5;
+    return 2;
+}
+
 int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n, bool force_skip = false)
 {
     mcl::RayArgs a{};
@@ -437,25 +510,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.tw_cells = h->tw_cells;
     a.counters = h->d_counters;
     a.force_exact = h->cfg.debug_force_exact;
-    // kernel choice: QUAD needs monotone beams over less than a turn and a map whose MAX_RANGE_PX leaves room
-    // for a useful cloud extent in an 80 KB byte window (two workgroups per CU)
-    int mode = 2;
     h->last_quad = false;
-    if (h->cfg.ray_kernel == MCL_RAYS_MARCH) mode = 1;
-    else if (h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_CELL || h->cfg.ray_kernel == MCL_RAYS_AUTO)
-        mode = (h->quad_ok && h->qside > 0) ? 3 : 2;
-    if (force_skip && mode == 3) mode = 2;
-    if ((h->cfg.ray_kernel == MCL_RAYS_QUAD || h->cfg.ray_kernel == MCL_RAYS_CELL) && mode != 3 && !force_skip)
-        return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD / MCL_RAYS_CELL not usable with this map / beam set");
-    // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
-    // with 64-particle groups and enough rays to amortise the sort (measured, wall ms skip / quad / cell:
-    // 4096 x 1081 0.16/0.28/0.40, 65536 x 1081 0.55/0.56/0.44, 65536 x 61 0.21/0.33/0.25, 262144 x 61 0.47/0.76/0.40);
-    // below that the self-contained k_rays_skip (one launch, no work lists) is the quickest
-    const char *cell_env = getenv("MCL_CELL_MIN");
-    const int64_t cell_min = cell_env ? atoll(cell_env) : 65536;
-    const bool auto_cell = h->cfg.ray_kernel == MCL_RAYS_AUTO && n >= cell_min && n * (int64_t)h->B >= (8 << 20);
-    const bool cell = mode == 3 && (h->cfg.ray_kernel == MCL_RAYS_CELL || auto_cell);
-    if (mode == 3 && h->cfg.ray_kernel == MCL_RAYS_AUTO && !cell) mode = 2;
+    h->max_partials_ready = false;
+    const int mode = choose_ray_mode(h, n, force_skip);
+    if (mode == 0) return fail(h, MCL_ERR_UNSUPPORTED, "MCL_RAYS_QUAD / MCL_RAYS_CELL / MCL_RAYS_SWEEP not usable with this map / beam set");
+    const bool windows = mode >= 3;                 // quadrant / wedge windows + work lists
+    const bool cell = mode >= 4;                    // cell-sorted particles, one particle per lane
+    const bool sweep = mode == 5;
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
     if (mode == 2)
@@ -466,27 +527,38 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     dim3 g(grid), b(mcl::kRayThreads);
     int R = h->cfg.rays_per_lane;
     if (R <= 0) R = 1;   // measured on MI355X: the kernel is VALU-issue-bound, extra chains per lane only add idle slots
-    if (mode != 3 && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
+    if (!windows && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
     if (mode == 1) {
         if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
         else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
-    } else if (mode == 3) {
+    } else if (windows) {
         // work list for undecided rays (~0.06 % of the rays in practice): one segment per persistent workgroup of
         // k_rays_quad with room for 1/256 of that workgroup's share of the rays (at least 2048 entries)
-        const char *ns_env = getenv("MCL_QSLICES_PER_CU");
         // item granularity: 32 slices per CU (measured best at 4M: 4/8/16/32/64 -> 22.1/20.2/19.7/19.6/20.2 ms), but at
         // least 256 particles per slice so that the 78 KB window load stays amortised
-        const int spc = ns_env ? atoi(ns_env) : 32;
+        const int spc = h->env_qslices_per_cu > 0 ? h->env_qslices_per_cu : 32;
         int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
+        int sweep_g = 1;
         if (cell) {
             // k_rays_cell: a slice is a run of the sorted order; 2048 particles = two 64-particle groups per wave.  Longer
             // slices amortise the window load better, shorter ones balance the persistent workgroups better
             // (measured at 4M: 1024/2048/4096/8192/16384 -> 8.59/8.04/7.86/7.96/8.64 ms; at 256k: 2048/4096 -> 0.68/0.79 ms)
-            const char *cs_env = getenv("MCL_CELL_SLICE");
-            const int64_t slice_len = cs_env ? std::max<int64_t>(64, atoll(cs_env)) : (n >= (1 << 21) ? 4096 : 2048);
+            int64_t slice_len = h->env_cell_slice > 0 ? std::max<int64_t>(64, h->env_cell_slice) : (n >= (1 << 21) ? 4096 : 2048);
             nsl = (int)std::max<int64_t>(1, (n + slice_len - 1) / slice_len);
         }
-        const int nseg = (int)std::min<int64_t>(2 * (int64_t)(h->num_cu - h->reserved_cus), (cell ? mcl::kWedges : 4) * (int64_t)nsl);   // one segment per persistent workgroup
+        const int max_wg = 2 * (h->num_cu - h->reserved_cus);             // persistent: 2 workgroups per CU
+        if (sweep) {
+            // k_rays_sweep: a work item is (run of 1024-particle units, G wedges); the G wedges of a group share one
+            // partial-sum array.  G = 4 unless that leaves fewer than four items per workgroup.
+            const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
+            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : 4;
+            if (sweep_g > mcl::kWedges || (mcl::kWedges % sweep_g) != 0) sweep_g = 4;
+            if (h->env_sweep_g <= 0)
+                while (sweep_g > 1 && M * (mcl::kWedges / sweep_g) < 4 * (int64_t)max_wg) sweep_g >>= 1;
+            nsl = (int)M;
+        }
+        const int items_per_slice = sweep ? mcl::kWedges / sweep_g : (cell ? mcl::kWedges : 4);
+        const int nseg = (int)std::min<int64_t>(max_wg, items_per_slice * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
         unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 256 + 7) & ~7ull);
         if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
@@ -533,42 +605,72 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart);
             hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_skey, h->d_srank,
                                h->d_hist, h->d_pcs, h->d_ths, h->d_perm);
-            if ((size_t)nsl > h->slice_mean_capacity) {
-                dfree(h->d_slice_mean);
-                HIPCHK(h, hipMalloc(&h->d_slice_mean, (size_t)nsl * sizeof(double2)));
-                h->slice_mean_capacity = nsl;
+            if (sweep) {
+                if ((size_t)nsl > h->unit_sums_capacity) {
+                    dfree(h->d_unit_sums);
+                    HIPCHK(h, hipMalloc(&h->d_unit_sums, (size_t)nsl * sizeof(double4)));
+                    h->unit_sums_capacity = nsl;
+                }
+                hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)nsl), dim3(256), 0, h->stream, h->d_pcs, n, h->d_unit_sums);
+            } else {
+                if ((size_t)nsl > h->slice_mean_capacity) {
+                    dfree(h->d_slice_mean);
+                    HIPCHK(h, hipMalloc(&h->d_slice_mean, (size_t)nsl * sizeof(double2)));
+                    h->slice_mean_capacity = nsl;
+                }
+                hipLaunchKernelGGL(mcl::k_slice_means, dim3((unsigned)nsl), dim3(256), 0, h->stream, h->d_pcs, n, (n + nsl - 1) / nsl, h->d_slice_mean);
             }
-            hipLaunchKernelGGL(mcl::k_slice_means, dim3((unsigned)nsl), dim3(256), 0, h->stream, h->d_pcs, n, (n + nsl - 1) / nsl, h->d_slice_mean);
             a.pcs = h->d_pcs; a.ths = h->d_ths; a.perm = h->d_perm; a.slice_mean = h->d_slice_mean;
             a.distw = h->d_distw; a.distw_stride = (size_t)h->Hp * h->Wps;
+        }
+        if (sweep) {
+            const size_t need = (size_t)(mcl::kWedges / sweep_g) * (size_t)n;
+            if (need > h->partial_capacity) {
+                dfree(h->d_partial);
+                HIPCHK(h, hipMalloc(&h->d_partial, need * sizeof(double)));
+                h->partial_capacity = need;
+            }
+            if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not built (internal)");
+            const int rc_plan = build_sweep_plan(h, n, nseg, sweep_g);
+            if (rc_plan) return rc_plan;
+            a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
+            a.items = h->d_items; a.nitems = h->nitems; a.unit_sums = h->d_unit_sums; a.slot_space = 1;
         }
         size_t qlds = (size_t)h->qside * h->qside;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
-        const char *dbgpath = getenv("MCL_DEBUG_WG");
-        if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
+        const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();
+        if (dbgpath && !sweep) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
         // k_rays_far is bound by global-memory latency: 4 workgroups per CU worth of blocks (2 resident at a time)
         dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU
         HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
+            if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, a);
+            else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
-            hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         } else {
-            if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
+            if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, a);
+            else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<false>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
-            hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         }
-        hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
+        hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
+        if (sweep) {
+            // partial sums (sorted order) + what the far / fix / exact kernels added -> d_logw, and the per-workgroup maxima
+            hipLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, h->d_partial, mcl::kWedges / sweep_g, n,
+                               h->d_perm, h->d_logw_acc, h->d_logw, h->d_part);
+            h->max_partials_ready = true;
+        } else {
+            hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
+        }
         if (d_dbg) {
             std::vector<unsigned long long> hd((size_t)qg.x * 4);
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -587,8 +689,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         default: hipLaunchKernelGGL((mcl::k_rays_skip<4, false>), g, b, lds, h->stream, a); break;
         }
     }
-    if (mode != 3 && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
-    h->last_mode = (mode == 3 && cell) ? 4 : mode;
+    if (!windows && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+    h->last_mode = mode;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -609,6 +711,10 @@ int upload_observation(mcl_engine *h)
     dim3 g((h->bpad + 255) / 256, h->P + 1);
     hipLaunchKernelGGL(mcl::k_build_lt, g, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->bpad, h->P + 1, h->d_Lt,
                        h->d_Lt + (size_t)(h->P + 1) * h->bpad);
+    if (choose_ray_mode(h, h->N, false) == 5) {
+        dim3 gd((h->ltd_cols + 255) / 256, mcl::sweep_table_rows(h->P));
+        hipLaunchKernelGGL(mcl::k_build_ltd, gd, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->ltd_cols, h->P, h->d_Ltd);
+    }
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -682,8 +788,9 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     g_create_error.clear();
     if (!cfg || !out) { g_create_error = "null argument"; return MCL_ERR_INVALID_ARG; }
     *out = nullptr;
-    if (cfg->max_particles <= 0 || cfg->max_particles > ((int64_t)1 << 30) || cfg->squash_factor <= 0 || cfg->max_range_m <= 0) {
-        g_create_error = "bad config (max_particles / squash_factor / max_range_m)";
+    // weights are quantised to 2^-36 and summed in uint64 (E5/E6): N * 2^36 must stay below 2^64 with a bit to spare
+    if (cfg->max_particles <= 0 || cfg->max_particles >= MCL_MAX_TOTAL_PARTICLES || cfg->squash_factor <= 0 || cfg->max_range_m <= 0) {
+        g_create_error = "bad config (max_particles must be in [1, 2^27) / squash_factor / max_range_m)";
         return MCL_ERR_INVALID_ARG;
     }
     int ndev = 0;
@@ -702,6 +809,13 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     }
     mcl_engine *h = new mcl_engine();
     h->cfg = *cfg;
+    // tuning knobs of the environment, read once here (never on the update path)
+    if (const char *e = getenv("MCL_CELL_MIN")) h->env_cell_min = atoll(e);
+    if (const char *e = getenv("MCL_CELL_SLICE")) h->env_cell_slice = atoll(e);
+    if (const char *e = getenv("MCL_QSLICES_PER_CU")) h->env_qslices_per_cu = atoi(e);
+    if (const char *e = getenv("MCL_QSIDE")) h->env_qside = atoi(e);
+    if (const char *e = getenv("MCL_SWEEP_G")) h->env_sweep_g = atoi(e);
+    if (const char *e = getenv("MCL_DEBUG_WG")) h->env_debug_wg = e;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
     auto bail = [&](const char *what) {
@@ -760,6 +874,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #undef CRT
     *out = h;
     return MCL_OK;
@@ -768,15 +884,15 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
 void mcl_destroy(mcl_engine_t *h)
 {
     if (!h) return;
-    graph_reset(h);
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    graph_reset(h);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -802,7 +918,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     h->tw_cells = 568;
     // k_rays_quad: byte window of side S in half the LDS (S*S <= 80 KiB, S % 8 == 0); usable when the extent
     // budget S - (P+2) - 3 is at least 48 cells, otherwise k_rays_skip's full-LDS nibble window is used
-    { const char *qs = getenv("MCL_QSIDE"); int S = qs ? atoi(qs) : 280; h->qside = (S - (P + 2) - 3 >= 32) ? S : 0; }
+    { const int S = h->env_qside > 0 ? h->env_qside : 280; h->qside = (S - (P + 2) - 3 >= 32) ? S : 0; }
     build_sensor_table(h->cfg, P, h->table);
     const int tw = P + 1;
     std::vector<float> L((size_t)tw * tw);
@@ -811,6 +927,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
         for (int d = 0; d < tw; ++d) L[(size_t)r * tw + d] = (float)(std::log(h->table[(size_t)d * tw + r]) * inv_squash);
     std::vector<uint8_t> dist;
     build_distance_field(data, h->W, h->H, h->Wp, h->Hp, h->Wps, dist);
+    h->have_map = false;                 // until every buffer below exists again: a failure leaves "map not set", never dangling pointers
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     HIPCHK(h, hipMalloc(&h->d_grid, (size_t)h->W * h->H));
@@ -855,7 +972,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     }
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
-    h->lt_capacity = 0; dfree(h->d_Lt);
+    h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd);
     {   // free-space list for initialize_global (cpp:199-213, 411-421): row-major order of data == 0
         std::vector<uint32_t> fr;
         for (size_t i = 0; i < (size_t)h->W * h->H; ++i)
@@ -894,7 +1011,8 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!angles || n_beams <= 0 || n_beams > 65536) return fail(h, MCL_ERR_INVALID_ARG, "bad beam angles");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->B = n_beams; h->bpad = (n_beams + 63) & ~63;
+    h->B = 0;                            // until every buffer below exists again (ready() tests B > 0)
+    h->bpad = (n_beams + 63) & ~63;
     h->quad_ok = n_beams < 16384;
     for (int j = 1; j < n_beams && h->quad_ok; ++j)
         if (!(angles[j] > angles[j - 1])) h->quad_ok = false;
@@ -915,7 +1033,7 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     HIPCHK(h, hipMalloc(&h->d_obs_idx, (size_t)n_beams * sizeof(int32_t)));
     HIPCHK(h, hipMemcpy(h->d_angle, angles, (size_t)n_beams * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)ncs * sizeof(double2), hipMemcpyHostToDevice));
-    h->lt_capacity = 0; dfree(h->d_Lt);
+    h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd);
     if (h->cfg.keep_ray_steps) {
         size_t need = (size_t)h->cap * n_beams;
         if (need > h->steps_capacity) {
@@ -924,6 +1042,7 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
             h->steps_capacity = need;
         }
     }
+    h->B = n_beams;
     return MCL_OK;
 }
 
@@ -974,7 +1093,8 @@ static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
 int mcl_init_particles_pose(mcl_engine_t *h, const double pose[3], int64_t n, int64_t first_global_index, int64_t n_total)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
-    if (!pose || n <= 0 || n > h->cap || first_global_index < 0 || n_total < n) return fail(h, MCL_ERR_INVALID_ARG, "bad init arguments");
+    if (!pose || n <= 0 || n > h->cap || first_global_index < 0 || n_total < n || n_total >= MCL_MAX_TOTAL_PARTICLES)
+        return fail(h, MCL_ERR_INVALID_ARG, "bad init arguments (the sharded total must stay below 2^27)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int c = h->cur;
     hipLaunchKernelGGL(mcl::k_init_pose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, pose[0], pose[1], pose[2], n,
@@ -988,7 +1108,8 @@ int mcl_init_global(mcl_engine_t *h, int64_t n, int64_t first_global_index, int6
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!h->have_map) return fail(h, MCL_ERR_NOT_READY, "map not set");                 // cpp:403
     if (h->n_free == 0) return fail(h, MCL_ERR_NOT_READY, "No free space found in map!");   // cpp:423-427
-    if (n <= 0 || n > h->cap || first_global_index < 0 || n_total < n) return fail(h, MCL_ERR_INVALID_ARG, "bad init arguments");
+    if (n <= 0 || n > h->cap || first_global_index < 0 || n_total < n || n_total >= MCL_MAX_TOTAL_PARTICLES)
+        return fail(h, MCL_ERR_INVALID_ARG, "bad init arguments (the sharded total must stay below 2^27)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int c = h->cur;
     hipLaunchKernelGGL(mcl::k_init_global, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_free, h->n_free, h->W, h->res,
@@ -1139,33 +1260,44 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     // Small updates are launch-bound (about twenty launches for ~0.06 ms of kernels): once a regular update has run with
     // these sizes on the k_rays_skip path, everything after the resampling kernel is replayed as one hipGraph per
     // particle buffer (observation upload, table build, rays, weights, CDF, result read-back: all arguments are fixed).
-    const bool graph_ok = h->cfg.graph_mode != 1 && h->graph_warm && h->last_mode == 2 && !keep && !h->cfg.debug_count_probes &&
-                          h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0 &&
-                          (h->cfg.ray_kernel == MCL_RAYS_AUTO || h->cfg.ray_kernel == MCL_RAYS_SKIP);
+    // Eligibility is a pure function of the configuration and the sizes (choose_ray_mode), never of what the previous
+    // update happened to run: k_rays_skip chosen outright has no work lists, no allocation and no fallback.
+    bool graph_ok = h->cfg.graph_mode != 1 && h->graph_warm && choose_ray_mode(h, n, false) == 2 && !keep && !h->cfg.debug_count_probes &&
+                    h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0;
     if (graph_ok) {
         stage_observation(h, obs, obs_stride);
         const int gi = h->cur;
         if (!h->graph_exec[gi]) {
+            // nothing executes during capture, so a failure here simply falls back to the launch-by-launch path below
             hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            h->capturing = true;
-            rc = upload_observation(h);
-            if (!rc) rc = launch_rays(h, h->d_x[gi], h->d_y[gi], h->d_th[gi], n);
-            if (!rc) rc = sensor_and_weights(h, nullptr);
-            if (!rc) rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
-            hipError_t ce = hipSuccess;
-            if (!rc) ce = hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream);
-            h->capturing = false;
-            const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
-            if (rc || ce != hipSuccess || ee != hipSuccess || !graph || h->last_mode != 2) {
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+                graph_ok = false;
+            } else {
+                h->capturing = true;
+                rc = upload_observation(h);
+                if (!rc) rc = launch_rays(h, h->d_x[gi], h->d_y[gi], h->d_th[gi], n);
+                if (!rc) rc = sensor_and_weights(h, nullptr);
+                if (!rc) rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+                hipError_t ce = hipSuccess;
+                if (!rc) ce = hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream);
+                h->capturing = false;
+                const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
+                hipError_t ie = hipErrorUnknown;
+                if (!rc && ce == hipSuccess && ee == hipSuccess && graph && h->last_mode == 2)
+                    ie = hipGraphInstantiate(&h->graph_exec[gi], graph, nullptr, nullptr, 0);
                 if (graph) (void)hipGraphDestroy(graph);
-                graph_reset(h);
-                return fail(h, rc ? rc : MCL_ERR_HIP, "capturing the update graph failed");
+                if (ie != hipSuccess) {
+                    h->graph_exec[gi] = nullptr;
+                    graph_reset(h);
+                    (void)hipGetLastError();
+                    h->cfg.graph_mode = 1;          // do not try again on this engine
+                    graph_ok = false;
+                }
             }
-            const hipError_t ie = hipGraphInstantiate(&h->graph_exec[gi], graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { h->graph_exec[gi] = nullptr; graph_reset(h); return fail(h, MCL_ERR_HIP, "hipGraphInstantiate failed"); }
         }
+    }
+    if (graph_ok) {
+        const int gi = h->cur;
         HIPCHK(h, hipGraphLaunch(h->graph_exec[gi], h->stream));
         HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1174,19 +1306,26 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->have_logw = true;
         h->have_steps = h->cfg.keep_ray_steps != 0;
         if (resample_and_move) h->update_idx++;
+        // the captured tail is one unit: its time is reported as the ray-cast stage (query prep and table evaluation
+        // are inside it), so that the six stages still add up to the total the host uses for delay compensation
         h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
         h->timings[1] = 0.0; h->timings[2] = 0.0; h->timings[4] = 0.0;
         h->timings[3] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_SENSOR]);      // the graph as a whole
         h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         h->ray_ms = h->timings[3];
+        h->ray_ms_is_graph_tail = true;
         return MCL_OK;
     }
+    h->ray_ms_is_graph_tail = false;
     rc = prepare_observation(h, obs, obs_stride);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
     if (rc) return rc;
-    if (keep) hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
+    if (keep) {
+        hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
+        h->max_partials_ready = false;
+    }
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     rc = sensor_and_weights(h, nullptr);
     if (rc) return rc;
@@ -1201,7 +1340,10 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
         rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, true);
         if (rc) return rc;
-        if (keep) hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
+        if (keep) {
+            hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
+            h->max_partials_ready = false;
+        }
         rc = sensor_and_weights(h, nullptr);
         if (rc) return rc;
         rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
@@ -1452,8 +1594,9 @@ static int stage_resample_impl(mcl_engine_t *h, const double *d_px, const double
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
-    if ((!d_records && (!d_px || !d_py || !d_pth)) || !d_cdf || !action || n_parents <= 0)
-        return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments");
+    if ((!d_records && (!d_px || !d_py || !d_pth)) || !d_cdf || !action || n_parents <= 0 || n_parents >= MCL_MAX_TOTAL_PARTICLES ||
+        n_children_total >= MCL_MAX_TOTAL_PARTICLES)
+        return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments (totals must stay below 2^27)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t n = h->N;
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
@@ -1522,8 +1665,10 @@ int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
         rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, attempt == 1);
         if (rc) return rc;
         HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
-        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
+        if (!h->max_partials_ready)
+            hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
         hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+        h->max_partials_ready = false;
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1565,10 +1710,16 @@ int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!h->have_logw) return MCL_ERR_NOT_READY;
+    if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
+        return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_scalars, &global_max_logw, sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int rc = weight_stats(h, true, h->d_scalars);
+    if (rc) return rc;
+    h->carry_pending = false;
+    // the shard's own CDF follows its new weights: mcl_sample_particles (visualize) and a later plain mcl_update search it
+    rc = scan_weights(h, h->d_q, h->d_cdf, h->N, 0, nullptr);
     if (rc) return rc;
     return fetch_scalars(h);
 }

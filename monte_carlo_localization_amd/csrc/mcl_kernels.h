@@ -378,6 +378,15 @@ struct RayArgs {
     double beam_a0, beam_inv_inc;  // first angle and beams per radian (k_rays_cell's guess of a wedge's first beam)
     const float *Lt;               // (P+1) x bpad
     const float *Ltr;              // the same with the rows reversed (row P - d)
+    const double *Ltd;             // k_rays_sweep: fp64 table indexed by samples left + kSwUnder (mcl_rays_sweep.h), ltd_cols columns
+    int ltd_cols;
+    double *part;                  // k_rays_sweep: [kWedges / sweep_g][n] partial log-weights in sorted-slot order
+    int sweep_g;                   // k_rays_sweep: wedges per work item
+    const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, -), big first (guided schedule)
+    int nitems;
+    const double4 *unit_sums;      // k_rays_sweep: per unit of kSwUnit sorted particles (sum px, sum py, count, -), k_slice_means
+    int slot_space;                // 1: fix-list entries, far flags and `logw` are indexed by sorted slot (k_rays_sweep), and the
+                                   // per-particle constants of k_rays_fix / k_rays_far come from pcs / ths; perm gives the particle
     double *logw;                  // out
     uint8_t *steps;                // out N*B or null
     // map
@@ -1629,9 +1638,9 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
     const unsigned long long *list = a.fix_list + (size_t)seg * a.fix_cap;
     for (unsigned long long k = (unsigned long long)part * blockDim.x + threadIdx.x; k < n; k += (unsigned long long)blockDim.x * split) {
         const unsigned long long e = atomicAdd(const_cast<unsigned long long *>(&list[k]), 0ull);
-        const int64_t i = (int64_t)(e >> 16);
+        const int64_t p = (int64_t)(e >> 16);                     // particle index, or sorted slot (slot_space)
         const int j = (int)(e & 0xFFFF);
-        const double4 pci = a.pc[i];
+        const double4 pci = a.slot_space ? a.pcs[p] : a.pc[p];
         const double2 cs = a.beam_cs[j];
         const double ux = pci.x * cs.x - pci.y * cs.y, uy = pci.y * cs.x + pci.x * cs.y;
         const bool sane = (pci.z > -200000.0) && (pci.z < 200000.0) && (pci.w > -200000.0) && (pci.w < 200000.0);
@@ -1654,11 +1663,12 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
                 const unsigned long long slot = atomicAdd(a.exact_count, 1ull);
                 if (slot < a.exact_cap) { atomicExch(&a.exact_list[slot], e); continue; }
             }
+            const int64_t i = a.slot_space ? (int64_t)a.perm[p] : p;
             r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
             ++cnt_exact;
         }
-        atomicAdd(&a.logw[i], (double)a.Lt[(size_t)r * a.bpad + j]);
-        if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+        atomicAdd(&a.logw[p], (double)a.Lt[(size_t)r * a.bpad + j]);
+        if (a.steps) a.steps[(size_t)(a.slot_space ? (int64_t)a.perm[p] : p) * a.B + j] = (uint8_t)r;
         if (COUNT) cnt_probe += np;
     }
     }
@@ -1687,7 +1697,8 @@ __global__ __launch_bounds__(256) void k_rays_exact(RayArgs a)
         unsigned long long e = 0;
         if (lane == 0) e = atomicAdd(&a.exact_list[k], 0ull);
         e = (unsigned long long)__shfl((long long)e, 0, 64);
-        const int64_t i = (int64_t)(e >> 16);
+        const int64_t p = (int64_t)(e >> 16);
+        const int64_t i = a.slot_space ? (int64_t)a.perm[p] : p;
         const int j = (int)(e & 0xFFFF);
         const double angle = a.th[i] + (double)a.beam_angle[j];
         const double dx = cos(angle) * a.res, dy = sin(angle) * a.res;
@@ -1706,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_rays_exact(RayArgs a)
             for (int t = 0; t < 64; ++t) { cx += dx; cy += dy; }        // 64 samples further
         }
         if (lane == 0) {
-            atomicAdd(&a.logw[i], (double)a.Lt[(size_t)r * a.bpad + j]);
+            atomicAdd(&a.logw[p], (double)a.Lt[(size_t)r * a.bpad + j]);
             if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
             ++done;
         }
@@ -1714,12 +1725,15 @@ __global__ __launch_bounds__(256) void k_rays_exact(RayArgs a)
     if (a.counters && lane == 0 && done) atomicAdd(&a.counters[0], done);
 }
 
-// log-weights accumulated with memory-side fp64 atomics must be read back the same way: a plain load may be
-// served from an L2 line cached before the atomics ran.  acc -> plain array for the rest of the pipeline.
-__global__ void k_gather_logw(double *__restrict__ acc, int64_t n, double *__restrict__ out)
+// acc (fp64 atomics of the ray kernels of this launch sequence) -> plain array for the rest of the pipeline.  Plain loads
+// in a LATER kernel see the result of memory-side atomics (tools/ubench/coherence.hip, profiles/r02_coherence.txt: 0 stale
+// entries in 8 x 84M reads, whether the zeroing was a plain or a write-through store); round 1 read these back with atomics
+// because of wrong sums that went away with the stream fix of the same day (memsets on the null stream racing the engine's
+// stream), not because of the cache hierarchy.
+__global__ void k_gather_logw(const double *__restrict__ acc, int64_t n, double *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = atomicAdd(&acc[i], 0.0);
+    if (i < n) out[i] = acc[i];
 }
 
 // overflow flag of the fix-up list: *over = number of segments whose append count exceeded the capacity
@@ -1754,10 +1768,11 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
       while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int64_t i = i0 + src;
+        const int64_t p = i0 + src;                                 // particle index, or sorted slot (slot_space)
+        const int64_t i = a.slot_space ? (int64_t)a.perm[p] : p;
         const uint32_t fl = (uint32_t)__shfl((int)myfl, src, 64);
         if (lane == 0) ++cnt_off;
-        const double4 pci = a.pc[i];
+        const double4 pci = a.slot_space ? a.pcs[p] : a.pc[p];
         const double cth = pci.x, sth = pci.y, gpx = pci.z, gpy = pci.w;
         const bool sane = (gpx > -200000.0) && (gpx < 200000.0) && (gpy > -200000.0) && (gpy < 200000.0);
         const double p0x = (gpx + 1.0 + 262144.0) + kMagic, p0y = (gpy + 1.0 + 262144.0) + kMagic;
@@ -1807,7 +1822,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
             }
         }
         acc = wave_sum(acc);
-        if (lane == 0) atomicAdd(&a.logw[i], acc);
+        if (lane == 0) atomicAdd(&a.logw[p], acc);
       }
     }
     if (a.counters) {
@@ -2011,3 +2026,5 @@ __global__ void k_sample(const double *__restrict__ x, const double *__restrict_
 }
 
 }  // namespace mcl
+
+#include "mcl_rays_sweep.h"

@@ -1,0 +1,428 @@
+// mcl_rays_sweep.h — K3e: k_rays_sweep, the default ray-cast + likelihood kernel from 65 536 particles (MCL_RAYS_SWEEP).
+//
+// Same algorithm and the same bits as k_rays_cell (cell-sorted particles, one particle per lane, 16 wedge fields, 22-bit
+// fixed point with a boundary guard, fix-up list, far flags; reference rows Q, C, E = cpp:524-650).  What changed, and why:
+//
+//   * gfx950 issues v_add/v_and/v_lshrrev/v_mov and the fp32 add/mul/fma every 2 cycles per wave64 but v_mad_*24,
+//     every three-operand integer op, v_min/v_max, shifts left, conversions, compares and all fp64 every 4
+//     (profiles/r02_op_rates.txt).  The probe trip and the per-ray code are rebuilt around that table:
+//       - the guard bias is folded into the window-relative origin, so the fraction test is two v_and (2 cycles each)
+//         and one v_min3 instead of two v_lshl_add and one v_min3;
+//       - the table is read as fp64 (no v_cvt_f64_f32), has 127 extra rows below "no hit" (no clamp of the samples
+//         left) and one all-zero row that undecided rays are pointed at (no select, no exec juggling);
+//       - the beam walk of the slots every live lane of the wave has is ONE asm block with its own vmcnt counting,
+//         induction variables advanced by per-lane increments (0 for a lane without rays) and undecided rays parked in
+//         two registers until the pass is over.
+//   * A work item is (slice, group of G wedges): the workgroup keeps the running sum of a particle in part[group][slot]
+//     (sorted order, plain loads and stores by the one lane that owns the slot), so the 16 fp64 atomics per particle of
+//     k_rays_cell are gone and k_combine_logw reads G-fold fewer partial sums.
+#pragma once
+
+namespace mcl {
+
+constexpr int kSwUnder = 127;            // table rows below "no hit": samples left in [-127, -1] after an over-long jump
+constexpr int kSwUnit = 1024;            // particles per scheduling unit: one pass of the 16 waves of a workgroup
+constexpr int kSwFx = kQFx;              // 22 fractional bits
+
+// rows of the per-update fp64 table of k_rays_sweep: row r = samples left + kSwUnder, plus one all-zero row
+__host__ __device__ inline int sweep_table_rows(int P) { return P + kSwUnder + 2; }
+
+// Ltd[r][j]: r = left + kSwUnder for left in [-kSwUnder, P] -> (double)L[obs_idx[j]][P - max(left, 0)];
+// r = P + kSwUnder + 1 -> 0 (undecided rays: k_rays_fix adds their entry); columns j >= B are 0 (lanes without rays).
+__global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int cols, int P,
+                            double *__restrict__ Ltd)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j >= cols) return;
+    double v = 0.0;
+    if (j < B && r <= P + kSwUnder) {
+        const int left = r - kSwUnder;
+        const int d = P - (left > 0 ? left : 0);
+        v = (double)L[(size_t)obs_idx[j] * (P + 1) + d];
+    }
+    Ltd[(size_t)r * cols + j] = v;
+}
+
+// (sum of pixel x, sum of pixel y, count) of the finite positions of every unit of kSwUnit sorted particles: a work item
+// centres its windows on the mean over its units
+__global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ pcs, int64_t n, double4 *__restrict__ out)
+{
+    __shared__ double sm[4][3];
+    const int64_t p_begin = (int64_t)blockIdx.x * kSwUnit;
+    const int64_t p_end = (p_begin + kSwUnit < n) ? p_begin + kSwUnit : n;
+    double sx = 0.0, sy = 0.0, cnt = 0.0;
+    for (int64_t s = p_begin + threadIdx.x; s < p_end; s += blockDim.x) {
+        const double4 c = pcs[s];
+        if (c.z == c.z && c.w == c.w && fabs(c.z) < 1e9 && fabs(c.w) < 1e9) { sx += c.z; sy += c.w; cnt += 1.0; }
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = sx; sm[threadIdx.x >> 6][1] = sy; sm[threadIdx.x >> 6][2] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = make_double4(sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0], sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1],
+                                       sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2], 0.0);
+}
+
+// One probe trip on window-relative fixed-point positions that carry the guard bias: T = P0 + G + s * U.
+//   frac(T) < 2G  <=>  the unbiased sample lies within G units of a cell boundary (either side);
+// the cell is read at the biased position, which differs from the true cell only for such a sample.
+#define MCL_SW_TRIP(REM, GIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, NUX, NUY, PEX, PEY, STR, MASK, LB) \
+    "v_mad_i32_i24 " TX ", " REM ", " NUX ", " PEX "\n\t"                                              \
+    "v_mad_i32_i24 " TY ", " REM ", " NUY ", " PEY "\n\t"                                              \
+    "v_lshrrev_b32 " T0 ", 22, " TX "\n\t"                                                             \
+    "v_lshrrev_b32 " T1 ", 22, " TY "\n\t"                                                             \
+    "v_mad_u32_u24 " AD ", " T1 ", " STR ", " T0 "\n\t"                                                \
+    "ds_read_i8 " BY ", " AD " offset:" LB "\n\t"                                                      \
+    "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                           \
+    "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                           \
+    "v_min3_u32 " GOUT ", " GIN ", " T0 ", " T1 "\n\t"                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
+    "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                \
+    "s_andn2_b64 exec, exec, vcc\n\t"
+
+template <bool COUNT>
+__global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int item_sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long cnt_probe = 0;
+    const int G = a.sweep_g;                                   // wedges per work item (divides kWedges)
+    const int nitems = a.nitems;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
+    const int S = a.qside;
+    // level-1 error bound: 0.5 unit for the origin + 0.5 unit per sample for the direction, s <= P samples (+4)
+    const uint32_t guard_units = (uint32_t)(a.P + 1) / 2u + 5u;
+    const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : 2u * guard_units;
+    const uint32_t fmask = (1u << kSwFx) - 1u;
+    const int negP = __builtin_amdgcn_readfirstlane(-a.P);
+    const uint32_t st8 = (uint32_t)__builtin_amdgcn_readfirstlane(a.ltd_cols * 8);
+    const uint32_t zrow = (uint32_t)(a.P + 1);                 // "samples left" that selects the all-zero row
+    const unsigned char *ldsb = lds_raw;
+    uint32_t stride_v = (uint32_t)S;
+    asm volatile("" : "+v"(stride_v));
+    for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) item_sh = (int)atomicAdd(a.work_counter, 1ull);
+    __syncthreads();
+    const int item = item_sh;
+    if (item >= nitems) break;
+    // (first unit, units, wedge group): the host lists big items first and single units last (guided schedule), so the
+    // persistent workgroups finish within one small item of each other
+    const int4 it = a.items[item];                                   // wave-uniform: scalar loads
+    const int grp = it.z;
+    const int64_t p_begin = (int64_t)it.x * kSwUnit;
+    const int64_t p_end = (p_begin + (int64_t)it.y * kSwUnit < a.n) ? p_begin + (int64_t)it.y * kSwUnit : a.n;
+    if (p_begin >= p_end) continue;
+    double *part = a.part + (size_t)grp * (size_t)a.n;
+    double2 mm = make_double2(0.0, 0.0);
+    {
+        double sx = 0.0, sy = 0.0, cnt = 0.0;
+        for (int u = 0; u < it.y; ++u) { const double4 us = a.unit_sums[it.x + u]; sx += us.x; sy += us.y; cnt += us.z; }
+        if (cnt > 0.0) mm = make_double2(sx / cnt, sy / cnt);
+    }
+    for (int gw = 0; gw < G; ++gw) {
+    const int kbin = grp * G + gw;
+    const int q = kbin >> kWedgeShift;
+    const int sxp = (q == 0 || q == 3), syp = (q == 0 || q == 1);
+    const int mlo = 3;
+    int wx0, wy0;
+    {
+        const double mx = mm.x, my = mm.y;
+        const int E = S - (a.P + 2) - mlo;
+        const int back = E / 2 + mlo;
+        int cxm = (int)floor(mx) + 1, cym = (int)floor(my) + 1;
+        wx0 = sxp ? cxm - back : cxm + back - S;
+        wy0 = syp ? cym - back : cym + back - S;
+        uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
+        const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
+        const int wpr = S >> 3;
+        const int nwords = wpr * S;
+        const int drow = kRayThreads / wpr, dcw = kRayThreads - drow * wpr;
+        int row = (int)threadIdx.x / wpr, cw = (int)threadIdx.x - row * wpr;
+        if (gw > 0) __syncthreads();                                       // every wave is done with the previous window
+        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads, row += drow, cw += dcw) {
+            if (cw >= wpr) { cw -= wpr; ++row; }
+            int gy = wy0 + row, gx = wx0 + cw * 8;
+            // the wedge fields are stored in the LDS encoding (stop = 0xFF, skips 1..127); outside the grid is stop
+            uint64_t b8 = ~0ull;
+            if (gy >= 0 && gy < a.Hp) {
+                const uint8_t *rowp = fieldq + (size_t)gy * a.Wps;
+                if (gx >= 0 && gx + 8 <= a.Wp) {
+                    b8 = *reinterpret_cast<const uint64_t *>(rowp + gx);
+                } else {
+                    for (int k = 0; k < 8; ++k)
+                        if (gx + k >= 0 && gx + k < a.Wp) b8 = (b8 & ~(0xFFull << (8 * k))) | ((uint64_t)rowp[gx + k] << (8 * k));
+                }
+            }
+            win[wi] = b8;
+        }
+        __syncthreads();
+    }
+
+    for (int64_t s0g = p_begin + (int64_t)wave * 64; s0g < p_end; s0g += (int64_t)kRayWaves * 64) {
+        const int64_t slot = s0g + lane;
+        const bool have = slot < p_end;
+        const int64_t sl = have ? slot : p_end - 1;
+        const double4 pci = a.pcs[sl];
+        // running sum of this group's earlier wedges (the same lane wrote it): requested now, needed after the walk
+        double prev = 0.0;
+        if (gw > 0 && have) prev = part[slot];
+        // beams of this particle in wedge kbin: [ja, jb) and, for scans wider than a turn minus one wedge, [ja2, B)
+        int ja = 0, jb = 0, ja2 = a.B;
+        {
+            const double th = a.ths[sl];
+            if (th == th && fabs(th) < 1e6) {
+                const int w0 = beam_wedge(th, a.beam_angle[0]), wl = beam_wedge(th, a.beam_angle[a.B - 1]);
+                const int m = w0 + ((kbin - w0) & (kWedges - 1));
+                if (m <= wl) {
+                    ja = m == w0 ? 0 : first_beam_in_wedge(th, a.beam_angle, a.B, m, a.beam_a0, a.beam_inv_inc);
+                    jb = m == wl ? a.B : first_beam_in_wedge(th, a.beam_angle, a.B, m + 1, a.beam_a0, a.beam_inv_inc);
+                    if (m + kWedges <= wl) ja2 = first_beam_in_wedge(th, a.beam_angle, a.B, m + kWedges, a.beam_a0, a.beam_inv_inc);
+                }
+            } else if (kbin == 0) {
+                jb = a.B;            // garbage heading: one range in quadrant 0 like k_particle_prep (position is NaN -> far path)
+            }
+        }
+        int n1 = jb > ja ? jb - ja : 0, n2 = a.B > ja2 ? a.B - ja2 : 0;
+        if (!have) { n1 = 0; n2 = 0; }
+        const double wpx = pci.z - (double)(wx0 - 1);
+        const double wpy = pci.w - (double)(wy0 - 1);
+        const double fwd = (double)(a.P + 2), bwd = 2.0;
+        const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
+        const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
+        const bool inwin = inx && iny;
+        uint32_t i = 0xFFFFFFFFu;                                  // particle index, loaded by the rare paths that need it
+        if (!inwin && n1 + n2 > 0) {                           // not in this window (or NaN): k_rays_far does this pair
+            atomicOr(reinterpret_cast<unsigned int *>(a.far_flags) + sl, 1u << (8 * q));      // flags, lists and sums are slot-indexed
+            n1 = 0; n2 = 0;
+        }
+        const int total = n1 + n2;
+        // a lane without rays gets a zero direction and zero samples from the window's cell (2, 2): every probe it
+        // makes reads that cell, whose byte is never 0, and leaves the loop at once; its table column is the zero column B
+        const bool live = total > 0;
+        const double lpx = live ? wpx : 2.5, lpy = live ? wpy : 2.5;
+        const double p0x = lpx + kMagic, p0y = lpy + kMagic;
+        const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
+        const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
+        const int d0 = ldsb[cy0 * S + cx0];
+        const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
+        const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
+        // window-relative origin in 2^-22 px, biased by the guard (see MCL_SW_TRIP)
+        const uint32_t P0x = (uint32_t)rint_i32(lpx * 4194304.0 - 2147483648.0) + 0x80000000u + guard_units;
+        const uint32_t P0y = (uint32_t)rint_i32(lpy * 4194304.0 - 2147483648.0) + 0x80000000u + guard_units;
+        const int rem_start = (live && s0 <= a.P) ? a.P - s0 : 0;
+        const double ncth = live ? -pci.x * 4194304.0 : 0.0, sths = live ? pci.y * 4194304.0 : 0.0;
+        int tmax = total, tmin = live ? total : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { tmax = max(tmax, __shfl_xor(tmax, o, 64)); tmin = min(tmin, __shfl_xor(tmin, o, 64)); }
+        tmax = __builtin_amdgcn_readfirstlane(tmax);
+        tmin = __builtin_amdgcn_readfirstlane(tmin);
+        // a second range only exists for scans wider than three quadrants; the common case steps j by one
+        const bool wraps = __builtin_amdgcn_readfirstlane((int)(__ballot(n2 > 0 && n1 > 0) != 0ull)) != 0;
+        const int jfirst = n1 > 0 ? ja : (n2 > 0 ? ja2 : 0);
+        double acc_fast = 0.0, acc = 0.0;
+        uint32_t ambcnt = 0, ambj1 = 0, ambj2 = 0;
+        int t_done = 0;
+        bool expired_fast = false;
+        if (!COUNT && !a.steps && !wraps && tmax > 0 && tmin > 0) {
+            // ---- the slots every live lane has: one asm block, all 64 lanes active, no per-slot validity tests ----
+            // v[40:43] direction of the beam (cos, sin); v[44:45] / v[46:47] rotated direction + magic: NUx = v44, NUy = v46, and
+            // once those exist v45 / v47 are the trip's scratch; v[48:49] product, then LDS address / cell byte / table offset;
+            // v[50:51] pending table entry; v52 v53 Pe; v54 v55 T; v56 guard minimum; v57 samples left
+            uint32_t j16 = live ? (uint32_t)jfirst << 4 : 0u;
+            // table column offset, biased by kSwUnder rows so that (samples left) * row bytes + j8b is never negative
+            uint32_t j8b = (uint32_t)kSwUnder * st8 + (live ? (uint32_t)jfirst << 3 : (uint32_t)a.B << 3);
+            const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
+            uint32_t tc = (uint32_t)tmin - 1u, expired = 0u, cd;
+            const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
+            asm volatile(
+                "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"
+                "v_mov_b32 v48, %[zoff]\n\t"
+                "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"             // 0.0: keeps the vmcnt pattern of the steady state
+                "3:\n\t"
+                "s_waitcnt vmcnt(1)\n\t"                                    // direction landed (the table entry may be in flight)
+                "v_mul_f64 v[48:49], %[sths], v[42:43]\n\t"
+                "v_fma_f64 v[44:45], %[ncth], v[40:41], v[48:49]\n\t"
+                "v_mul_f64 v[48:49], %[sths], v[40:41]\n\t"
+                "v_fma_f64 v[46:47], %[ncth], v[42:43], -v[48:49]\n\t"
+                "v_add_f64 v[44:45], v[44:45], %[magic]\n\t"
+                "v_add_f64 v[46:47], v[46:47], %[magic]\n\t"
+                "v_add_u32 %[j16], %[j16], %[inc16]\n\t"
+                "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"          // next beam's direction
+                "v_mad_i32_i24 v52, %[negp], v44, %[p0x]\n\t"
+                "v_mad_i32_i24 v53, %[negp], v46, %[p0y]\n\t"
+                "s_movk_i32 %[cd], 300\n\t"
+                MCL_SW_TRIP("%[rem0]", "%[g0]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "v52", "v53", "%[str]", "%[mask]", "%[lb]")
+                "s_cbranch_execz 2f\n"
+                "1:\n\t"
+                MCL_SW_TRIP("v57", "v56", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "v52", "v53", "%[str]", "%[mask]", "%[lb]")
+                "s_cbranch_execz 2f\n\t"
+                "s_sub_u32 %[cd], %[cd], 1\n\t"
+                "s_cbranch_scc0 1b\n\t"
+                "s_mov_b32 %[expired], 1\n"                                 // malformed window (impossible): the pass is redone by the fix-up path
+                "2:\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "v_cmp_gt_u32 vcc, %[thr], v56\n\t"                         // undecided: a sample within the guard of a boundary
+                "s_cbranch_vccz 4f\n\t"
+                "s_mov_b64 exec, vcc\n\t"
+                "v_mov_b32 %[ambj2], %[ambj1]\n\t"
+                "v_mov_b32 %[ambj1], %[j16]\n\t"                            // (beam + 1) << 4
+                "v_add_u32 %[ambcnt], 1, %[ambcnt]\n\t"
+                "v_mov_b32 v57, %[zrow]\n\t"
+                "s_mov_b64 exec, -1\n"
+                "4:\n\t"
+                "s_waitcnt vmcnt(1)\n\t"                                    // previous beam's table entry landed
+                "v_add_f64 %[acc], %[acc], v[50:51]\n\t"
+                "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"
+                "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"
+                "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"
+                "s_sub_u32 %[tc], %[tc], 1\n\t"
+                "s_cbranch_scc0 3b\n\t"
+                "s_waitcnt vmcnt(0)\n\t"
+                "v_add_f64 %[acc], %[acc], v[50:51]"
+                : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2),
+                  [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)
+                : [ncth] "v"(ncth), [sths] "v"(sths), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0),
+                  [inc16] "v"(inc16), [inc8] "v"(inc8), [str] "v"(stride_v), [csb] "s"(a.beam_cs), [ltb] "s"(a.Ltd), [negp] "s"(negP),
+                  [st8] "s"(st8), [mask] "s"(fmask), [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff),
+                  [lb] "n"(kQLdsBase)
+                : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+                  "v54", "v55", "v56", "v57");
+            t_done = tmin;
+            expired_fast = expired != 0u;
+        }
+        // ---- remaining slots (lanes differ in how many rays they have), scans that wrap, probe counting, step output ----
+        if (t_done < tmax) {
+            // slot t of this lane is beam ja + t for t < n1, then ja2 + (t - n1); past its last slot a lane repeats
+            // its last beam (result discarded) so that it stays on a valid in-window ray
+            const int jlast = total > 0 ? (n2 > 0 ? a.B - 1 : jb - 1) : 0;
+            int j = jfirst + t_done;                                  // t_done > 0 only without a second range
+            if (j > jlast) j = jlast;
+            if (i == 0xFFFFFFFFu && (a.steps || COUNT)) i = a.perm[sl];
+            double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
+            double lt_pending = 0.0;
+            for (int t = t_done; t < tmax; ++t) {
+                acc += lt_pending;
+                asm volatile("" : "+v"(acc));
+                const bool valid = t < total;
+                const int jcur = j;
+                {
+                    int jn = j + 1;
+                    if (wraps && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
+                    j = min(jn, jlast);
+                }
+                const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
+                const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
+                cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
+                const uint32_t Pex = mad_i24_s(negP, NUx, P0x), Pey = mad_i24_s(negP, NUy, P0y);
+                int rem;
+                uint32_t g;
+                bool expired = false;
+                if (!COUNT) {
+                    uint32_t Tx, Ty, t0, t1, addr, byte;
+                    unsigned long long saved_exec;
+                    uint32_t countdown;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "s_movk_i32 %[cd], 300\n\t"
+                        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[nux]", "%[nuy]", "%[pex]", "%[pey]", "%[str]", "%[mask]", "%[lb]")
+                        "s_cbranch_execz 2f\n"
+                        "1:\n\t"
+                        MCL_SW_TRIP("%[rem]", "%[g]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[nux]", "%[nuy]", "%[pex]", "%[pey]", "%[str]", "%[mask]", "%[lb]")
+                        "s_cbranch_execz 2f\n\t"
+                        "s_sub_u32 %[cd], %[cd], 1\n\t"
+                        "s_cbranch_scc0 1b\n"
+                        "2:\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
+                          [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                        : [rem0] "v"(rem_start), [g0] "v"(g0), [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v),
+                          [mask] "s"(fmask), [lb] "n"(kQLdsBase)
+                        : "memory", "vcc", "scc");
+                    // the countdown only expires if the window is malformed (impossible): every ray of the pass to the fix-up list
+                    expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
+                } else {
+                    bool go;
+                    int trips = 0;
+                    rem = rem_start;
+                    g = g0;
+                    do {
+                        const uint32_t Tx = mad_i24(rem, NUx, Pex), Ty = mad_i24(rem, NUy, Pey);
+                        const uint32_t gm = (Tx & fmask) < (Ty & fmask) ? (Tx & fmask) : (Ty & fmask);
+                        g = g < gm ? g : gm;
+                        const uint32_t byte = (uint32_t)(int)(int8_t)ldsb[(Ty >> kSwFx) * (uint32_t)S + (Tx >> kSwFx)];
+                        uint32_t nr;
+                        const bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);
+                        go = !over;
+                        rem = (int)nr;
+                        cnt_probe += (go && valid) ? 1 : 0;
+                    } while (go && ++trips <= 300);
+                    if (go) g = 0u;
+                }
+                if (COUNT && valid) ++cnt_probe;
+                const uint32_t thr = expired ? 0xFFFFFFFFu : gthresh;     // wave-uniform: a scalar select
+                const bool amb = valid && g < thr;
+                lt_pending = 0.0;
+                if (valid && !amb) {
+                    const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
+                    lt_pending = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.Ltd) +
+                                                                   mad_u24_s((uint32_t)(left + kSwUnder), st8, (uint32_t)jcur << 3));
+                    if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
+                }
+                if (amb) {
+                    const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
+                    if (fslot < a.fix_cap)
+                        atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)sl << 16) | (unsigned long long)jcur);
+                }
+            }
+            acc += lt_pending;
+        }
+        // undecided rays of the asm walk: up to two per lane were parked; a lane with more (or an expired countdown)
+        // hands its whole range of that walk to the fix-up list and drops what it summed there
+        if (expired_fast) ambcnt = 3u;
+        if (!live) ambcnt = 0u;                                    // a lane without rays traces a dummy ray: nothing to redo
+        if (ambcnt != 0u) {
+            const int nlist = ambcnt > 2u ? t_done : (int)ambcnt;
+            for (int k = 0; k < nlist; ++k) {
+                const int jamb = ambcnt > 2u ? jfirst + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1;
+                const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
+                if (fslot < a.fix_cap)
+                    atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)sl << 16) | (unsigned long long)(jamb & 0xFFFF));
+            }
+            if (ambcnt > 2u) acc_fast = 0.0;
+        }
+        if (have) part[slot] = prev + (acc_fast + acc);
+    }
+    }   // wedges of the group
+    }   // work items
+    if (COUNT && a.counters) {
+        cnt_probe = wave_sum_u64(cnt_probe);
+        if (lane == 0 && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
+    }
+}
+
+// log-weight of every particle = the partial sums of its wedge groups + what k_rays_far / k_rays_fix / k_rays_exact added
+// for it (fp64 atomics of earlier kernels: plain loads see them, profiles/r02_coherence.txt), all in sorted-slot order and
+// read coalesced; one scattered 8-byte store per particle puts the sum where the rest of the update expects it.  Also the
+// per-workgroup maximum for the normalisation (replaces k_reduce_max; k_final_max reduces `maxpart`).
+__global__ __launch_bounds__(256) void k_combine_logw(const double *__restrict__ part, int ngroups, int64_t n, const uint32_t *__restrict__ perm,
+                                                     const double *__restrict__ acc, double *__restrict__ logw, double *__restrict__ maxpart)
+{
+    __shared__ double sm[4];
+    double m = -INFINITY;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        double v = acc[s];
+        for (int g = 0; g < ngroups; ++g) v += part[(size_t)g * (size_t)n + s];
+        logw[perm[s]] = v;
+        m = fmax(m, v);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) maxpart[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+}  // namespace mcl

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmcl_hip_engine.so")
 MCL_OK = 0
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 WEIGHT_LOG, WEIGHT_PRODUCT = 0, 1
-RAYS_AUTO, RAYS_MARCH, RAYS_SKIP, RAYS_QUAD, RAYS_CELL = 0, 1, 2, 3, 4
+RAYS_AUTO, RAYS_MARCH, RAYS_SKIP, RAYS_QUAD, RAYS_CELL, RAYS_SWEEP = 0, 1, 2, 3, 4, 5
 BUF_X, BUF_Y, BUF_THETA, BUF_QWEIGHT, BUF_LOGW, BUF_SCALARS = range(6)
 
 EXPORTS = [
@@ -297,7 +297,7 @@ class Engine:
     def ray_kernel_name(self):
         v = C.c_int32()
         self._chk(self.lib.mcl_get_ray_kernel_id(self._h, C.byref(v)), "mcl_get_ray_kernel_id")
-        return {1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell"}.get(v.value, "?")
+        return {1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}.get(v.value, "?")
 
     # -- multi-GPU staging (raw device pointers as ints)
     def device_ptr(self, which) -> int:

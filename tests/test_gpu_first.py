@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kernel", ["march", "skip", "skip_forced_exact", "skip_forced_level2", "quad", "quad_forced_exact",
-                                    "quad_forced_level2", "cell", "cell_forced_exact", "cell_forced_level2"])
+                                    "quad_forced_level2", "cell", "cell_forced_exact", "cell_forced_level2",
+                                    "w_sweep", "w_sweep_forced_exact", "w_sweep_forced_level2"])
 def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_oracle, kernel):
     om = spielberg_oracle
     ang = orc.beam_angles(angle_step=9)       # 121 beams
@@ -17,7 +18,8 @@ def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_o
     N = 777
     p = tracking_cloud(rng, N)
     cfg = dict(keep_ray_steps=1, debug_count_probes=1)
-    cfg["ray_kernel"] = {"m": engine_mod.RAYS_MARCH, "s": engine_mod.RAYS_SKIP, "q": engine_mod.RAYS_QUAD, "c": engine_mod.RAYS_CELL}[kernel[0]]
+    cfg["ray_kernel"] = {"m": engine_mod.RAYS_MARCH, "s": engine_mod.RAYS_SKIP, "q": engine_mod.RAYS_QUAD, "c": engine_mod.RAYS_CELL,
+                         "w": engine_mod.RAYS_SWEEP}[kernel[0]]
     if kernel.endswith("forced_exact"):
         cfg["debug_force_exact"] = 1
     if kernel.endswith("forced_level2"):
@@ -36,7 +38,7 @@ def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_o
         assert c["exact_fallback_rays"] == N * ang.size
     if kernel.endswith("forced_level2"):
         assert c["level2_rays"] == N * ang.size and c["exact_fallback_rays"] < N * ang.size // 1000
-    if kernel in ("skip", "quad", "cell"):
+    if kernel in ("skip", "quad", "cell", "w_sweep"):
         # level 1 hands only a small fraction of rays to level 2, and level 2 almost none to level 3
         assert c["level2_rays"] < N * ang.size // 100 and c["exact_fallback_rays"] < N * ang.size // 10000
         assert 0 < c["probes"] < probes

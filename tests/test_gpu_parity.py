@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def KERNELS(engine_mod):
-    return {"auto": engine_mod.RAYS_AUTO, "cell": engine_mod.RAYS_CELL}
+    return {"auto": engine_mod.RAYS_AUTO, "cell": engine_mod.RAYS_CELL, "sweep": engine_mod.RAYS_SWEEP}
 
 ACTION = (0.05, 0.0, 0.01)
 
@@ -39,14 +39,15 @@ def test_sensor_table_bit_exact(request, orc, engine_mod, mapname, P):
 
 # ------------------------------------------------------------------------------------------- C (G2)
 @pytest.mark.parametrize("name", ["Spielberg_map", "sibal1"])
-@pytest.mark.parametrize("kernel", ["march", "skip", "skip_l2", "auto", "cell"])
+@pytest.mark.parametrize("kernel", ["march", "skip", "skip_l2", "auto", "cell", "sweep"])
 def test_cast_ray_golden(orc, engine_mod, maps_mod, name, kernel):
     """One particle per golden ray, a single beam at angle 0: step index == fixture (incl. rays that
     start outside the map, inside walls, within a cell of the lower/left edge, axis-aligned)."""
     m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{name}.npz"))
     z = load(f"g2_cast_ray_{name}.npz")
     n = z["x"].size
-    rk = {"march": engine_mod.RAYS_MARCH, "auto": engine_mod.RAYS_AUTO, "cell": engine_mod.RAYS_CELL}.get(kernel, engine_mod.RAYS_SKIP)
+    rk = {"march": engine_mod.RAYS_MARCH, "auto": engine_mod.RAYS_AUTO, "cell": engine_mod.RAYS_CELL,
+          "sweep": engine_mod.RAYS_SWEEP}.get(kernel, engine_mod.RAYS_SKIP)
     e = make_engine(engine_mod, m, np.zeros(1, np.float32), n, keep_ray_steps=1, ray_kernel=rk,
                     debug_force_exact=2 if kernel == "skip_l2" else 0)
     e.set_particles(np.stack([z["x"], z["y"], z["theta"]]), np.full(n, 1.0 / n))
@@ -54,7 +55,7 @@ def test_cast_ray_golden(orc, engine_mod, maps_mod, name, kernel):
     assert np.array_equal(e.ray_steps()[:, 0].astype(np.int16), z["steps"])
 
 
-@pytest.mark.parametrize("path", ["auto", "cell"])
+@pytest.mark.parametrize("path", ["auto", "cell", "sweep"])
 def test_cast_ray_many_beams_scattered_particles(orc, engine_mod, sibal1, sibal1_oracle, path):
     """Particles scattered over the whole (small) map and beyond it: exercises the off-window path."""
     om = sibal1_oracle
@@ -72,7 +73,7 @@ def test_cast_ray_many_beams_scattered_particles(orc, engine_mod, sibal1, sibal1
     assert np.array_equal(e.log_weights(), logw)
 
 
-@pytest.mark.parametrize("path", ["auto", "cell"])
+@pytest.mark.parametrize("path", ["auto", "cell", "sweep"])
 def test_global_regime_uses_fallback_and_stays_exact(orc, engine_mod, spielberg, spielberg_oracle, path):
     from monte_carlo_localization_amd import synth
     om = spielberg_oracle
@@ -92,7 +93,7 @@ def test_global_regime_uses_fallback_and_stays_exact(orc, engine_mod, spielberg,
         assert e.counters()["off_window_particles"] > 0
 
 
-@pytest.mark.parametrize("path", ["auto", "cell"])
+@pytest.mark.parametrize("path", ["auto", "cell", "sweep"])
 def test_nonfinite_particles_do_not_hang_or_crash(orc, engine_mod, sibal1, path):
     ang = orc.beam_angles(angle_step=60)
     n = 64
@@ -384,7 +385,7 @@ def test_update_scan_downsamples_like_lidarcb(orc, engine_mod, spielberg):
 
 @pytest.mark.parametrize("mapname", ["Spielberg_map", "sibal1", "icra_2_clean", "first_map"])
 @pytest.mark.parametrize("max_range,n_beams_step", [(12.0, 7), (5.0, 13), (3.3, 31)])
-@pytest.mark.parametrize("path", ["auto", "cell"])
+@pytest.mark.parametrize("path", ["auto", "cell", "sweep"])
 def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_range, n_beams_step, path):
     """Every fixture map, three MAX_RANGE_PX values, global clouds (free cells) plus particles inside walls
     and outside the map: steps and log-weights bit-exact vs the oracle through the default kernel."""
@@ -411,7 +412,7 @@ def test_ray_steps_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_r
     assert np.array_equal(e.log_weights(), logw)
 
 
-@pytest.mark.parametrize("path", ["auto", "cell"])
+@pytest.mark.parametrize("path", ["auto", "cell", "sweep"])
 def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle, path):
     """Window partly outside the map (lower-left corner): out-of-map cells must read as stops, and the
     truncation-toward-zero column/row (pixel coordinates in (-1,0)) must read cell 0."""
@@ -453,24 +454,25 @@ def test_cell_kernel_full_turn_scan_and_identical_particles(orc, engine_mod, sib
 
 
 def test_cell_and_quad_agree_over_updates(orc, engine_mod, spielberg):
-    """Same seed, 200k particles, thirty updates: the cell-sorted kernel (default at this size) and k_rays_quad give
+    """Same seed, 200k particles, thirty updates: k_rays_sweep (default at this size), k_rays_cell and k_rays_quad give
     the same particles, weights and pose bit for bit (the sort only changes which rays share a wave; a lost or
-    duplicated slot of the per-XCD counting sort would show up here)."""
+    duplicated slot of the per-XCD counting sort, or a partial sum read back stale, would show up here)."""
     from monte_carlo_localization_amd import synth
     ang = orc.beam_angles(angle_step=9)
     obs = load("scan_Spielberg_map_origin.npz")["ranges"][::9].copy()
     n = 200000
     out = {}
-    for name, rk in (("auto", engine_mod.RAYS_AUTO), ("quad", engine_mod.RAYS_QUAD)):
+    for name, rk in (("auto", engine_mod.RAYS_AUTO), ("cell", engine_mod.RAYS_CELL), ("quad", engine_mod.RAYS_QUAD)):
         e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=rk, seed=5)
         e.init_particles_pose((0.0, 0.0, 0.0), n)
         for _ in range(30):
             e.update(ACTION, obs)
         out[name] = (e.ray_kernel_name(), e.get_particles(), e.get_weights(), e.expected_pose())
-    assert out["auto"][0] == "k_rays_cell" and out["quad"][0] == "k_rays_quad"
-    assert np.array_equal(out["auto"][1], out["quad"][1])
-    assert np.array_equal(out["auto"][2], out["quad"][2])
-    assert np.array_equal(out["auto"][3], out["quad"][3])
+    assert out["auto"][0] == "k_rays_sweep" and out["cell"][0] == "k_rays_cell" and out["quad"][0] == "k_rays_quad"
+    for other in ("cell", "quad"):
+        assert np.array_equal(out["auto"][1], out[other][1])
+        assert np.array_equal(out["auto"][2], out[other][2])
+        assert np.array_equal(out["auto"][3], out[other][3])
 
 
 # ------------------------------------------------------------------------------------------- adaptive resampling

@@ -1,0 +1,141 @@
+"""k_rays_sweep (MCL_RAYS_SWEEP, the default ray kernel from 65 536 particles) against the CPU oracle WITHOUT
+keep_ray_steps: that is the configuration in which its hand-written beam walk runs (step output, probe counting and
+scans that wrap take the plain per-ray path, which tests/test_gpu_parity.py and test_gpu_first.py cover through the
+`sweep` parameter).  Log-weights are exact fp64 sums of fp32 table entries, so the comparison is
+bit for bit: a single wrong ray step, a stale partial sum, a ray counted twice by the fix-up list or an undecided ray
+dropped shows up as a different double."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_engine, tracking_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_logw(orc, om, p, ang, obs, inv_squash=None):
+    T = orc.sensor_table(om.max_range_px)
+    L = orc.eng_log_table(T) if inv_squash is None else orc.eng_log_table(T, inv_squash)
+    logw, _, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L)
+    return logw
+
+
+def sweep_logw(engine_mod, m, ang, p, obs, **cfg):
+    n = p.shape[1]
+    e = make_engine(engine_mod, m, ang, n, ray_kernel=engine_mod.RAYS_SWEEP, **cfg)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(obs)
+    assert e.ray_kernel_name() == "k_rays_sweep"
+    out = e.log_weights(), e.counters()
+    e.close()
+    return out
+
+
+def scan1081():
+    return np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
+
+
+@pytest.mark.parametrize("force", [0, 2, 1])
+def test_tracking_cloud_1081_beams(orc, engine_mod, spielberg, spielberg_oracle, force):
+    """BASELINE config #1's shape (tracking cloud x 1081 beams).  force = 2 / 1 sends EVERY ray through the parked-ray
+    overflow of the beam walk into the fix-up list (level 2 / level 3): nothing may be counted twice or lost."""
+    ang = orc.beam_angles(angle_step=1)
+    n = {0: 8192, 2: 2048, 1: 512}[force]
+    p = tracking_cloud(np.random.default_rng(3), n)
+    got, c = sweep_logw(engine_mod, spielberg, ang, p, scan1081(), debug_force_exact=force)
+    assert np.array_equal(got, oracle_logw(orc, spielberg_oracle, p, ang, scan1081()))
+    if force == 0:
+        assert 0 < c["level2_rays"] < n * ang.size // 100
+    if force == 2:
+        assert c["level2_rays"] == n * ang.size
+    if force == 1:
+        assert c["exact_fallback_rays"] == n * ang.size
+
+
+def test_scattered_particles_and_off_window_pairs(orc, engine_mod, sibal1, sibal1_oracle):
+    om = sibal1_oracle
+    ang = orc.beam_angles(angle_step=5)
+    rng = np.random.default_rng(11)
+    n = 3000
+    p = np.stack([om.origin_x + rng.uniform(-2, 20, n), om.origin_y + rng.uniform(-2, 11, n), rng.uniform(-np.pi, np.pi, n)])
+    obs = np.full(ang.size, 3.0, np.float32)
+    got, c = sweep_logw(engine_mod, sibal1, ang, p, obs)
+    assert np.array_equal(got, oracle_logw(orc, om, p, ang, obs))
+    assert c["off_window_particles"] > 0
+
+
+def test_full_turn_scan_identical_particles_wedge_edges(orc, engine_mod, sibal1, sibal1_oracle):
+    om = sibal1_oracle
+    ang = np.linspace(-np.pi, np.pi - 0.004, 720).astype(np.float32)
+    rng = np.random.default_rng(31)
+    n = 3000
+    p = np.stack([rng.uniform(-1.0, 1.0, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-np.pi, np.pi, n)])
+    p[:, :1000] = np.array([[0.3], [0.1], [0.7]])                       # one hot bucket of the sort
+    p[2, 1000:1100] = np.pi * rng.integers(-4, 5, 100) / 8.0             # headings exactly on wedge edges
+    obs = rng.uniform(0.5, 8.0, ang.size).astype(np.float32)
+    got, _ = sweep_logw(engine_mod, sibal1, ang, p, obs)
+    assert np.array_equal(got, oracle_logw(orc, om, p, ang, obs))
+
+
+@pytest.mark.parametrize("mapname", ["Spielberg_map", "sibal1", "icra_2_clean", "first_map"])
+@pytest.mark.parametrize("max_range,n_beams_step", [(12.0, 7), (5.0, 13), (3.3, 31)])
+def test_all_maps_and_ranges(orc, engine_mod, maps_mod, mapname, max_range, n_beams_step):
+    m = maps_mod.load_npz(os.path.join(GOLDEN, f"map_{mapname}.npz"))
+    om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y, max_range_m=max_range)
+    from monte_carlo_localization_amd import synth
+    ang = orc.beam_angles(angle_step=n_beams_step)
+    rng = np.random.default_rng(zlib.crc32(f"sweep{mapname}{n_beams_step}".encode()))
+    n = 2500
+    p = synth.global_cloud(rng, m, n)
+    p[:2, :100] += rng.normal(0, 3.0, (2, 100))           # some land in walls / outside the map
+    p[:, 100:1100] = p[:, 100:101] + rng.normal(0, 0.05, (3, 1000))     # and a tight cluster: full 64-lane groups of near-identical rays
+    obs = rng.uniform(0.0, max_range * 1.2, ang.size).astype(np.float32)
+    got, _ = sweep_logw(engine_mod, m, ang, p, obs, max_range_m=max_range, squash_factor=3.1)
+    assert np.array_equal(got, oracle_logw(orc, om, p, ang, obs, 1.0 / 3.1))
+
+
+def test_cluster_near_map_corner_and_nonfinite(orc, engine_mod, sibal1, sibal1_oracle):
+    om = sibal1_oracle
+    ang = orc.beam_angles(angle_step=3)
+    rng = np.random.default_rng(21)
+    n = 2000
+    p = np.stack([om.origin_x + rng.uniform(-0.2, 1.0, n), om.origin_y + rng.uniform(-0.2, 1.0, n), rng.uniform(-np.pi, np.pi, n)])
+    bad = np.array([0, 1, 2, 3, 4])
+    p[0, 0] = np.nan; p[1, 1] = np.inf; p[0, 2] = -np.inf; p[2, 3] = np.nan; p[0, 4] = 1e300
+    obs = np.full(ang.size, 1.0, np.float32)
+    got, _ = sweep_logw(engine_mod, sibal1, ang, p, obs)
+    fin = np.setdiff1d(np.arange(n), bad)
+    assert np.array_equal(got[fin], oracle_logw(orc, om, p[:, fin], ang, obs))
+
+
+@pytest.mark.parametrize("g", [1, 2, 4, 8, 16])
+def test_every_wedge_group_size_gives_the_same_sums(orc, engine_mod, spielberg, spielberg_oracle, g, monkeypatch):
+    """MCL_SWEEP_G (read at mcl_create) sets how many wedges a work item walks, i.e. how many partial-sum arrays the
+    update keeps and how the running sums are carried: the log-weights must not depend on it."""
+    monkeypatch.setenv("MCL_SWEEP_G", str(g))
+    ang = orc.beam_angles(angle_step=3)
+    n = 70000                                                    # 69 units: runs of several units and single ones
+    p = tracking_cloud(np.random.default_rng(5), n)
+    obs = scan1081()[::3].copy()
+    got, _ = sweep_logw(engine_mod, spielberg, ang, p, obs)
+    assert np.array_equal(got, oracle_logw(orc, spielberg_oracle, p, ang, obs))
+
+
+def test_default_kernel_at_size_and_updates_match_cell(orc, engine_mod, spielberg):
+    """AUTO picks k_rays_sweep at 65 536 particles x 1081 beams; ten updates give the same particles, weights and pose as
+    k_rays_cell, bit for bit."""
+    ang = orc.beam_angles(angle_step=1)
+    n = 65536
+    out = {}
+    for name, rk in (("auto", engine_mod.RAYS_AUTO), ("cell", engine_mod.RAYS_CELL)):
+        e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=rk, seed=9)
+        e.init_particles_pose((0.0, 0.0, 0.0), n)
+        for _ in range(10):
+            e.update((0.05, 0.0, 0.01), scan1081())
+        out[name] = (e.ray_kernel_name(), e.get_particles(), e.get_weights(), e.expected_pose())
+        e.close()
+    assert out["auto"][0] == "k_rays_sweep" and out["cell"][0] == "k_rays_cell"
+    for k in (1, 2, 3):
+        assert np.array_equal(out["auto"][k], out["cell"][k])
