@@ -549,10 +549,12 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int max_wg = 2 * (h->num_cu - h->reserved_cus);             // persistent: 2 workgroups per CU
         if (sweep) {
             // k_rays_sweep: a work item is (run of 1024-particle units, G wedges); the G wedges of a group share one
-            // partial-sum array.  G = 4 unless that leaves fewer than four items per workgroup.
+            // partial-sum array.  G = 2 (measured at 4M x 1081, ray kernel / update ms, same device: G = 1 6.50 / 7.87,
+            // 2 6.54 / 7.86, 4 6.69 / 7.97, 8 6.99 / 8.27, 16 7.62 / 8.90: a longer item is a longer tail) unless that
+            // leaves fewer than four items per workgroup.
             const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
-            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : 4;
-            if (sweep_g > mcl::kWedges || (mcl::kWedges % sweep_g) != 0) sweep_g = 4;
+            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : 2;
+            if (sweep_g > mcl::kWedges || (mcl::kWedges % sweep_g) != 0) sweep_g = 2;
             if (h->env_sweep_g <= 0)
                 while (sweep_g > 1 && M * (mcl::kWedges / sweep_g) < 4 * (int64_t)max_wg) sweep_g >>= 1;
             nsl = (int)M;

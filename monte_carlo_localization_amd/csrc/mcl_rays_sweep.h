@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int item_sh;
+    __shared__ unsigned int fixn_sh;                           // entries this workgroup appended to ITS segment of the fix-up list
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long cnt_probe = 0;
@@ -103,6 +104,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const unsigned char *ldsb = lds_raw;
     uint32_t stride_v = (uint32_t)S;
     asm volatile("" : "+v"(stride_v));
+    if (threadIdx.x == 0) fixn_sh = 0u;                        // published by the first barrier of the item loop
+    // the segment belongs to this workgroup alone: the append counter lives in LDS and entries are plain stores (the list
+    // is read by k_rays_fix, a later kernel); the count goes to memory once, at the end
+    unsigned long long *const fix_seg = a.fix_list + (size_t)blockIdx.x * a.fix_cap;
     for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) item_sh = (int)atomicAdd(a.work_counter, 1ull);
@@ -373,9 +378,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
                 }
                 if (amb) {
-                    const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
-                    if (fslot < a.fix_cap)
-                        atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)sl << 16) | (unsigned long long)jcur);
+                    const unsigned int fslot = atomicAdd(&fixn_sh, 1u);
+                    if (fslot < a.fix_cap) fix_seg[fslot] = ((unsigned long long)sl << 16) | (unsigned long long)jcur;
                 }
             }
             acc += lt_pending;
@@ -388,9 +392,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             const int nlist = ambcnt > 2u ? t_done : (int)ambcnt;
             for (int k = 0; k < nlist; ++k) {
                 const int jamb = ambcnt > 2u ? jfirst + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1;
-                const unsigned long long fslot = atomicAdd(&a.fix_count[(size_t)blockIdx.x * 8], 1ull);
-                if (fslot < a.fix_cap)
-                    atomicExch(&a.fix_list[(size_t)blockIdx.x * a.fix_cap + fslot], ((unsigned long long)sl << 16) | (unsigned long long)(jamb & 0xFFFF));
+                const unsigned int fslot = atomicAdd(&fixn_sh, 1u);
+                if (fslot < a.fix_cap) fix_seg[fslot] = ((unsigned long long)sl << 16) | (unsigned long long)(jamb & 0xFFFF);
             }
             if (ambcnt > 2u) acc_fast = 0.0;
         }
@@ -398,6 +401,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     }
     }   // wedges of the group
     }   // work items
+    __syncthreads();
+    if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = fixn_sh;      // may exceed fix_cap: k_fix_overflow reports it
     if (COUNT && a.counters) {
         cnt_probe = wave_sum_u64(cnt_probe);
         if (lane == 0 && cnt_probe) atomicAdd(&a.counters[2], cnt_probe);
