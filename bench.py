@@ -6,14 +6,21 @@
 One "step" = one full update (resample -> motion -> ray cast + likelihood -> normalise -> expected
 pose) of the 4M-particle x 1081-beam Spielberg workload (BASELINE.json configs[2]; SURVEY.md §8(d)
 inputs), per GPU.  N > 1 is launched by torch.distributed.run, one rank per GPU; particles are
-sharded 4M per GPU (weak scaling, configs[4] at N=8) with RCCL all-gather / all-reduce per update
+sharded 4M per GPU (weak scaling, configs[4] at N=8) with RCCL per update: all-gather of the
+fixed-point weights, all-to-all fetch of the DISTINCT selected parents, two small all-reduces
 (monte_carlo_localization_amd/dist.py).  Inputs are resident in HBM before the timed region; the
 per-update host->device traffic is the 1081-float scan and the 3-double action only.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_rays) against the HBM peak
-with the ALGORITHMIC bytes of SURVEY.md §8(d): per ray S-bar grid probes of 1 B (as the reference
-reads them, cpp:642) + one 4 B table entry (cpp:576), per particle 24 B state in + 8 B log-weight
-out; its duration is measured inside the engine with HIP events on the engine's own stream.
+Rank 0 prints ONE JSON line.
+
+`roofline` names the bound that applies to the dominant kernel (k_rays_sweep): VALU issue.  Its inputs are the
+kernel's VALU instruction count (rocprofv3 PMC), the cycles one wave64 instruction of ITS instruction mix occupies a
+SIMD (tools/ubench/valu_rates.hip, measured on the box), the clock the kernel held (GRBM_GUI_ACTIVE) -- all read from
+profiles/r02_roofline_inputs.json, which tools/roofline_inputs.py writes from the committed rocprofv3 / ubench
+outputs -- and the kernel duration measured live with HIP events on the engine's stream.  `roofline.algorithmic`
+keeps SURVEY.md §8(d)'s figure (per ray S-bar one-byte grid probes as the reference reads them, cpp:642, + one 4-byte
+table entry, cpp:576; per particle 32 B) priced against the HBM peak: it exceeds 1 because the kernel examines a
+tenth of those samples (same results) and is NOT a bound.
 `cpu_baseline` times the CPU oracle's as-reference step (same materialised arrays and the same
 `omp parallel for schedule(dynamic)` ray loop as cpp:593) on this box's host cores.
 """
@@ -32,13 +39,23 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_PER_GPU = 4 * 1024 * 1024
 ACTION = (0.05, 0.0, 0.01)
 TRUE_POSE = (0.0, 0.0, 0.0)
+ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")
+
+
+def mean_probes_per_ray(m, ang, scan, p):
+    """S-bar of SURVEY.md §8(d): mean number of grid samples the reference's fixed-step march (cpp:611-650) reads per
+    ray, measured by the oracle on the given particles (3 x n, column-major)."""
+    from oracle import oracle as orc
+    om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    _, _, probes = orc.eng_log_weights(om, np.ascontiguousarray(p), ang, orc.obs_index(scan, om), L)
+    return probes / float(p.shape[1] * ang.size)
 
 
 def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
     """Oracle (kind 'port'): BASELINE config #1 = 4000 particles x 1081 beams, all host cores,
     plus the 1-thread figure because the reference's chunk-1 dynamic schedule does not scale
-    (SURVEY D11).  Also returns S-bar, the mean number of grid probes per ray of the fixed-step
-    march on this input."""
+    (SURVEY D11)."""
     from oracle import oracle as orc
     om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
     n = 4000
@@ -62,14 +79,39 @@ def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
                 break
         out[label] = (n * ang.size / float(np.median(times)), len(times))
     orc.omp_threads(cores)
-    L = orc.eng_log_table(T)
-    _, _, probes = orc.eng_log_weights(om, p, ang, orc.obs_index(scan, om), L)
-    sbar = probes / float(n * ang.size)
-    base = {"value": out["all"][0], "unit": "particle*beam/s", "cores": cores, "kind": "port",
+    return {"value": out["all"][0], "unit": "particle*beam/s", "cores": cores, "kind": "port",
             "sample": f"{out['all'][1]} updates of 4000 particles x {ang.size} beams (BASELINE config #1), "
                       f"Spielberg_map, tracking-regime cloud, omp schedule(dynamic) as cpp:593",
             "single_thread_value": out["one"][0], "three_thread_value": out["three"][0]}
-    return base, sbar
+
+
+def roofline_block(kernel_name, k_ms, n, B, sbar):
+    """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time."""
+    alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per launch (one GPU's shard), SURVEY §8(d)
+    alg = {"bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar, "achieved": alg_bytes / (k_ms * 1e-3) / 1e9,
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "SURVEY 8(d) algorithmic bytes / kernel time / 8 TB/s: not a bound (the kernel skips ~90 % of the priced samples)"}
+    block = {"bound": "valu", "kernel": kernel_name, "kernel_ms": k_ms, "algorithmic": alg, "traffic": None}
+    inp = None
+    if os.path.exists(ROOFLINE_INPUTS):
+        try:
+            inp = json.load(open(ROOFLINE_INPUTS))
+        except Exception:
+            inp = None
+    if inp and inp.get("kernel") == kernel_name and inp.get("particles") == n and inp.get("beams") == B:
+        insts, cpi, simds, ghz = inp["valu_insts_per_launch"], inp["cycles_per_valu_inst"], inp["simds"], inp["clock_ghz"]
+        floor_ms = insts * cpi / (simds * ghz * 1e6)
+        # achieved / peak in VALU issue cycles: what the launch needed vs what 1024 SIMDs offer in the measured time
+        block.update({"achieved": insts * cpi / (k_ms * 1e-3) / 1e9, "peak": simds * ghz, "unit": "G SIMD-cycles/s",
+                      "frac": floor_ms / k_ms,
+                      "valu": {"insts_per_launch": insts, "cycles_per_inst": cpi, "simds": simds, "clock_ghz": ghz,
+                               "floor_ms": floor_ms, "frac": floor_ms / k_ms, "source": "profiles/r02_roofline_inputs.json"},
+                      "traffic": inp.get("hbm_bytes_per_launch"),
+                      "traffic_source": inp.get("hbm_bytes_source")})
+    else:
+        block.update({"achieved": None, "peak": None, "unit": "G SIMD-cycles/s", "frac": None,
+                      "note": "no profile inputs for this kernel / size under profiles/: VALU bound not priced"})
+    return block
 
 
 def main():
@@ -83,7 +125,7 @@ def main():
     ap.add_argument("--regime", choices=["tracking", "global"], default="tracking")
     ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: gather the particle columns synchronously")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: gather the weights synchronously")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the sharded (torch.distributed/RCCL) path even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -133,6 +175,7 @@ def main():
         scan = synth.scan_from_pose(e, m, ang, true_pose)
     rng = np.random.default_rng(42 + rank)
     p = synth.tracking_cloud(rng, n, true_pose) if args.regime == "tracking" else synth.global_cloud(rng, m, n)
+    sample_first = np.ascontiguousarray(p[:, :4000])           # the first update traces the spread cloud
     e.set_particles(p, np.full(n, 1.0 / (n * world)))
     del p
 
@@ -152,9 +195,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # warm-up: the FIRST update works on the spread cloud the workload string names; resampling then collapses the set to
+    # motion-noise width around a few parents, which is the state every timed update sees.  Both are reported.
+    first_ms, first_ray_ms = None, None
+    for k in range(args.warmup):
+        fence()
+        t0 = time.perf_counter()
         step()
-    ray_ms, probes = [], []
+        fence()
+        if k == 0:
+            first_ms, first_ray_ms = (time.perf_counter() - t0) * 1e3, e.ray_kernel_ms()
+    ray_ms = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -172,42 +223,45 @@ def main():
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
         value = n * world * B / (elapsed / args.steps)
-        base, sbar = (None, 43.4)
+        base, sbar_first, sbar_timed = None, None, None
         if world == 1 and not args.no_cpu_baseline:
-            base, sbar = cpu_baseline(m, ang, scan, true_pose)
+            base = cpu_baseline(m, ang, scan, true_pose)
+        try:
+            # S-bar on a sample of the particles actually timed (after the last update) and on the spread cloud
+            pt = e.get_particles()
+            pick = np.random.default_rng(7).choice(n, size=min(4000, n), replace=False)
+            sbar_timed = mean_probes_per_ray(m, ang, scan, pt[:, pick])
+            sbar_first = mean_probes_per_ray(m, ang, scan, sample_first)
+            del pt
+        except Exception:
+            sbar_timed = sbar_first = None       # no oracle on this box: the algorithmic figure falls back to the survey's value
         k_ms = float(np.mean(ray_ms))
-        alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per k_rays launch (one GPU's shard)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        roof = roofline_block(e.ray_kernel_name(), k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4)
+        roof["algorithmic"]["s_bar_first_update"] = sbar_first
         line = {
-            "metric": "MCL updates/sec (particle*beam/s) at 4M particles x 1081 beams",
+            "metric": "MCL updates/sec (particle*beam/s)",
             "value": value, "unit": "particle*beam/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n} particles/GPU x {B} beams, "
                                    + ("Spielberg_map (2000x2000 @ 0.05796), " if args.map == "spielberg"
                                       else "SYNTHETIC levine stand-in (2049x2049 @ 0.05), ")
-                                   + (f"tracking-regime cloud N({true_pose},(0.5 m,0.5 m,0.4 rad)), " if args.regime == "tracking"
-                                      else "global-regime cloud (uniform over free cells), ")
+                                   + (f"initial cloud N({true_pose},(0.5 m,0.5 m,0.4 rad)) (tracking regime), " if args.regime == "tracking"
+                                      else "initial cloud uniform over the free cells (global regime), ")
                                    + f"action {ACTION}, "
-                                   f"stock sensor/motion params, {args.resample} resampling, Philox seed 42",
+                                   f"stock sensor/motion params, {args.resample} resampling, Philox seed 42; the timed updates "
+                                   f"follow {args.warmup} warm-up updates (the particle set has resampled to motion-noise width)",
                        "particles_total": n * world, "beams": B,
                        "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": e.ray_kernel_name(),
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar,
-                         "note": "algorithmic (effective) bytes per SURVEY 8(d); real HBM traffic is far lower because "
-                                 "the grid window lives in LDS and the kernel skips empty space; it is VALU/LDS-bound"},
+            "first_update_ms": first_ms, "first_update_ray_kernel_ms": first_ray_ms,
+            "steady_state_ms": ms,
+            "roofline": roof,
             "cpu_baseline": base,
             "pose": [float(v) for v in pose],
             "counters_last_update": counters,
         }
+        if use_dist:
+            line["exchange_bytes_per_update_per_gpu"] = sf.exchange_bytes
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -242,6 +242,16 @@ int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, 
 int mcl_export_records(mcl_engine_t *h, void *d_records);
 int mcl_stage_resample_records(mcl_engine_t *h, const void *d_records, const uint64_t *d_cdf, int64_t n_parents,
                                uint64_t q_total, int64_t child_first, int64_t n_children_total, const double action[3]);
+/* The exchange without wholesale gathers: only the fixed-point weights (8 B per particle) are gathered; each rank then
+ * asks which parents its children selected (mcl_stage_resample_indices: global parent index per local child, written to
+ * a caller-owned DEVICE buffer of N int32, engine state untouched), fetches the distinct ones from their owners with
+ * whatever transport the host has (torch.distributed all-to-all in dist.py), and hands the compact record table plus the
+ * per-child position in it to mcl_stage_motion_records, which gathers, applies the motion model and makes the children
+ * current.  Same random streams as the fused call: bit-identical children. */
+int mcl_stage_resample_indices(mcl_engine_t *h, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total, int64_t child_first,
+                               int64_t n_children_total, int32_t *d_parent_idx);
+int mcl_stage_motion_records(mcl_engine_t *h, const void *d_records, int64_t n_records, const int32_t *d_record_of_child,
+                             int64_t child_first, int64_t n_children_total, const double action[3]);
 int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams);
 /* Leave n_cus compute units out of k_rays_quad's persistent grid (it otherwise occupies every CU for the
  * whole kernel, which would serialise a collective launched beside it). */
@@ -253,6 +263,38 @@ int mcl_stage_weights(mcl_engine_t *h, double global_max_logw);
 int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5]);
 /* Inclusive scan of q (uint64) on the engine's stream: cdf[i] = offset + q[0] + ... + q[i]. */
 int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset);
+
+/* ---- several GPUs behind one handle (SURVEY.md §8(b).1 "device list", §8(e)) -------------------------------------
+ * The reference is ONE process (main, cpp:1019-1025; MCL called from timer_update, cpp:777): a group owns one engine per
+ * listed device, shards the particle set contiguously (n_total / n_devices each; cfg->max_particles is PER DEVICE,
+ * cfg->device is ignored) and mirrors the single-engine entry points the host patch uses.  Per update a device receives
+ * the other shards' fixed-point weights (8 B per particle, peer copies), scans the same exact global CDF, draws its own
+ * children and reads each selected parent where it lives (peer pointer over xGMI); maxima and sums are combined on the
+ * host.  Results are bit-identical to a single engine holding all particles.  The devices must have peer access to each
+ * other; weight_mode LOG and resample_neff_permille 0 only. */
+typedef struct mcl_group mcl_group_t;
+int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_devices, mcl_group_t **out);
+void mcl_group_destroy(mcl_group_t *g);
+const char *mcl_group_last_error(const mcl_group_t *g);
+int32_t mcl_group_size(const mcl_group_t *g);
+int mcl_group_engine(mcl_group_t *g, int32_t i, mcl_engine_t **out);           /* the i-th shard's engine (diagnostics) */
+int mcl_group_set_map(mcl_group_t *g, const int8_t *data, uint32_t width, uint32_t height, float resolution, double origin_x,
+                      double origin_y);
+int mcl_group_set_beam_angles(mcl_group_t *g, const float *angles, int32_t n_beams);
+/* xyz: n_total x 3 column-major, weights: n_total (all shards must see the same weight scale: uniform weights, as both
+ * of the reference's initialisers produce, cpp:388 / 443); n_total a multiple of the device count */
+int mcl_group_set_particles(mcl_group_t *g, const double *xyz, const double *weights, int64_t n_total);
+int mcl_group_init_particles_pose(mcl_group_t *g, const double pose[3], int64_t n_total);
+int mcl_group_init_global(mcl_group_t *g, int64_t n_total);
+int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, int32_t n_beams);
+int mcl_group_expected_pose(mcl_group_t *g, double out[3]);
+int mcl_group_get_particles(mcl_group_t *g, double *xyz, int64_t n_total);
+int mcl_group_get_weights(mcl_group_t *g, double *weights, int64_t n_total);
+int mcl_group_get_resample_indices(mcl_group_t *g, int32_t *idx, int64_t n_total);   /* global parent indices */
+int mcl_group_get_stage_timings(const mcl_group_t *g, double ms[6]);           /* per stage: the slowest device */
+/* bytes the last update moved between devices: [0] fixed-point weights received PER DEVICE, [1] parent records read from
+ * peers by ALL devices (children with a remote parent x 32 B: an upper bound, a shared parent is cached after its first fetch) */
+int mcl_group_exchange_bytes(const mcl_group_t *g, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

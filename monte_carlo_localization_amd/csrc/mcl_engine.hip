@@ -1590,28 +1590,50 @@ int mcl_get_host_scalars(const mcl_engine_t *h, double out[8])
     return MCL_OK;
 }
 
-static int stage_resample_impl(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const void *d_records,
-                               const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total,
-                               const double action[3])
+// Where the parents of a staged resample come from.
+struct ParentSource {
+    const double *px = nullptr, *py = nullptr, *pth = nullptr;     // gathered columns, n_parents entries each
+    const void *records = nullptr;                                  // gathered (or compacted) packed records
+    const double4 *rank_records[mcl::kMaxShards] = {};              // one record array per shard (peer pointers, same process)
+    int64_t n_per_rank = 0;
+    int self_rank = 0;
+    unsigned long long *remote_count = nullptr;
+    const int32_t *idx_in = nullptr;                                // parents decided by an earlier index-only pass (into `records`)
+    int32_t *idx_only_out = nullptr;                                // index-only pass: parents go here, nothing else happens
+};
+
+// Launches the staged resample (+ motion) on the engine's stream; no synchronisation.  An index-only pass leaves the
+// engine untouched; otherwise the children land in the other particle buffer, which becomes current.
+static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
+                                 int64_t child_first, int64_t n_children_total, const double action[3])
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
-    if ((!d_records && (!d_px || !d_py || !d_pth)) || !d_cdf || !action || n_parents <= 0 || n_parents >= MCL_MAX_TOTAL_PARTICLES ||
+    const bool have_parents = src.records || src.n_per_rank > 0 || (src.px && src.py && src.pth) || src.idx_only_out;
+    if (!have_parents || (!d_cdf && !src.idx_in) || (!action && !src.idx_only_out) || n_parents <= 0 || n_parents >= MCL_MAX_TOTAL_PARTICLES ||
         n_children_total >= MCL_MAX_TOTAL_PARTICLES)
         return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments (totals must stay below 2^27)");
+    if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
+        return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t n = h->N;
-    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
-    HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
+    const bool index_only = src.idx_only_out != nullptr;
+    if (!index_only) {
+        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
+    }
     const int nx = h->cur ^ 1;
     mcl::ResampleArgs a{};
-    a.px = d_px; a.py = d_py; a.pth = d_pth; a.cdf = d_cdf; a.n_parents = n_parents; a.q_total = q_total;
-    a.ppack = reinterpret_cast<const double4 *>(d_records);
+    a.px = src.px; a.py = src.py; a.pth = src.pth; a.cdf = d_cdf; a.n_parents = n_parents; a.q_total = q_total;
+    a.ppack = reinterpret_cast<const double4 *>(src.records);
+    for (int r = 0; r < mcl::kMaxShards; ++r) a.ppack_rank[r] = src.rank_records[r];
+    a.n_per_rank = src.n_per_rank; a.self_rank = src.self_rank; a.remote_count = src.remote_count;
+    a.idx_in = src.idx_in; a.index_only = index_only ? 1 : 0;
     a.cpack = h->d_pack[nx];
-    a.tile_excl = (h->blocktot_for == d_cdf && h->blocktot_n == n_parents) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
+    a.tile_excl = (d_cdf && h->blocktot_for == d_cdf && h->blocktot_n == n_parents) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
     a.leaders = a.tile_excl ? h->d_leaders : nullptr;
     a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
-    a.idx_out = h->d_idx;
+    a.idx_out = src.idx_in ? nullptr : h->d_idx;       // the global parents of an earlier index-only pass stay in d_idx
     a.n_children = n; a.child_first = child_first; a.n_children_total = n_children_total;
     a.mode = h->cfg.resample_mode;
     a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
@@ -1625,34 +1647,67 @@ static int stage_resample_impl(mcl_engine_t *h, const double *d_px, const double
         }
         a.k0 = c0;
     }
-    motion_scalars(action, a.dt, a.v, a.w);
+    if (action) motion_scalars(action, a.dt, a.v, a.w);
     a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
     a.do_resample = 1; a.do_motion = 1;
     hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
+    if (index_only) {
+        HIPCHK(h, hipMemcpyAsync(src.idx_only_out, h->d_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        h->have_idx = true;
+        return MCL_OK;
+    }
     h->cur = nx;
     h->pack_valid[nx] = true;
     h->have_idx = true;
     h->have_logw = false;
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));           // the children are final: the host may export / gather them now
     h->update_idx++;
+    return MCL_OK;
+}
+
+static int stage_resample_sync(mcl_engine_t *h, const ParentSource &src, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
+                               int64_t child_first, int64_t n_children_total, const double action[3])
+{
+    int rc = stage_resample_launch(h, src, d_cdf, n_parents, q_total, child_first, n_children_total, action);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));           // the children (or the indices) are final: the host may export / gather them now
     return MCL_OK;
 }
 
 int mcl_stage_resample(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
                        int64_t n_parents, uint64_t q_total, int64_t child_first, int64_t n_children_total, const double action[3])
 {
-    return stage_resample_impl(h, d_px, d_py, d_pth, nullptr, d_cdf, n_parents, q_total, child_first, n_children_total, action);
+    ParentSource src; src.px = d_px; src.py = d_py; src.pth = d_pth;
+    if (!d_px || !d_py || !d_pth) return h ? fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments") : MCL_ERR_INVALID_ARG;
+    return stage_resample_sync(h, src, d_cdf, n_parents, q_total, child_first, n_children_total, action);
 }
 
 int mcl_stage_resample_records(mcl_engine_t *h, const void *d_records, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
                                int64_t child_first, int64_t n_children_total, const double action[3])
 {
-    return stage_resample_impl(h, nullptr, nullptr, nullptr, d_records, d_cdf, n_parents, q_total, child_first, n_children_total, action);
+    ParentSource src; src.records = d_records;
+    if (!d_records) return h ? fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments") : MCL_ERR_INVALID_ARG;
+    return stage_resample_sync(h, src, d_cdf, n_parents, q_total, child_first, n_children_total, action);
 }
 
-int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
+int mcl_stage_resample_indices(mcl_engine_t *h, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total, int64_t child_first,
+                               int64_t n_children_total, int32_t *d_parent_idx)
+{
+    ParentSource src; src.idx_only_out = d_parent_idx;
+    if (!d_parent_idx || !d_cdf) return h ? fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample_indices arguments") : MCL_ERR_INVALID_ARG;
+    return stage_resample_sync(h, src, d_cdf, n_parents, q_total, child_first, n_children_total, nullptr);
+}
+
+int mcl_stage_motion_records(mcl_engine_t *h, const void *d_records, int64_t n_records, const int32_t *d_record_of_child, int64_t child_first,
+                             int64_t n_children_total, const double action[3])
+{
+    ParentSource src; src.records = d_records; src.idx_in = d_record_of_child;
+    if (!d_records || !d_record_of_child || n_records <= 0) return h ? fail(h, MCL_ERR_INVALID_ARG, "bad stage_motion_records arguments") : MCL_ERR_INVALID_ARG;
+    return stage_resample_sync(h, src, nullptr, n_records, 0, child_first, n_children_total, action);
+}
+
+static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams, bool force_skip)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
@@ -1660,25 +1715,38 @@ int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t n = h->N;
     const int c = h->cur;
-    int rc = prepare_observation(h, obs, 1);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, attempt == 1);
+    int rc = MCL_OK;
+    if (!force_skip) {
+        rc = prepare_observation(h, obs, 1);
         if (rc) return rc;
-        HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
-        if (!h->max_partials_ready)
-            hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
-        hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
-        h->max_partials_ready = false;
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
+    } else {
+        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    }
+    rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, force_skip);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    if (!h->max_partials_ready)
+        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
+    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+    h->max_partials_ready = false;
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
+    return MCL_OK;
+}
+
+static int stage_rays_finish(mcl_engine_t *h, const float *obs, int32_t n_beams)
+{
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         std::memcpy(h->h_scalars, h->h_result, 8 * sizeof(double));       // [0] = local max log-weight (mcl_get_host_scalars)
         std::memcpy(h->h_counters, h->h_result + 8, 4 * sizeof(unsigned long long));
         h->h_fix_count = h->h_result[12];
-        if (!(h->last_quad && h->h_fix_count != 0)) break;        // work-list overflow: once more with k_rays_skip (see do_update)
-        HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+        if (!(h->last_quad && h->h_fix_count != 0) || attempt == 1) break;
+        // work-list overflow (only with debug_force_exact at large sizes): once more with the self-contained k_rays_skip
+        int rc = stage_rays_launch(h, obs, n_beams, true);
+        if (rc) return rc;
     }
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
@@ -1688,6 +1756,13 @@ int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
     h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
     h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
     return MCL_OK;
+}
+
+int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams)
+{
+    int rc = stage_rays_launch(h, obs, n_beams, false);
+    if (rc) return rc;
+    return stage_rays_finish(h, obs, n_beams);
 }
 
 int mcl_stage_propagate(mcl_engine_t *h, const double *d_px, const double *d_py, const double *d_pth, const uint64_t *d_cdf,
@@ -1708,22 +1783,41 @@ int mcl_set_reserved_cus(mcl_engine_t *h, int32_t n_cus)
     return MCL_OK;
 }
 
-int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
+static int stage_weights_launch(mcl_engine_t *h, double global_max_logw)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!h->have_logw) return MCL_ERR_NOT_READY;
     if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
         return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipMemcpyAsync(h->d_scalars, &global_max_logw, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->h_result[15] = 0;
+    std::memcpy(&h->h_result[15], &global_max_logw, sizeof(double));   // pinned: stays valid until the copy has run
+    HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[15], sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = weight_stats(h, true, h->d_scalars);
     if (rc) return rc;
     h->carry_pending = false;
     // the shard's own CDF follows its new weights: mcl_sample_particles (visualize) and a later plain mcl_update search it
     rc = scan_weights(h, h->d_q, h->d_cdf, h->N, 0, nullptr);
     if (rc) return rc;
-    return fetch_scalars(h);
+    HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
+    return MCL_OK;
+}
+
+static int stage_weights_finish(mcl_engine_t *h)
+{
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unpack_result(h);
+    h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
+    return MCL_OK;
+}
+
+int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
+{
+    int rc = stage_weights_launch(h, global_max_logw);
+    if (rc) return rc;
+    return stage_weights_finish(h);
 }
 
 int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5])
@@ -1747,6 +1841,349 @@ int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int6
     int rc = scan_weights(h, d_q, d_cdf, n, offset, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Several GPUs driven by ONE host process (the reference is a single ROS 2 process, cpp:1019-1025): a group owns one engine
+// per device, shards the particles contiguously and runs every update phase on all devices before the next phase starts,
+// so the devices work concurrently although one host thread issues the calls.  Per update and device:
+//   * the other shards' fixed-point weights arrive by peer copies (8 B per particle of the other shards), every device
+//     scans the same exact global CDF and draws its own children;
+//   * a child's parent record is read where it lives (peer pointer): only SELECTED parents cross a link, no record is
+//     gathered wholesale;
+//   * max log-weight and the seven sums are combined on the host (a few doubles per device).
+// Results are bit-identical to one engine holding all particles (exact integer CDF, exact fp64 log-weight sums, Philox
+// keyed by the global particle index), which tests/test_gpu_group.py checks with two engines on one device.
+// ---------------------------------------------------------------------------------------------
+struct mcl_group {
+    std::vector<mcl_engine *> eng;
+    std::vector<uint64_t *> d_qall, d_cdfall;      // per device: all shards' weights and their global CDF
+    std::vector<unsigned long long *> d_remote;    // per device: children whose parent was fetched from a peer (last update)
+    int64_t n_per = 0, n_total = 0;
+    uint64_t q_total = 0;
+    bool have_q_total = false;
+    double sums[5] = {0, 0, 0, 0, 0};
+    double timings[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t bytes_weights = 0, bytes_parents = 0;
+    std::string err;
+};
+
+static int gfail(mcl_group *g, int rc, const std::string &msg)
+{
+    if (g) g->err = msg;
+    return rc;
+}
+
+static int group_sync_q_total(mcl_group *g)
+{
+    // after set_particles / init: every shard has its local fixed-point total on the host (fetch_scalars)
+    uint64_t t = 0;
+    for (auto *e : g->eng) t += e->q_total;
+    g->q_total = t;
+    g->have_q_total = true;
+    double gs[5] = {0, 0, 0, 0, 0};
+    for (auto *e : g->eng)
+        for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];
+    for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
+    for (auto *e : g->eng) mcl_stage_finish(e, gs);
+    return MCL_OK;
+}
+
+const char *mcl_group_last_error(const mcl_group_t *g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+
+void mcl_group_destroy(mcl_group_t *g)
+{
+    if (!g) return;
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        if (!g->eng[d]) continue;
+        (void)hipSetDevice(g->eng[d]->cfg.device);
+        if (d < g->d_qall.size() && g->d_qall[d]) (void)hipFree(g->d_qall[d]);
+        if (d < g->d_cdfall.size() && g->d_cdfall[d]) (void)hipFree(g->d_cdfall[d]);
+        if (d < g->d_remote.size() && g->d_remote[d]) (void)hipFree(g->d_remote[d]);
+        mcl_destroy(g->eng[d]);
+    }
+    delete g;
+}
+
+int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_devices, mcl_group_t **out)
+{
+    g_create_error.clear();
+    if (!cfg || !devices || !out || n_devices <= 0 || n_devices > mcl::kMaxShards) { g_create_error = "bad group arguments (1..16 devices)"; return MCL_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (cfg->weight_mode != MCL_WEIGHT_LOG || cfg->resample_neff_permille != 0) {
+        g_create_error = "a device group needs weight_mode LOG and resample_neff_permille 0";
+        return MCL_ERR_UNSUPPORTED;
+    }
+    if ((int64_t)cfg->max_particles * n_devices >= MCL_MAX_TOTAL_PARTICLES) { g_create_error = "particle total must stay below 2^27"; return MCL_ERR_INVALID_ARG; }
+    mcl_group *g = new mcl_group();
+    for (int d = 0; d < n_devices; ++d) {
+        mcl_config_t c = *cfg;
+        c.device = devices[d];
+        mcl_engine_t *e = nullptr;
+        const int rc = mcl_create(&c, &e);
+        if (rc != MCL_OK) { mcl_group_destroy(g); return rc; }
+        g->eng.push_back(e);
+    }
+    g->d_qall.assign(n_devices, nullptr); g->d_cdfall.assign(n_devices, nullptr); g->d_remote.assign(n_devices, nullptr);
+    const size_t cap_total = (size_t)cfg->max_particles * n_devices;
+    for (int d = 0; d < n_devices; ++d) {
+        if (hipSetDevice(devices[d]) != hipSuccess || hipMalloc(&g->d_qall[d], cap_total * 8) != hipSuccess ||
+            hipMalloc(&g->d_cdfall[d], cap_total * 8) != hipSuccess || hipMalloc(&g->d_remote[d], 8) != hipSuccess) {
+            g_create_error = "group buffers: hipMalloc failed";
+            mcl_group_destroy(g);
+            return MCL_ERR_HIP;
+        }
+        // parents are read where they live: peer access to every other device of the group
+        for (int o = 0; o < n_devices; ++o) {
+            if (devices[o] == devices[d]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[d], devices[o]) != hipSuccess || !can) {
+                g_create_error = "devices of a group must have peer access to each other";
+                mcl_group_destroy(g);
+                return MCL_ERR_UNSUPPORTED;
+            }
+            const hipError_t pe = hipDeviceEnablePeerAccess(devices[o], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { g_create_error = "hipDeviceEnablePeerAccess failed"; mcl_group_destroy(g); return MCL_ERR_HIP; }
+            (void)hipGetLastError();
+        }
+    }
+    *out = g;
+    return MCL_OK;
+}
+
+int32_t mcl_group_size(const mcl_group_t *g) { return g ? (int32_t)g->eng.size() : 0; }
+
+int mcl_group_engine(mcl_group_t *g, int32_t i, mcl_engine_t **out)
+{
+    if (!g || !out || i < 0 || i >= (int32_t)g->eng.size()) return MCL_ERR_INVALID_ARG;
+    *out = g->eng[i];
+    return MCL_OK;
+}
+
+int mcl_group_set_map(mcl_group_t *g, const int8_t *data, uint32_t width, uint32_t height, float resolution, double origin_x, double origin_y)
+{
+    if (!g) return MCL_ERR_INVALID_ARG;
+    for (auto *e : g->eng) {
+        const int rc = mcl_set_map(e, data, width, height, resolution, origin_x, origin_y);
+        if (rc) return gfail(g, rc, e->err);
+    }
+    return MCL_OK;
+}
+
+int mcl_group_set_beam_angles(mcl_group_t *g, const float *angles, int32_t n_beams)
+{
+    if (!g) return MCL_ERR_INVALID_ARG;
+    for (auto *e : g->eng) {
+        const int rc = mcl_set_beam_angles(e, angles, n_beams);
+        if (rc) return gfail(g, rc, e->err);
+    }
+    return MCL_OK;
+}
+
+static int group_check_total(mcl_group *g, int64_t n_total)
+{
+    const int64_t G = (int64_t)g->eng.size();
+    if (n_total <= 0 || n_total % G != 0 || n_total / G > g->eng[0]->cap)
+        return gfail(g, MCL_ERR_INVALID_ARG, "the particle total must be a multiple of the device count and fit max_particles per device");
+    g->n_total = n_total; g->n_per = n_total / G;
+    return MCL_OK;
+}
+
+int mcl_group_set_particles(mcl_group_t *g, const double *xyz, const double *weights, int64_t n_total)
+{
+    if (!g || !xyz || !weights) return MCL_ERR_INVALID_ARG;
+    int rc = group_check_total(g, n_total);
+    if (rc) return rc;
+    // all shards must quantise their weights against the same scale: the reference's initialisers (cpp:388, 443) and
+    // every caller of this path hand over uniform weights; the global maximum is what a single engine would use
+    std::vector<double> shard((size_t)g->n_per * 3);
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        for (int c = 0; c < 3; ++c)
+            std::memcpy(shard.data() + (size_t)c * g->n_per, xyz + (size_t)c * n_total + d * (size_t)g->n_per, (size_t)g->n_per * 8);
+        rc = mcl_set_particles(g->eng[d], shard.data(), weights + d * (size_t)g->n_per, g->n_per);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    return group_sync_q_total(g);
+}
+
+int mcl_group_init_particles_pose(mcl_group_t *g, const double pose[3], int64_t n_total)
+{
+    if (!g || !pose) return MCL_ERR_INVALID_ARG;
+    int rc = group_check_total(g, n_total);
+    if (rc) return rc;
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        rc = mcl_init_particles_pose(g->eng[d], pose, g->n_per, (int64_t)d * g->n_per, n_total);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    return group_sync_q_total(g);
+}
+
+int mcl_group_init_global(mcl_group_t *g, int64_t n_total)
+{
+    if (!g) return MCL_ERR_INVALID_ARG;
+    int rc = group_check_total(g, n_total);
+    if (rc) return rc;
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        rc = mcl_init_global(g->eng[d], g->n_per, (int64_t)d * g->n_per, n_total);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    return group_sync_q_total(g);
+}
+
+#define GHIP(g, call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return gfail(g, MCL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, int32_t n_beams)
+{
+    if (!g || !action || !obs) return MCL_ERR_INVALID_ARG;
+    if (g->n_per <= 0 || !g->have_q_total) return gfail(g, MCL_ERR_NOT_READY, "particles not set");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int G = (int)g->eng.size();
+    const int64_t n = g->n_per, nt = g->n_total;
+    // phase 1: weights of every shard to every device (peer copies on the destination's stream), exact global CDF,
+    // children drawn from it with the parents read in place
+    for (int d = 0; d < G; ++d) {
+        mcl_engine *e = g->eng[d];
+        GHIP(g, hipSetDevice(e->cfg.device));
+        for (int s = 0; s < G; ++s)
+            GHIP(g, hipMemcpyPeerAsync(g->d_qall[d] + (size_t)s * n, e->cfg.device, g->eng[s]->d_q, g->eng[s]->cfg.device, (size_t)n * 8, e->stream));
+        GHIP(g, hipMemsetAsync(g->d_remote[d], 0, 8, e->stream));
+        if (!e->pack_valid[e->cur]) {      // first update after set_particles / init: the records do not exist yet
+            hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->d_x[e->cur], e->d_y[e->cur],
+                               e->d_th[e->cur], n, e->d_pack[e->cur]);
+            e->pack_valid[e->cur] = true;
+        }
+    }
+    for (int d = 0; d < G; ++d) {          // the records of every shard exist before any device reads them
+        GHIP(g, hipSetDevice(g->eng[d]->cfg.device));
+        GHIP(g, hipStreamSynchronize(g->eng[d]->stream));
+    }
+    const double4 *parents[mcl::kMaxShards] = {};      // the launch below flips an engine's current buffer: take the pointers first
+    for (int s = 0; s < G; ++s) parents[s] = g->eng[s]->d_pack[g->eng[s]->cur];
+    for (int d = 0; d < G; ++d) {
+        mcl_engine *e = g->eng[d];
+        GHIP(g, hipSetDevice(e->cfg.device));
+        if ((size_t)nt / mcl::kScanTile + 2 > e->blocktot_capacity) {
+            dfree(e->d_blocktot);
+            GHIP(g, hipMalloc(&e->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8));
+            e->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;
+        }
+        int rc = scan_weights(e, g->d_qall[d], g->d_cdfall[d], nt, 0, nullptr);
+        if (rc) return gfail(g, rc, e->err);
+        ParentSource src;
+        for (int s = 0; s < G; ++s) src.rank_records[s] = parents[s];
+        src.n_per_rank = n; src.self_rank = d; src.remote_count = g->d_remote[d];
+        rc = stage_resample_launch(e, src, g->d_cdfall[d], nt, g->q_total, (int64_t)d * n, nt, action);
+        if (rc) return gfail(g, rc, e->err);
+    }
+    for (int d = 0; d < G; ++d) {          // children final everywhere: nobody reads the old buffers any more
+        GHIP(g, hipSetDevice(g->eng[d]->cfg.device));
+        GHIP(g, hipStreamSynchronize(g->eng[d]->stream));
+    }
+    // phase 2: rays + likelihood on every device, then the global maximum
+    for (int d = 0; d < G; ++d) {
+        const int rc = stage_rays_launch(g->eng[d], obs, n_beams, false);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    double gmax = -INFINITY;
+    for (int d = 0; d < G; ++d) {
+        const int rc = stage_rays_finish(g->eng[d], obs, n_beams);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+        gmax = std::max(gmax, g->eng[d]->h_scalars[0]);
+    }
+    // phase 3: weights against the global maximum, sums
+    for (int d = 0; d < G; ++d) {
+        const int rc = stage_weights_launch(g->eng[d], gmax);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    double gs[5] = {0, 0, 0, 0, 0};
+    uint64_t qt = 0;
+    unsigned long long remote = 0;
+    for (int d = 0; d < G; ++d) {
+        mcl_engine *e = g->eng[d];
+        const int rc = stage_weights_finish(e);
+        if (rc) return gfail(g, rc, e->err);
+        for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];      // unpack_result left the LOCAL sums there
+        qt += e->q_total;
+        unsigned long long r = 0;
+        GHIP(g, hipMemcpy(&r, g->d_remote[d], 8, hipMemcpyDeviceToHost));
+        remote += r;
+    }
+    for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
+    g->q_total = qt;
+    for (int d = 0; d < G; ++d) mcl_stage_finish(g->eng[d], gs);
+    g->bytes_weights = (uint64_t)(G - 1) * (uint64_t)n * 8u;          // received per device
+    g->bytes_parents = (uint64_t)remote * 32u;                         // upper bound: children of remote parents x record size
+    for (int k = 0; k < 5; ++k) {
+        double m = 0.0;
+        for (int d = 0; d < G; ++d) m = std::max(m, g->eng[d]->timings[k]);
+        g->timings[k] = m;
+    }
+    g->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MCL_OK;
+}
+
+int mcl_group_expected_pose(mcl_group_t *g, double out[3])
+{
+    if (!g || !out) return MCL_ERR_INVALID_ARG;
+    if (g->n_per <= 0) return MCL_ERR_NOT_READY;
+    const double s = g->sums[0];
+    const double k = (s > 0.0) ? 1.0 / s : 1.0;
+    out[0] = g->sums[1] * k;
+    out[1] = g->sums[2] * k;
+    out[2] = std::atan2(g->sums[3] * k, g->sums[4] * k);
+    return MCL_OK;
+}
+
+int mcl_group_get_particles(mcl_group_t *g, double *xyz, int64_t n_total)
+{
+    if (!g || !xyz || n_total != g->n_total || g->n_per <= 0) return MCL_ERR_INVALID_ARG;
+    std::vector<double> shard((size_t)g->n_per * 3);
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        const int rc = mcl_get_particles(g->eng[d], shard.data(), g->n_per);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+        for (int c = 0; c < 3; ++c)
+            std::memcpy(xyz + (size_t)c * n_total + d * (size_t)g->n_per, shard.data() + (size_t)c * g->n_per, (size_t)g->n_per * 8);
+    }
+    return MCL_OK;
+}
+
+int mcl_group_get_weights(mcl_group_t *g, double *weights, int64_t n_total)
+{
+    if (!g || !weights || n_total != g->n_total || g->n_per <= 0) return MCL_ERR_INVALID_ARG;
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        const int rc = mcl_get_weights(g->eng[d], weights + d * (size_t)g->n_per, g->n_per);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    return MCL_OK;
+}
+
+int mcl_group_get_resample_indices(mcl_group_t *g, int32_t *idx, int64_t n_total)
+{
+    if (!g || !idx || n_total != g->n_total || g->n_per <= 0) return MCL_ERR_INVALID_ARG;
+    for (size_t d = 0; d < g->eng.size(); ++d) {
+        const int rc = mcl_get_resample_indices(g->eng[d], idx + d * (size_t)g->n_per, g->n_per);
+        if (rc) return gfail(g, rc, g->eng[d]->err);
+    }
+    return MCL_OK;
+}
+
+int mcl_group_get_stage_timings(const mcl_group_t *g, double ms[6])
+{
+    if (!g || !ms) return MCL_ERR_INVALID_ARG;
+    std::memcpy(ms, g->timings, sizeof(g->timings));
+    return MCL_OK;
+}
+
+int mcl_group_exchange_bytes(const mcl_group_t *g, uint64_t out[2])
+{
+    if (!g || !out) return MCL_ERR_INVALID_ARG;
+    out[0] = g->bytes_weights; out[1] = g->bytes_parents;
     return MCL_OK;
 }
 

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__r
 //   NaN CDF -> every draw returns 0).
 //   then row gather (cpp:664) and the motion model (cpp:474-502) with the three normals.
 // ------------------------------------------------------------------------------------------------
+constexpr int kMaxShards = 16;
 struct ResampleArgs {
     const double *px, *py, *pth;      // parents
     const uint64_t *cdf;              // inclusive CDF over parents
@@ -145,6 +146,13 @@ struct ResampleArgs {
     double disp_x, disp_y, disp_th;
     int do_resample;                  // 0: children = parents (identity), used by tests
     int do_motion;
+    // sharded particle sets: parents of other shards are fetched on demand instead of being gathered
+    const double4 *ppack_rank[kMaxShards];   // records of shard r (peer pointers within one process), or all null
+    int64_t n_per_rank;               // parents per shard (global index = r * n_per_rank + local index)
+    int self_rank;
+    unsigned long long *remote_count; // += children whose parent lives in another shard (exchange accounting), or null
+    const int32_t *idx_in;            // parent of every child decided earlier (index-only pass + exchange), or null
+    int index_only;                   // 1: write idx_out and stop (the host fetches the selected parents, then calls again)
 };
 
 __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
@@ -153,7 +161,9 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     if (m >= a.n_children) return;
     uint64_t g = (uint64_t)(a.child_first + m);
     int64_t idx = m;
-    if (a.do_resample) {
+    if (a.idx_in) {
+        idx = a.idx_in[m];
+    } else if (a.do_resample) {
         idx = 0;
         if (a.q_total != 0) {
             uint64_t lmul, r0, r1 = a.q_total;
@@ -211,8 +221,19 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
         }
     }
     if (a.idx_out) a.idx_out[m] = (int32_t)idx;
+    if (a.index_only) return;
     double x, y, th;
-    if (a.ppack) { const double4 pr = a.ppack[idx]; x = pr.x; y = pr.y; th = pr.z; }
+    if (a.n_per_rank > 0) {
+        // the parent's record straight from the shard that owns it (this GPU or a peer over xGMI): only selected
+        // parents ever cross a link, and a parent many children share is served from this GPU's L2 after the first fetch
+        const int r = (int)(idx / a.n_per_rank);
+        const double4 pr = a.ppack_rank[r][idx - (int64_t)r * a.n_per_rank];
+        x = pr.x; y = pr.y; th = pr.z;
+        if (a.remote_count) {
+            const unsigned long long rem = __ballot(r != a.self_rank);
+            if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1 && rem) atomicAdd(a.remote_count, (unsigned long long)__popcll(rem));
+        }
+    } else if (a.ppack) { const double4 pr = a.ppack[idx]; x = pr.x; y = pr.y; th = pr.z; }
     else { x = a.px[idx]; y = a.py[idx]; th = a.pth[idx]; }
     if (a.do_motion) {
         double n0, n1, n2;

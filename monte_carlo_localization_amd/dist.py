@@ -1,21 +1,27 @@
 """Particle set sharded over the GPUs of one node: one process per GPU, one engine per process,
-torch.distributed (backend "nccl" == RCCL over xGMI) for the three exchange steps of an update.
+torch.distributed (backend "nccl" == RCCL over xGMI) for the exchange steps of an update.
 
 The reference has no distributed code.  The update couples particles only through
-  (1) resampling  — children of rank g are drawn from the GLOBAL weighted set: all-gather of the
-                    particles as packed (x, y, theta, -) records and of the fixed-point weights
-                    (32 + 8 B per particle), exact integer CDF;
+  (1) resampling  — children of rank g are drawn from the GLOBAL weighted set.  Only the fixed-point weights are
+                    gathered (all-gather, 8 B per particle: every rank scans the same exact integer CDF); each rank then
+                    asks the engine which parents its children selected (`stage_resample_indices`), requests the DISTINCT
+                    ones from their owners (two all-to-alls: 4-byte local indices out, 32-byte records back) and hands the
+                    compact record table to `stage_motion_records`.  With the peaked weights of a converged filter a few
+                    thousand parents serve millions of children, so almost nothing crosses a link; the worst case
+                    (uniform weights) moves what the former wholesale all-gather of the records always moved;
   (2) max log-weight — all-reduce(MAX) of one double;
   (3) normalisation / pose — all-reduce(SUM) of five doubles (+ the two halves of the local
                     fixed-point weight total, so that the next update knows the global total
                     without reading it back from the device).
 Everything else (motion, ray cast, likelihood) is local to a shard.  Because the CDF is an exact
 integer scan and the log-weights are exact fp64 sums, resample indices and weights are bit-identical
-for any number of ranks.
+for any number of ranks.  (Several GPUs driven by ONE process do the same through `mcl_group_*` in the
+library itself, with peer copies and peer pointers instead of collectives.)
 
 `shard` is anything with the staging interface of engine.Engine (export_state / export_records /
-scan_weights / stage_resample_records / stage_rays / scalars / stage_weights / stage_finish); tests drive this class on CPU tensors over
-gloo with an oracle-backed stand-in that lives under tests/.
+scan_weights / stage_resample_indices / stage_motion_records / stage_rays / scalars / stage_weights /
+stage_finish); tests drive this class on CPU tensors over gloo with an oracle-backed stand-in that lives
+under tests/.
 """
 from __future__ import annotations
 
@@ -27,11 +33,10 @@ import torch.distributed as dist
 
 
 class ShardedFilter:
-    """overlap=True: the children's columns are all-gathered for the NEXT update while this update's ray
-    kernel runs (they are final right after the motion step); only the 8-byte fixed-point weights remain on the
-    critical path.  Needs `shard.set_reserved_cus` so that the persistent ray kernel leaves a few CUs to RCCL."""
+    """overlap=True: the fixed-point weights are all-gathered for the NEXT update as soon as this update has produced
+    them, beside the sums all-reduce and the host work between updates."""
 
-    def __init__(self, shard, n_local: int, device: torch.device, group=None, overlap: bool = True, reserved_cus: int = 8):
+    def __init__(self, shard, n_local: int, device: torch.device, group=None, overlap: bool = True, reserved_cus: int = 0):
         self.shard = shard
         self.n = int(n_local)
         self.group = group
@@ -40,21 +45,20 @@ class ShardedFilter:
         self.device = device
         # a single rank has nothing to overlap; MCL_FORCE_OVERLAP=1 keeps the path on for rehearsals
         self.overlap = bool(overlap) and (self.world > 1 or os.environ.get("MCL_FORCE_OVERLAP") == "1")
-        if self.overlap and hasattr(shard, "set_reserved_cus"):
+        if reserved_cus and hasattr(shard, "set_reserved_cus"):
             shard.set_reserved_cus(reserved_cus)
-        f64, i64 = torch.float64, torch.int64
+        f64, i64, i32 = torch.float64, torch.int64, torch.int32
         n, nt = self.n, self.n * self.world
         self.n_total = nt
         self.loc = torch.empty((n, 4), dtype=f64, device=device)        # (x, y, theta, -) records of this shard
         self.loc_q = torch.empty(n, dtype=i64, device=device)           # uint64 bits
-        self.glob = [torch.empty((nt, 4), dtype=f64, device=device) for _ in range(2 if self.overlap else 1)]
-        self.cur = 0
-        self.pending = None                                              # async gather filling self.glob[self.cur]
         self.q_total = None                                              # global fixed-point weight total, once known
         self.pending_q = None                                            # async gather of the weights issued by the previous update
         self.glob_q = torch.empty(nt, dtype=i64, device=device)
         self.glob_cdf = torch.empty(nt, dtype=i64, device=device)
+        self.parent = torch.empty(n, dtype=i32, device=device)          # global parent index of every local child
         self.pose = np.zeros(3)
+        self.exchange_bytes = dict(weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
 
     def _sync(self):
         if self.device.type == "cuda":
@@ -62,28 +66,41 @@ class ShardedFilter:
 
     def reset(self):
         """Call after the shard's particle state was replaced from outside (set_particles / init_*)."""
-        if self.pending is not None:
-            self.pending.wait()
-            self._sync()
         if self.pending_q is not None:
             self.pending_q.wait()
             self._sync()
-        self.pending = None
         self.pending_q = None
         self.q_total = None
 
-    def _gather_records(self, buf: int, async_op: bool):
+    def _fetch_parents(self):
+        """self.parent (global indices) -> (compact record table, position of every child's parent in it).  Distinct
+        parents only; the ones this rank owns are copied locally, the others requested from their owners."""
+        n, world = self.n, self.world
+        uniq, inv = torch.unique(self.parent.to(torch.int64), sorted=True, return_inverse=True)
         self.shard.export_records(self.loc.data_ptr())
-        return dist.all_gather_into_tensor(self.glob[buf], self.loc, group=self.group, async_op=async_op)
+        self._sync()
+        owner = torch.div(uniq, n, rounding_mode="floor")
+        local = uniq - owner * n
+        send_counts = torch.bincount(owner, minlength=world)
+        if world == 1:
+            table = self.loc[local]
+            self.exchange_bytes.update(requests_sent=0, records_received=0, distinct_remote_parents=0)
+            return table.contiguous(), inv.to(torch.int32).contiguous()
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc, rcv = send_counts.tolist(), recv_counts.tolist()
+        req_in = torch.empty(int(sum(rcv)), dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(req_in, local.contiguous(), output_split_sizes=rcv, input_split_sizes=sc, group=self.group)
+        reply = self.loc[req_in].contiguous()                            # the records the other ranks asked this one for
+        table = torch.empty((int(uniq.numel()), 4), dtype=torch.float64, device=self.device)
+        dist.all_to_all_single(table, reply, output_split_sizes=sc, input_split_sizes=rcv, group=self.group)
+        remote = int(uniq.numel()) - sc[self.rank]
+        self.exchange_bytes.update(requests_sent=8 * remote, records_received=32 * remote, distinct_remote_parents=remote)
+        return table, inv.to(torch.int32).contiguous()
 
     def update(self, action, obs):
         s = self.shard
-        # (1) exchange for resampling: particle columns (possibly gathered during the previous update) + weights
-        if self.pending is None:
-            self._gather_records(self.cur, async_op=False)
-        else:
-            self.pending.wait()
-            self.pending = None
+        # (1) exchange for resampling: weights everywhere, then only the selected parents
         if self.pending_q is None:
             s.export_state(0, 0, 0, self.loc_q.data_ptr())
             dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
@@ -91,13 +108,13 @@ class ShardedFilter:
             self.pending_q.wait()                                        # issued at the end of the previous update
             self.pending_q = None
         self._sync()
+        self.exchange_bytes["weights_received"] = 8 * self.n * (self.world - 1)
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
-        s.stage_resample_records(self.glob[self.cur].data_ptr(), self.glob_cdf.data_ptr(), self.n_total, q_total,
-                                 self.rank * self.n, self.n_total, action)
-        if self.overlap:
-            self.cur ^= 1
-            self.pending = self._gather_records(self.cur, async_op=True)   # runs beside the ray kernel
+        s.stage_resample_indices(self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, self.parent.data_ptr())
+        table, slot = self._fetch_parents()
+        self._sync()
+        s.stage_motion_records(table.data_ptr(), int(table.shape[0]), slot.data_ptr(), self.rank * self.n, self.n_total, action)
         s.stage_rays(obs)
         # (2) global max log-weight
         read = getattr(s, "host_scalars", s.scalars)                      # the stage calls already read SCALARS back

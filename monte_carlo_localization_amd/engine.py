@@ -28,7 +28,11 @@ EXPORTS = [
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
     "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_get_effective_sample_size", "mcl_get_host_scalars", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
-    "mcl_set_reserved_cus",
+    "mcl_set_reserved_cus", "mcl_stage_resample_indices", "mcl_stage_motion_records",
+    "mcl_group_create", "mcl_group_destroy", "mcl_group_last_error", "mcl_group_size", "mcl_group_engine", "mcl_group_set_map",
+    "mcl_group_set_beam_angles", "mcl_group_set_particles", "mcl_group_init_particles_pose", "mcl_group_init_global",
+    "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
+    "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
 ]
 
 
@@ -66,6 +70,11 @@ def load_library():
         lib.mcl_destroy.restype = None
         lib.mcl_default_config.argtypes = [C.POINTER(Config)]
         lib.mcl_default_config.restype = None
+        lib.mcl_group_last_error.restype = C.c_char_p
+        lib.mcl_group_last_error.argtypes = [C.c_void_p]
+        lib.mcl_group_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.mcl_group_destroy.argtypes = [C.c_void_p]
+        lib.mcl_group_destroy.restype = None
         _lib = lib
     return _lib
 
@@ -343,6 +352,16 @@ class Engine:
                                                       C.c_uint64(q_total), C.c_int64(child_first), C.c_int64(n_children_total), _p(a)),
                   "mcl_stage_resample_records")
 
+    def stage_resample_indices(self, d_cdf, n_parents, q_total, child_first, n_children_total, d_parent_idx):
+        self._chk(self.lib.mcl_stage_resample_indices(self._h, C.c_void_p(d_cdf), C.c_int64(n_parents), C.c_uint64(q_total),
+                                                      C.c_int64(child_first), C.c_int64(n_children_total), C.c_void_p(d_parent_idx)),
+                  "mcl_stage_resample_indices")
+
+    def stage_motion_records(self, d_records, n_records, d_record_of_child, child_first, n_children_total, action):
+        a = _c(action, np.float64)
+        self._chk(self.lib.mcl_stage_motion_records(self._h, C.c_void_p(d_records), C.c_int64(n_records), C.c_void_p(d_record_of_child),
+                                                    C.c_int64(child_first), C.c_int64(n_children_total), _p(a)), "mcl_stage_motion_records")
+
     def stage_rays(self, obs):
         o = _c(obs, np.float32)
         self._chk(self.lib.mcl_stage_rays(self._h, _p(o), C.c_int32(o.size)), "mcl_stage_rays")
@@ -360,3 +379,98 @@ class Engine:
     def scan_weights(self, d_q, d_cdf, n, offset=0):
         self._chk(self.lib.mcl_scan_weights(self._h, C.c_void_p(d_q), C.c_void_p(d_cdf), C.c_int64(n),
                                             C.c_uint64(offset)), "mcl_scan_weights")
+
+
+class Group:
+    """Several GPUs behind one handle, driven by this one process (mcl_group_*): the particle set is sharded contiguously
+    over `devices`; results are bit-identical to one Engine holding all particles."""
+
+    def __init__(self, devices, cfg: Config | None = None, **over):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        if cfg is not None:
+            for k, v in over.items():
+                setattr(self.cfg, k, v)
+        dev = np.ascontiguousarray(np.asarray(devices, np.int32))
+        h = C.c_void_p()
+        rc = self.lib.mcl_group_create(C.byref(self.cfg), _p(dev), C.c_int32(dev.size), C.byref(h))
+        if rc != MCL_OK:
+            raise EngineError(f"mcl_group_create rc={rc}: {self.lib.mcl_group_last_error(None).decode()}")
+        self._h = h
+        self.size = int(dev.size)
+        self.n_total = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mcl_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != MCL_OK:
+            raise EngineError(f"{what} rc={rc}: {self.lib.mcl_group_last_error(self._h).decode()}")
+
+    def set_map(self, grid, resolution, origin_x, origin_y):
+        g = _c(grid, np.int8)
+        H, W = g.shape
+        self._chk(self.lib.mcl_group_set_map(self._h, _p(g), C.c_uint32(W), C.c_uint32(H), C.c_float(resolution),
+                                             C.c_double(origin_x), C.c_double(origin_y)), "mcl_group_set_map")
+
+    def set_beam_angles(self, angles):
+        a = _c(angles, np.float32)
+        self._chk(self.lib.mcl_group_set_beam_angles(self._h, _p(a), C.c_int32(a.size)), "mcl_group_set_beam_angles")
+
+    def set_particles(self, p_colmajor, weights):
+        p = _c(p_colmajor, np.float64)
+        w = _c(weights, np.float64)
+        self.n_total = int(p.shape[1])
+        self._chk(self.lib.mcl_group_set_particles(self._h, _p(p), _p(w), C.c_int64(self.n_total)), "mcl_group_set_particles")
+
+    def init_particles_pose(self, pose, n_total):
+        q = _c(pose, np.float64)
+        self.n_total = int(n_total)
+        self._chk(self.lib.mcl_group_init_particles_pose(self._h, _p(q), C.c_int64(n_total)), "mcl_group_init_particles_pose")
+
+    def init_global(self, n_total):
+        self.n_total = int(n_total)
+        self._chk(self.lib.mcl_group_init_global(self._h, C.c_int64(n_total)), "mcl_group_init_global")
+
+    def update(self, action, obs):
+        a = _c(action, np.float64)
+        o = _c(obs, np.float32)
+        self._chk(self.lib.mcl_group_update(self._h, _p(a), _p(o), C.c_int32(o.size)), "mcl_group_update")
+
+    def expected_pose(self):
+        out = np.empty(3)
+        self._chk(self.lib.mcl_group_expected_pose(self._h, _p(out)), "mcl_group_expected_pose")
+        return out
+
+    def get_particles(self):
+        out = np.empty((3, self.n_total))
+        self._chk(self.lib.mcl_group_get_particles(self._h, _p(out), C.c_int64(self.n_total)), "mcl_group_get_particles")
+        return out
+
+    def get_weights(self):
+        out = np.empty(self.n_total)
+        self._chk(self.lib.mcl_group_get_weights(self._h, _p(out), C.c_int64(self.n_total)), "mcl_group_get_weights")
+        return out
+
+    def resample_indices(self):
+        out = np.empty(self.n_total, np.int32)
+        self._chk(self.lib.mcl_group_get_resample_indices(self._h, _p(out), C.c_int64(self.n_total)), "mcl_group_get_resample_indices")
+        return out
+
+    def stage_timings(self):
+        out = np.empty(6)
+        self._chk(self.lib.mcl_group_get_stage_timings(self._h, _p(out)), "mcl_group_get_stage_timings")
+        return out
+
+    def exchange_bytes(self):
+        out = np.zeros(2, np.uint64)
+        self._chk(self.lib.mcl_group_exchange_bytes(self._h, _p(out)), "mcl_group_exchange_bytes")
+        return dict(weights_received_per_device=int(out[0]), parent_records_from_peers=int(out[1]))

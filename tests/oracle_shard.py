@@ -76,6 +76,29 @@ class OracleShard:
         self.p = orc.motion_model(parents, action, nrm)
         self.upd += 1
 
+    def _draw(self, d_cdf, n_parents, q_total, child_first, n_children_total):
+        cdf = _view(d_cdf, n_parents, ctypes.c_uint64, np.uint64)
+        assert int(cdf[-1]) == q_total
+        q = np.diff(cdf, prepend=np.uint64(0)).astype(np.uint64)
+        n = self.n
+        if self.mode == 0:
+            return orc.eng_resample_indices(q, 0, n_children=n, k53=orc.eng_philox_k53(self.seed, self.upd, child_first, n))
+        full = orc.eng_resample_indices(q, 1, n_children=n_children_total, k0=orc.eng_philox_k0(self.seed, self.upd))
+        return full[child_first:child_first + n]
+
+    def stage_resample_indices(self, d_cdf, n_parents, q_total, child_first, n_children_total, d_parent_idx):
+        """global parent of every local child -> caller's int32 buffer; the shard's particles stay as they are"""
+        self.idx = self._draw(d_cdf, n_parents, q_total, child_first, n_children_total)
+        _view(d_parent_idx, self.n, ctypes.c_int32, np.int32)[:] = self.idx
+
+    def stage_motion_records(self, d_records, n_records, d_record_of_child, child_first, n_children_total, action):
+        rec = _view(d_records, 4 * n_records, ctypes.c_double, np.float64).reshape(n_records, 4)
+        slot = _view(d_record_of_child, self.n, ctypes.c_int32, np.int32)
+        parents = np.stack([rec[slot, 0], rec[slot, 1], rec[slot, 2]])
+        nrm = orc.eng_philox_normals(self.seed, self.upd, child_first, self.n)
+        self.p = orc.motion_model(parents, action, nrm)
+        self.upd += 1
+
     def stage_rays(self, obs):
         oi = orc.obs_index(np.asarray(obs, np.float32), self.om)
         self.logw, _, _ = orc.eng_log_weights(self.om, self.p, self.angles, oi, self.L, use_omp=False)

@@ -1,0 +1,83 @@
+"""Several engines behind one handle (mcl_group_*): the reference's single process drives the
+shards.  With one GPU on the test box the group runs TWO (or four) engines on device 0 -- the peer copies and peer
+pointers then stay on one device, everything else (global CDF, children of a shard drawn from the global parent set,
+parents fetched where they live, host-side maxima and sums) is the real path.  It must equal one engine holding all
+particles bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_engine
+
+pytestmark = pytest.mark.gpu
+ACTION = (0.05, 0.0, 0.01)
+
+
+def make_group(engine_mod, m, ang, n_per, shards, **cfg):
+    g = engine_mod.Group([0] * shards, max_particles=n_per, **cfg)
+    g.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+    g.set_beam_angles(ang)
+    return g
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+@pytest.mark.parametrize("mode", ["multinomial", "systematic"])
+def test_group_equals_one_engine(orc, engine_mod, spielberg, shards, mode):
+    ang = orc.beam_angles(angle_step=18)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].copy()
+    n = 8192
+    rm = engine_mod.RESAMPLE_MULTINOMIAL if mode == "multinomial" else engine_mod.RESAMPLE_SYSTEMATIC
+    one = make_engine(engine_mod, spielberg, ang, n, seed=7, resample_mode=rm)
+    one.init_particles_pose((0.0, 0.0, 0.0), n)
+    grp = make_group(engine_mod, spielberg, ang, n // shards, shards, seed=7, resample_mode=rm)
+    grp.init_particles_pose((0.0, 0.0, 0.0), n)
+    assert np.array_equal(grp.get_particles(), one.get_particles())
+    for k in range(6):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        assert np.array_equal(grp.resample_indices(), one.resample_indices()), f"update {k}"
+        assert np.array_equal(grp.get_particles(), one.get_particles()), f"update {k}"
+        # normalised weights = w / sum(w): w is bit-identical, the sum is reduced per shard and then added (last-ulp order)
+        np.testing.assert_allclose(grp.get_weights(), one.get_weights(), rtol=1e-13, atol=0, err_msg=f"update {k}")
+        np.testing.assert_allclose(grp.expected_pose(), one.expected_pose(), rtol=0, atol=1e-12)
+    xb = grp.exchange_bytes()
+    assert xb["weights_received_per_device"] == (shards - 1) * (n // shards) * 8
+    # only children whose parent lives in another shard fetch a record across: never more than all children
+    assert 0 < xb["parent_records_from_peers"] <= n * 32
+    grp.close(); one.close()
+
+
+def test_group_with_the_sweep_kernel_and_set_particles(orc, engine_mod, spielberg):
+    """Two shards of 65 536 particles x 1081 beams (k_rays_sweep in both) from host-supplied particles."""
+    from conftest import tracking_cloud
+    ang = orc.beam_angles(angle_step=1)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
+    n = 131072
+    p = tracking_cloud(np.random.default_rng(4), n)
+    w = np.full(n, 1.0 / n)
+    one = make_engine(engine_mod, spielberg, ang, n, seed=11)
+    one.set_particles(p, w)
+    grp = make_group(engine_mod, spielberg, ang, n // 2, 2, seed=11)
+    grp.set_particles(p, w)
+    for _ in range(3):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+    assert one.ray_kernel_name() == "k_rays_sweep"
+    assert np.array_equal(grp.get_particles(), one.get_particles())
+    np.testing.assert_allclose(grp.get_weights(), one.get_weights(), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(grp.expected_pose(), one.expected_pose(), rtol=0, atol=1e-12)
+    grp.close(); one.close()
+
+
+def test_group_argument_errors(engine_mod, spielberg, orc):
+    with pytest.raises(engine_mod.EngineError):
+        engine_mod.Group([], max_particles=16)
+    with pytest.raises(engine_mod.EngineError):
+        engine_mod.Group([0, 0], max_particles=16, weight_mode=engine_mod.WEIGHT_PRODUCT, keep_ray_steps=1)
+    g = make_group(engine_mod, spielberg, orc.beam_angles(angle_step=60), 16, 2)
+    with pytest.raises(engine_mod.EngineError):
+        g.init_particles_pose((0, 0, 0), 31)            # not a multiple of the device count
+    with pytest.raises(engine_mod.EngineError):
+        g.update(ACTION, np.ones(19, np.float32))        # particles not set
+    g.close()

@@ -1,28 +1,45 @@
 #!/usr/bin/env bash
 # Regenerates the artefacts under profiles/ on a GPU box (run from the repository root, e.g. through gpurun):
-#   bench lines of the five configurations, a rocprofv3 kernel trace of the default bench command and the PMC
-#   passes (each counter group in its own run, as the MI355X guide prescribes), then the summaries.
-# usage: tools/profile_round.sh <round-tag, e.g. r01> [scratch dir, default gpurun_out]
+#   the VALU micro-benchmarks, a rocprofv3 kernel trace of the default bench command, the PMC passes (each counter group
+#   in its own run, as the MI355X guide prescribes), the roofline inputs bench.py reads, then the bench lines.
+# usage: tools/profile_round.sh <round-tag, e.g. r02> [scratch dir, default gpurun_out]
 set -euo pipefail
 TAG=${1:?round tag}
 OUT=${2:-gpurun_out}
 R=$(pwd)
-mkdir -p "$OUT"
+# gpurun only carries gpurun_out/ back: everything is written to $OUT/profiles_new and copied to profiles/ afterwards
+# (cp gpurun_out/profiles_new/* profiles/); bench.py's roofline block needs the inputs file in profiles/ while it runs
+PROF="$OUT/profiles_new"
+mkdir -p "$OUT" "$PROF"
+./tools/ubench/valu_rates > "$PROF/${TAG}_valu_rates.txt"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o t -- python3 "$R/bench.py" --steps 10 --no-cpu-baseline > "$R/$OUT/prof.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/pmc_write" -o w -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$R/$OUT/pmc_sq" -o s -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_sq.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$R/$OUT/pmc_sq2" -o s2 -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_sq2.log" 2>&1
+cd "$R"
+# keep only the rows of the ray-stage kernels in the committed PMC files (the full CSVs are tens of MB)
+for p in fetch:f write:w sq:s sq2:s2; do
+  d=${p%%:*}; o=${p##*:}
+  python3 - "$OUT/pmc_$d/${o}_counter_collection.csv" "$PROF/${TAG}_pmc_$d.csv" <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+keep = [rows[0]] + [r for r in rows[1:] if any(k in r[8] for k in ("k_rays_", "k_combine", "k_resample", "k_sort", "k_weights"))]
+csv.writer(open(sys.argv[2], "w")).writerows(keep)
+PY
+done
+python3 tools/summarize_rocprof.py "$OUT/prof/t_kernel_trace.csv" "$PROF/${TAG}_kernel_trace_summary.md" \
+    --pmc-fetch "$OUT/pmc_fetch/f_counter_collection.csv" --pmc-write "$OUT/pmc_write/w_counter_collection.csv" \
+    --pmc-sq "$OUT/pmc_sq/s_counter_collection.csv" --pmc-sq2 "$OUT/pmc_sq2/s2_counter_collection.csv" > /dev/null
+cp "$OUT/prof/t_kernel_stats.csv" "$PROF/${TAG}_kernel_stats.csv"
+python3 tools/roofline_inputs.py "$TAG" "$PROF/${TAG}_pmc_sq.csv" "$PROF/${TAG}_pmc_sq2.csv" "$PROF/${TAG}_pmc_fetch.csv" \
+    "$PROF/${TAG}_pmc_write.csv" "$PROF/${TAG}_valu_rates.txt" 4194304 1081 "$PROF" > "$OUT/roofline_inputs.log"
+cp "$PROF/${TAG}_roofline_inputs.json" "profiles/${TAG}_roofline_inputs.json"
 python bench.py > "$OUT/b_4m.json"
 python bench.py --no-cpu-baseline --particles-per-gpu 262144 > "$OUT/b_256k.json"
 python bench.py --no-cpu-baseline --map levine > "$OUT/b_levine.json"
 python bench.py --no-cpu-baseline --regime global > "$OUT/b_global.json"
 python bench.py --no-cpu-baseline --resample systematic > "$OUT/b_sys.json"
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o t -- python3 "$R/bench.py" --steps 10 --no-cpu-baseline > "$R/$OUT/prof.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 5 --no-cpu-baseline > "$R/$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/pmc_write" -o w -- python3 "$R/bench.py" --steps 5 --no-cpu-baseline > "$R/$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$R/$OUT/pmc_sq" -o s -- python3 "$R/bench.py" --steps 5 --no-cpu-baseline > "$R/$OUT/pmc_sq.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD --output-format csv -d "$R/$OUT/pmc_sq2" -o s2 -- python3 "$R/bench.py" --steps 5 --no-cpu-baseline > "$R/$OUT/pmc_sq2.log" 2>&1
-cd "$R"
-for n in 4m 256k levine global sys; do tail -n 1 "$OUT/b_$n.json" > "profiles/${TAG}_bench_$n.json"; done
-python tools/summarize_rocprof.py "$OUT/prof/t_kernel_trace.csv" "profiles/${TAG}_kernel_trace_summary.md" \
-    --pmc-fetch "$OUT/pmc_fetch/f_counter_collection.csv" --pmc-write "$OUT/pmc_write/w_counter_collection.csv" \
-    --pmc-sq "$OUT/pmc_sq/s_counter_collection.csv" --pmc-sq2 "$OUT/pmc_sq2/s2_counter_collection.csv" > /dev/null
-cp "$OUT/prof/t_kernel_stats.csv" "profiles/${TAG}_kernel_stats.csv"
-echo "profiles/${TAG}_* refreshed; update profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE rows of the summary"
+for n in 4m 256k levine global sys; do tail -n 1 "$OUT/b_$n.json" > "$PROF/${TAG}_bench_$n.json"; done
+echo "$PROF/${TAG}_* refreshed"

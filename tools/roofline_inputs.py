@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Writes profiles/<tag>_roofline_inputs.json, the static inputs of bench.py's `roofline` block, from committed evidence:
+
+  * the dominant kernel's VALU instruction count and the clock it held -- rocprofv3 --pmc passes of the bench workload
+    (counter_collection.csv: SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same dispatch);
+  * the cycles one wave64 VALU instruction of the kernel's own instruction mix occupies a SIMD -- the
+    "k_rays_sweep whole beam" row at 8 waves per SIMD of tools/ubench/valu_rates.hip's output;
+  * memory-side traffic per launch -- FETCH_SIZE / WRITE_SIZE passes (KB; FETCH_SIZE doubled as the MI355X guide
+    prescribes for gfx950, which counts 128-byte read requests at 64 bytes).
+
+usage: roofline_inputs.py <tag> <sq.csv> <sq2.csv> <fetch.csv> <write.csv> <valu_rates.txt> <particles> <beams> [out dir, default profiles]
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+tag, sq, sq2, fe, wr, ub, n, B = sys.argv[1:9]
+outdir = sys.argv[9] if len(sys.argv) > 9 else "profiles"
+KERNEL = "k_rays_sweep"
+
+
+def counters(path):
+    v = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if KERNEL in r["Kernel_Name"]:
+            v[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return v
+
+
+def steady(rows):
+    rows = rows[2:] if len(rows) > 3 else rows          # the first launches trace the spread cloud
+    return sum(x for x, _ in rows) / len(rows), sum(d for _, d in rows) / len(rows)
+
+
+a, b, f, w = counters(sq), counters(sq2), counters(fe), counters(wr)
+insts, _ = steady(a["SQ_INSTS_VALU"])
+gui, dur_ns = steady(b["GRBM_GUI_ACTIVE"])
+clock_ghz = gui / 8.0 / dur_ns
+fetch_kb, _ = steady(f["FETCH_SIZE"])
+write_kb, _ = steady(w["WRITE_SIZE"])
+cpi = None
+for line in open(ub):
+    if "k_rays_sweep whole beam" in line and "W=8" in line:
+        cpi = float(re.search(r"([0-9.]+) \(wall x clock\)", line).group(1))
+assert cpi, "ubench row not found"
+out = {
+    "kernel": KERNEL, "particles": int(n), "beams": int(B),
+    "valu_insts_per_launch": insts, "cycles_per_valu_inst": cpi, "simds": 1024, "clock_ghz": round(clock_ghz, 4),
+    "kernel_ms_while_profiled": dur_ns / 1e6,
+    "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
+    "hbm_bytes_source": f"profiles/{tag}_pmc_*.csv: 2 x FETCH_SIZE + WRITE_SIZE (KB) of {KERNEL}, steady-state launches; "
+                        "8-byte accesses are outside the guide's calibration (16 B per lane), so this is an upper estimate",
+    "fetch_kb": fetch_kb, "write_kb": write_kb,
+    "sources": {"SQ_INSTS_VALU": f"profiles/{tag}_pmc_sq.csv", "GRBM_GUI_ACTIVE": f"profiles/{tag}_pmc_sq2.csv",
+                "FETCH_SIZE": f"profiles/{tag}_pmc_fetch.csv", "WRITE_SIZE": f"profiles/{tag}_pmc_write.csv",
+                "cycles_per_valu_inst": f"profiles/{tag}_valu_rates.txt, row 'k_rays_sweep whole beam', W=8, wall x clock"},
+}
+json.dump(out, open(f"{outdir}/{tag}_roofline_inputs.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
