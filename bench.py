@@ -85,8 +85,23 @@ def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
             "single_thread_value": out["one"][0], "three_thread_value": out["three"][0]}
 
 
+MAX_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md chip table: max clock 2400 MHz
+SIMDS = 1024                   # 256 CUs x 4 SIMDs
+
+
 def roofline_block(kernel_name, k_ms, n, B, sbar):
-    """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time."""
+    """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time.
+
+    gfx950 issues a wave64 instruction of the simple classes (v_add/v_sub/v_and/v_or/v_lshrrev/v_mov, fp32 add/mul/fma) in
+    2 cycles and everything else the kernel uses (v_mad_*24, 3-operand integer ops, compares, conversions, all fp64) in 4
+    (profiles/r02_op_rates.txt).  With I = VALU instructions and T = probe trips per launch (SQ_INSTS_VALU, SQ_INSTS_LDS:
+    one ds_read per trip), a trip is 5 four-cycle + 4 two-cycle instructions and the rest of the stream is 11/13
+    four-cycle (mcl_rays_sweep.h), so the launch needs at least
+        cycles = 4 I - 2 (4 T + (2/13) (I - 9 T))
+    SIMD issue cycles; the chip offers SIMDS x clock of them per second.  `frac` prices that against the MAXIMUM clock,
+    so it cannot exceed 1; `valu.at_measured_mix_rate` is the same with the rate tools/ubench/valu_rates.hip measures
+    for this exact instruction sequence (two-cycle instructions next to four-cycle ones do not reach 2) and the clock the
+    profiled run held: the kernel sits at ~1.0 of that."""
     alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per launch (one GPU's shard), SURVEY §8(d)
     alg = {"bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar, "achieved": alg_bytes / (k_ms * 1e-3) / 1e9,
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -99,17 +114,23 @@ def roofline_block(kernel_name, k_ms, n, B, sbar):
         except Exception:
             inp = None
     if inp and inp.get("kernel") == kernel_name and inp.get("particles") == n and inp.get("beams") == B:
-        insts, cpi, simds, ghz = inp["valu_insts_per_launch"], inp["cycles_per_valu_inst"], inp["simds"], inp["clock_ghz"]
-        floor_ms = insts * cpi / (simds * ghz * 1e6)
-        # achieved / peak in VALU issue cycles: what the launch needed vs what 1024 SIMDs offer in the measured time
-        block.update({"achieved": insts * cpi / (k_ms * 1e-3) / 1e9, "peak": simds * ghz, "unit": "G SIMD-cycles/s",
+        I, T = inp["valu_insts_per_launch"], inp["lds_insts_per_launch"]
+        cycles = 4.0 * I - 2.0 * (4.0 * T + (2.0 / 13.0) * (I - 9.0 * T))
+        floor_ms = cycles / (SIMDS * MAX_CLOCK_GHZ * 1e6)
+        mix_floor_ms = I * inp["cycles_per_valu_inst"] / (SIMDS * inp["clock_ghz"] * 1e6)
+        block.update({"achieved": cycles / (k_ms * 1e-3) / 1e9, "peak": SIMDS * MAX_CLOCK_GHZ, "unit": "G SIMD issue cycles/s",
                       "frac": floor_ms / k_ms,
-                      "valu": {"insts_per_launch": insts, "cycles_per_inst": cpi, "simds": simds, "clock_ghz": ghz,
-                               "floor_ms": floor_ms, "frac": floor_ms / k_ms, "source": "profiles/r02_roofline_inputs.json"},
+                      "valu": {"insts_per_launch": I, "probe_trips_per_launch": T, "issue_cycles_per_launch": cycles,
+                               "cycles_per_inst": cycles / I, "simds": SIMDS, "clock_ghz": MAX_CLOCK_GHZ, "floor_ms": floor_ms,
+                               "frac": floor_ms / k_ms,
+                               "at_measured_mix_rate": {"cycles_per_inst": inp["cycles_per_valu_inst"], "clock_ghz": inp["clock_ghz"],
+                                                        "floor_ms": mix_floor_ms, "kernel_ms_while_profiled": inp["kernel_ms_while_profiled"],
+                                                        "frac": mix_floor_ms / inp["kernel_ms_while_profiled"]},
+                               "source": "profiles/r02_roofline_inputs.json"},
                       "traffic": inp.get("hbm_bytes_per_launch"),
                       "traffic_source": inp.get("hbm_bytes_source")})
     else:
-        block.update({"achieved": None, "peak": None, "unit": "G SIMD-cycles/s", "frac": None,
+        block.update({"achieved": None, "peak": SIMDS * MAX_CLOCK_GHZ, "unit": "G SIMD issue cycles/s", "frac": None,
                       "note": "no profile inputs for this kernel / size under profiles/: VALU bound not priced"})
     return block
 
@@ -176,8 +197,13 @@ def main():
     rng = np.random.default_rng(42 + rank)
     p = synth.tracking_cloud(rng, n, true_pose) if args.regime == "tracking" else synth.global_cloud(rng, m, n)
     sample_first = np.ascontiguousarray(p[:, :4000])           # the first update traces the spread cloud
-    e.set_particles(p, np.full(n, 1.0 / (n * world)))
-    del p
+    w0 = np.full(n, 1.0 / (n * world))
+    e.set_particles(p, w0)
+    # one throw-away update sizes every lazily allocated buffer (work lists, partial sums, tables), then the particle set is
+    # put back: first_update_ms below is the cost of an update on the spread cloud, not of hipMalloc
+    e.update(ACTION, scan)
+    e.set_particles(p, w0)
+    del p, w0
 
     if use_dist:
         from monte_carlo_localization_amd.dist import ShardedFilter

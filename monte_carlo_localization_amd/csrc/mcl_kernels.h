@@ -1777,13 +1777,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
-    const int64_t p_begin = (int64_t)blockIdx.x * per;
-    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
+    const int64_t p_end = a.n;
     unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0;
     const uint32_t *flags32 = reinterpret_cast<const uint32_t *>(a.far_flags);
-    // each wave scans 64 particles' flags with one coalesced load and visits only the flagged ones
-    for (int64_t i0 = p_begin + (int64_t)wave * 64; i0 < p_end; i0 += (int64_t)kRayWaves * 64) {
+    // each wave scans 64 particles' flags with one coalesced load and visits only the flagged ones.  The 64-particle
+    // chunks are dealt round-robin over ALL waves of the grid: in sorted-slot order (k_rays_sweep) the flagged particles
+    // sit in a few long runs, which a contiguous range per workgroup would hand to a few workgroups
+    for (int64_t i0 = ((int64_t)wave * gridDim.x + blockIdx.x) * 64; i0 < p_end; i0 += (int64_t)kRayWaves * gridDim.x * 64) {
       const uint32_t myfl = (i0 + lane < p_end) ? flags32[i0 + lane] : 0u;
       unsigned long long todo = __ballot(myfl != 0u);
       while (todo) {

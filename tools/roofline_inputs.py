@@ -36,6 +36,7 @@ def steady(rows):
 
 a, b, f, w = counters(sq), counters(sq2), counters(fe), counters(wr)
 insts, _ = steady(a["SQ_INSTS_VALU"])
+lds, _ = steady(a["SQ_INSTS_LDS"])
 gui, dur_ns = steady(b["GRBM_GUI_ACTIVE"])
 clock_ghz = gui / 8.0 / dur_ns
 fetch_kb, _ = steady(f["FETCH_SIZE"])
@@ -47,7 +48,7 @@ for line in open(ub):
 assert cpi, "ubench row not found"
 out = {
     "kernel": KERNEL, "particles": int(n), "beams": int(B),
-    "valu_insts_per_launch": insts, "cycles_per_valu_inst": cpi, "simds": 1024, "clock_ghz": round(clock_ghz, 4),
+    "valu_insts_per_launch": insts, "lds_insts_per_launch": lds, "cycles_per_valu_inst": cpi, "simds": 1024, "clock_ghz": round(clock_ghz, 4),
     "kernel_ms_while_profiled": dur_ns / 1e6,
     "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
     "hbm_bytes_source": f"profiles/{tag}_pmc_*.csv: 2 x FETCH_SIZE + WRITE_SIZE (KB) of {KERNEL}, steady-state launches; "
