@@ -707,11 +707,10 @@ void stage_observation(mcl_engine *h, const float *obs, int stride)
 int upload_observation(mcl_engine *h)
 {
     HIPCHK(h, hipMemcpyAsync(h->d_obs, h->h_obs, (size_t)h->B * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(mcl::k_obs_index, dim3(1), dim3(256), 0, h->stream, h->d_obs, h->B, h->res, h->P, h->d_obs_idx);
     int rc = h->capturing ? MCL_OK : ensure_lt(h);          // no allocation while a graph is being captured (sizes are warm)
     if (rc) return rc;
     dim3 g((h->bpad + 255) / 256, h->P + 1);
-    hipLaunchKernelGGL(mcl::k_build_lt, g, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->bpad, h->P + 1, h->d_Lt,
+    hipLaunchKernelGGL(mcl::k_obs_build_lt, g, dim3(256), 0, h->stream, h->d_obs, h->res, h->P, h->d_L, h->B, h->bpad, h->d_obs_idx, h->d_Lt,
                        h->d_Lt + (size_t)(h->P + 1) * h->bpad);
     if (choose_ray_mode(h, h->N, false) == 5) {
         dim3 gd((h->ltd_cols + 255) / 256, mcl::sweep_table_rows(h->P));
@@ -746,6 +745,24 @@ int sensor_and_weights(mcl_engine *h, const double *d_global_max)
         return weight_stats(h, false, nullptr);
     }
     return weight_stats(h, true, d_global_max);
+}
+
+// weights, sums and the CDF of the current log-weights (the tail of an update).  Small updates take one launch.
+int weights_and_cdf(mcl_engine *h)
+{
+    const int64_t n = h->N;
+    if (h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0 && n <= mcl::kTinyTailMax) {
+        hipLaunchKernelGGL(mcl::k_tiny_tail, dim3(1), dim3(1024), 0, h->stream, h->d_logw, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n,
+                           h->d_w, h->d_q, h->d_cdf, h->d_scalars);
+        HIPCHK(h, hipGetLastError());
+        h->max_partials_ready = false;
+        h->carry_pending = false;
+        h->blocktot_for = nullptr;             // no spine / leaders for this CDF: the resampling search bisects it directly
+        return MCL_OK;
+    }
+    int rc = sensor_and_weights(h, nullptr);
+    if (rc) return rc;
+    return scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);   // CDF for the next resample / visualize
 }
 
 bool ready(mcl_engine *h, bool need_particles)
@@ -1278,8 +1295,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
                 h->capturing = true;
                 rc = upload_observation(h);
                 if (!rc) rc = launch_rays(h, h->d_x[gi], h->d_y[gi], h->d_th[gi], n);
-                if (!rc) rc = sensor_and_weights(h, nullptr);
-                if (!rc) rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+                if (!rc) rc = weights_and_cdf(h);
                 hipError_t ce = hipSuccess;
                 if (!rc) ce = hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream);
                 h->capturing = false;
@@ -1329,9 +1345,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->max_partials_ready = false;
     }
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
-    rc = sensor_and_weights(h, nullptr);
-    if (rc) return rc;
-    rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);   // CDF for the next resample / visualize
+    rc = weights_and_cdf(h);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
     rc = fetch_scalars(h);                 // one D2H copy (scalars, counters, overflow flag); synchronises the stream
@@ -1346,9 +1360,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
             hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
             h->max_partials_ready = false;
         }
-        rc = sensor_and_weights(h, nullptr);
-        if (rc) return rc;
-        rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
+        rc = weights_and_cdf(h);
         if (rc) return rc;
         rc = fetch_scalars(h);
         if (rc) return rc;

@@ -284,21 +284,19 @@ __global__ void k_pack_records(const double *__restrict__ x, const double *__res
     if (i < n) out[i] = make_double4(x[i], y[i], th[i], 0.0);
 }
 
-// lidarCB's downsampled ranges -> table row per beam, cpp:549-554, 570, 573 (NaN -> 0): one block
-__global__ void k_obs_index(const float *__restrict__ obs, int B, double res, int P, int32_t *__restrict__ obs_idx)
+// lidarCB's downsampled range -> table row of a beam, cpp:549-554, 570, 573 (NaN -> 0)
+__device__ __forceinline__ int obs_index_of(float obs, double res, int P)
 {
-    for (int j = threadIdx.x; j < B; j += blockDim.x) {
-        float px = (float)((double)obs[j] / res);
-        if (px > (float)P) px = (float)P;
-        float r = roundf(px);
-        int idx;
-        if (r != r) idx = 0;
-        else if (r <= -2147483648.0f) idx = 0;
-        else idx = (int)r;
-        idx = idx > P ? P : idx;
-        idx = idx < 0 ? 0 : idx;
-        obs_idx[j] = idx;
-    }
+    float px = (float)((double)obs / res);
+    if (px > (float)P) px = (float)P;
+    float r = roundf(px);
+    int idx;
+    if (r != r) idx = 0;
+    else if (r <= -2147483648.0f) idx = 0;
+    else idx = (int)r;
+    idx = idx > P ? P : idx;
+    idx = idx < 0 ? 0 : idx;
+    return idx;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,16 +351,21 @@ __global__ void k_fill(double *__restrict__ p, int64_t n, double v)
     if (i < n) p[i] = v;
 }
 
-// per-update transposed log table: Lt[d * bpad + j] = L[obs_idx[j] * (P+1) + d]
+// per-update transposed log table: Lt[d * bpad + j] = L[obs_idx[j] * (P+1) + d], straight from the raw ranges (every thread
+// derives its beam's table row; row 0's threads also publish obs_idx for the kernels that read it).
 // Ltr holds the same rows in reverse order (row rho = P - d), the form k_rays_cell indexes with "samples left"
-__global__ void k_build_lt(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int bpad, int tw,
-                           float *__restrict__ Lt, float *__restrict__ Ltr)
+__global__ void k_obs_build_lt(const float *__restrict__ obs, double res, int P, const float *__restrict__ L, int B, int bpad,
+                               int32_t *__restrict__ obs_idx, float *__restrict__ Lt, float *__restrict__ Ltr)
 {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int d = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y, tw = P + 1;
     if (j >= bpad) return;
     float v = 0.f;
-    if (j < B) v = L[(size_t)obs_idx[j] * tw + d];
+    if (j < B) {
+        const int oi = obs_index_of(obs[j], res, P);
+        if (d == 0) obs_idx[j] = oi;
+        v = L[(size_t)oi * tw + d];
+    }
     Lt[(size_t)d * bpad + j] = v;
     Ltr[(size_t)(tw - 1 - d) * bpad + j] = v;
 }
@@ -1979,6 +1982,73 @@ __global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__rest
         scalars[1] = r[0]; scalars[2] = __longlong_as_double((long long)rq);
         scalars[3] = r[2]; scalars[4] = r[3]; scalars[5] = r[4]; scalars[6] = r[5];
         scalars[7] = r[6];                      // sum w^2: effective sample size = (sum w)^2 / sum w^2
+    }
+}
+
+// The whole tail of a SMALL update (N <= kTinyTailMax) by ONE workgroup: maximum, max-subtracted weights, fixed-point
+// weights, the seven sums and the inclusive CDF -- seven launches of ~4 us each otherwise, and no cross-workgroup
+// reduction is needed at this size.  Same formulas as k_reduce_max / k_weights / k_scan_*; the sums are reduced in this
+// kernel's own fixed order (thread-strided, wave butterflies, waves in order), so they are deterministic for a given N.
+constexpr int64_t kTinyTailMax = 8192;
+__global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ logw, const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ th, int64_t n, double *__restrict__ w_out,
+                                                   uint64_t *__restrict__ q_out, uint64_t *__restrict__ cdf_out, double *__restrict__ scalars)
+{
+    __shared__ double sm[16][7];
+    __shared__ uint64_t wave_tot[16];
+    __shared__ double mx_sh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int kPer = (int)(kTinyTailMax / 1024);             // consecutive entries per thread
+    const int64_t c0 = (int64_t)threadIdx.x * kPer;
+    double lw[kPer];
+    double m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { lw[k] = (c0 + k < n) ? logw[c0 + k] : -INFINITY; m = fmax(m, lw[k]); }
+    m = wave_max(m);
+    if (lane == 0) sm[wv][0] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sm[0][0];
+        for (int k = 1; k < 16; ++k) t = fmax(t, sm[k][0]);
+        mx_sh = t;
+    }
+    __syncthreads();
+    const double mx = mx_sh;
+    double sw = 0, swx = 0, swy = 0, sws = 0, swc = 0, sww = 0;
+    uint64_t q[kPer], tot = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        q[k] = 0;
+        if (c0 + k < n) {
+            const int64_t i = c0 + k;
+            const double w = det_exp(lw[k] - mx);
+            q[k] = (uint64_t)(w * kWeightScale);
+            w_out[i] = w;
+            q_out[i] = q[k];
+            double s, c;
+            sincos(th[i], &s, &c);
+            sw += w; swx += w * x[i]; swy += w * y[i]; sws += w * s; swc += w * c; sww += w * w;
+        }
+        tot += q[k];
+    }
+    sw = wave_sum(sw); swx = wave_sum(swx); swy = wave_sum(swy); sws = wave_sum(sws); swc = wave_sum(swc); sww = wave_sum(sww);
+    const uint64_t inc = wave_incl_scan_u64(tot, lane);
+    __syncthreads();
+    if (lane == 0) { sm[wv][0] = sw; sm[wv][2] = swx; sm[wv][3] = swy; sm[wv][4] = sws; sm[wv][5] = swc; sm[wv][6] = sww; }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint64_t run = inc - tot;
+    for (int k = 0; k < wv; ++k) run += wave_tot[k];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { run += q[k]; if (c0 + k < n) cdf_out[c0 + k] = run; }
+    if (threadIdx.x == 0) {
+        double r[7] = {0, 0, 0, 0, 0, 0, 0};
+        uint64_t rq = 0;
+        for (int k = 0; k < 16; ++k) { r[0] += sm[k][0]; r[2] += sm[k][2]; r[3] += sm[k][3]; r[4] += sm[k][4]; r[5] += sm[k][5]; r[6] += sm[k][6]; rq += wave_tot[k]; }
+        scalars[0] = mx;
+        scalars[1] = r[0]; scalars[2] = __longlong_as_double((long long)rq);
+        scalars[3] = r[2]; scalars[4] = r[3]; scalars[5] = r[4]; scalars[6] = r[5];
+        scalars[7] = r[6];
     }
 }
 
