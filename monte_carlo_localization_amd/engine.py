@@ -162,7 +162,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.lib.mcl_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.mcl_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -469,6 +470,14 @@ class Group:
         out = np.empty(6)
         self._chk(self.lib.mcl_group_get_stage_timings(self._h, _p(out)), "mcl_group_get_stage_timings")
         return out
+
+    def engine(self, i) -> "Engine":
+        """Non-owning view of shard i's engine (diagnostics: sample_particles, counters, ...)."""
+        h = C.c_void_p()
+        self._chk(self.lib.mcl_group_engine(self._h, C.c_int32(i), C.byref(h)), "mcl_group_engine")
+        e = Engine.__new__(Engine)
+        e.lib, e.cfg, e._h, e.n, e.n_beams, e._borrowed = self.lib, self.cfg, h, self.n_total // self.size, 0, True
+        return e
 
     def exchange_bytes(self):
         out = np.zeros(2, np.uint64)

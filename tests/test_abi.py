@@ -62,6 +62,17 @@ def test_no_gpu_means_loud_failure(engine_mod):
     assert "no HIP device" in str(ei.value) or "rc=-4" in str(ei.value)
 
 
+def test_particle_total_bound_is_checked_before_anything_else(engine_mod):
+    """weights are 2^-36 fixed point summed in 64 bits: 2^27 particles (or more) per engine / per group are refused with an
+    argument error, on a box without a GPU too (the check precedes the device probe)"""
+    with pytest.raises(engine_mod.EngineError) as ei:
+        engine_mod.Engine(max_particles=1 << 27)
+    assert "rc=-1" in str(ei.value)
+    with pytest.raises(engine_mod.EngineError) as ei:
+        engine_mod.Group([0, 0], max_particles=1 << 26)
+    assert "rc=-1" in str(ei.value)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "monte_carlo_localization_amd")
     for dp, _, fs in os.walk(pkg):

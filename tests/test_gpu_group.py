@@ -70,6 +70,24 @@ def test_group_with_the_sweep_kernel_and_set_particles(orc, engine_mod, spielber
     grp.close(); one.close()
 
 
+def test_shard_cdf_follows_the_staged_weights(orc, engine_mod, spielberg):
+    """After a staged (sharded) update the shard's own CDF must describe its NEW weights: mcl_sample_particles (the
+    reference's visualize(), cpp:946-958) on a one-shard group equals the same call on a plain engine."""
+    ang = orc.beam_angles(angle_step=18)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].copy()
+    n = 4096
+    one = make_engine(engine_mod, spielberg, ang, n, seed=3)
+    one.init_particles_pose((0.0, 0.0, 0.0), n)
+    grp = make_group(engine_mod, spielberg, ang, n, 1, seed=3)
+    grp.init_particles_pose((0.0, 0.0, 0.0), n)
+    u = np.random.default_rng(8).random(60)
+    for _ in range(3):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        assert np.array_equal(grp.engine(0).sample_particles(60, u), one.sample_particles(60, u))
+    grp.close(); one.close()
+
+
 def test_group_argument_errors(engine_mod, spielberg, orc):
     with pytest.raises(engine_mod.EngineError):
         engine_mod.Group([], max_particles=16)

@@ -139,3 +139,25 @@ def test_default_kernel_at_size_and_updates_match_cell(orc, engine_mod, spielber
     assert out["auto"][0] == "k_rays_sweep" and out["cell"][0] == "k_rays_cell"
     for k in (1, 2, 3):
         assert np.array_equal(out["auto"][k], out["cell"][k])
+
+
+def test_work_list_overflow_falls_back_on_every_update(orc, engine_mod, spielberg):
+    """AUTO at 7.9M rays with debug_force_exact=2: every ray is undecided, the fix-up lists overflow and EVERY update
+    re-runs its ray stage with k_rays_skip (the kernel choice and the graph eligibility are pure functions of the
+    configuration, so an overflow can never poison the next update).  Four updates equal a plain k_rays_skip engine."""
+    ang = orc.beam_angles(angle_step=9)
+    obs = scan1081()[::9].copy()
+    n = 65536
+    out = {}
+    for name, cfg in (("auto", dict(ray_kernel=engine_mod.RAYS_AUTO, debug_force_exact=2)), ("skip", dict(ray_kernel=engine_mod.RAYS_SKIP))):
+        e = make_engine(engine_mod, spielberg, ang, n, seed=21, **cfg)
+        e.init_particles_pose((0.0, 0.0, 0.0), n)
+        names = []
+        for _ in range(4):
+            e.update((0.05, 0.0, 0.01), obs)
+            names.append(e.ray_kernel_name())
+        out[name] = (names, e.get_particles(), e.get_weights(), e.expected_pose())
+        e.close()
+    assert out["auto"][0] == ["k_rays_skip"] * 4          # what finally produced each update's log-weights
+    for k in (1, 2, 3):
+        assert np.array_equal(out["auto"][k], out["skip"][k])
