@@ -136,6 +136,11 @@ def roofline_block(kernel_name, k_ms, n, B, sbar):
 
 
 def main():
+    # the contract is ONE JSON line on stdout: libraries that write there (RCCL prints a version banner when its first
+    # communicator is created) are pointed at stderr, the line goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -203,18 +208,21 @@ def main():
     # put back: first_update_ms below is the cost of an update on the spread cloud, not of hipMalloc
     e.update(ACTION, scan)
     e.set_particles(p, w0)
-    del p, w0
 
     if use_dist:
         from monte_carlo_localization_amd.dist import ShardedFilter
         dev = torch.device("cuda", local_rank)
         sf = ShardedFilter(e, n, dev, overlap=not args.no_overlap)
+        sf.update(ACTION, scan)               # the same for the exchange: RCCL builds its communicators on first use
+        e.set_particles(p, w0)
+        sf.reset()
 
         def step():
             sf.update(ACTION, scan)
     else:
         def step():
             e.update(ACTION, scan)
+    del p, w0
 
     def fence():
         if dist is not None:
@@ -288,7 +296,8 @@ def main():
         }
         if use_dist:
             line["exchange_bytes_per_update_per_gpu"] = sf.exchange_bytes
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

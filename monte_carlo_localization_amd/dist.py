@@ -57,6 +57,7 @@ class ShardedFilter:
         self.glob_q = torch.empty(nt, dtype=i64, device=device)
         self.glob_cdf = torch.empty(nt, dtype=i64, device=device)
         self.parent = torch.empty(n, dtype=i32, device=device)          # global parent index of every local child
+        self.mark = torch.zeros(nt, dtype=torch.bool, device=device)    # parents some local child selected
         self.pose = np.zeros(3)
         self.exchange_bytes = dict(weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
 
@@ -76,7 +77,14 @@ class ShardedFilter:
         """self.parent (global indices) -> (compact record table, position of every child's parent in it).  Distinct
         parents only; the ones this rank owns are copied locally, the others requested from their owners."""
         n, world = self.n, self.world
-        uniq, inv = torch.unique(self.parent.to(torch.int64), sorted=True, return_inverse=True)
+        # distinct parents in ascending order (= grouped by owner) and every child's position among them: mark, prefix-sum,
+        # compact -- streaming passes over n_total flags instead of a sort of the children's indices
+        par = self.parent.to(torch.int64)
+        self.mark.zero_()
+        self.mark[par] = True
+        pos = torch.cumsum(self.mark, 0, dtype=torch.int32)
+        uniq = self.mark.nonzero(as_tuple=False).squeeze(1)
+        inv = pos[par] - 1
         self.shard.export_records(self.loc.data_ptr())
         self._sync()
         owner = torch.div(uniq, n, rounding_mode="floor")
