@@ -118,6 +118,7 @@ struct mcl_engine {
     size_t fix_count_alloc = 0;
     int fix_segments = 0;
     uint8_t *d_far = nullptr;           // cap * 4 flags
+    uint32_t *d_far_list = nullptr;     // k_rays_sweep: slots with a flagged quadrant (cap entries, allocated on first use)
     // cell sort for k_rays_cell
     double4 *d_pcs = nullptr;           // cap: pc in sorted order
     double *d_ths = nullptr;            // cap: heading in sorted order
@@ -588,6 +589,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             mcl::PrepClear clr{};
             clr.logw_acc = h->d_logw_acc; clr.far_flags = reinterpret_cast<uint32_t *>(h->d_far);
             clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over; clr.exact_count = h->d_result + 14;
+            if (sweep) clr.far_count = h->d_result + 15;
             if (cell) { clr.bbox = h->d_bbox; clr.hist = h->d_hist; clr.hist_n = mcl::kSortBuckets; }
             hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
                                h->res, h->d_pc, h->d_angle, h->B, cell ? (short4 *)nullptr : h->d_qr, clr);
@@ -637,6 +639,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             if (rc_plan) return rc_plan;
             a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.items = h->d_items; a.nitems = h->nitems; a.unit_sums = h->d_unit_sums; a.slot_space = 1;
+            if (!h->d_far_list) HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
+            a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
         size_t qlds = (size_t)h->qside * h->qside;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
@@ -908,7 +912,7 @@ void mcl_destroy(mcl_engine_t *h)
     graph_reset(h);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);

@@ -409,6 +409,8 @@ struct RayArgs {
     const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, -), big first (guided schedule)
     int nitems;
     const double4 *unit_sums;      // k_rays_sweep: per unit of kSwUnit sorted particles (sum px, sum py, count, -), k_slice_means
+    uint32_t *far_list;            // k_rays_sweep -> k_rays_far: slots with at least one flagged quadrant (appended once each), or null
+    unsigned long long *far_count; // entries in far_list
     int slot_space;                // 1: fix-list entries, far flags and `logw` are indexed by sorted slot (k_rays_sweep), and the
                                    // per-particle constants of k_rays_fix / k_rays_far come from pcs / ths; perm gives the particle
     double *logw;                  // out
@@ -486,6 +488,7 @@ struct PrepClear {
     int fix_words;
     unsigned long long *fix_over;      // 2 words (overflow flag, work counter)
     unsigned long long *exact_count;   // 1 word
+    unsigned long long *far_count;     // 1 word
     int *bbox;                         // 4: +big, +big, -big, -big
     uint32_t *hist;                    // hist_n bucket counters
     uint32_t hist_n;
@@ -503,6 +506,7 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     if (clr.fix_count) for (int64_t k = i; k < clr.fix_words; k += n) clr.fix_count[k] = 0ull;
     if (clr.fix_over) for (int64_t k = i; k < 2; k += n) clr.fix_over[k] = 0ull;
     if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
+    if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
     if (clr.bbox) for (int64_t k = i; k < 4; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (int)0x80000000;
     if (clr.hist) for (int64_t k = i; k < clr.hist_n; k += n) clr.hist[k] = 0u;
     const double t = th[i];
@@ -1786,15 +1790,29 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
     // each wave scans 64 particles' flags with one coalesced load and visits only the flagged ones.  The 64-particle
     // chunks are dealt round-robin over ALL waves of the grid: in sorted-slot order (k_rays_sweep) the flagged particles
     // sit in a few long runs, which a contiguous range per workgroup would hand to a few workgroups
-    for (int64_t i0 = ((int64_t)wave * gridDim.x + blockIdx.x) * 64; i0 < p_end; i0 += (int64_t)kRayWaves * gridDim.x * 64) {
-      const uint32_t myfl = (i0 + lane < p_end) ? flags32[i0 + lane] : 0u;
-      unsigned long long todo = __ballot(myfl != 0u);
+    // With a list of the flagged slots (k_rays_sweep appends a slot when it sets its first flag) every wave takes list entries
+    // round-robin: in sorted-slot order the flagged particles sit in a few long runs, which any partition of the slot range
+    // would hand to a few waves.  Without a list the 64-particle chunks of the flag array are dealt round-robin.
+    const int64_t n_list = a.far_list ? (int64_t)min((unsigned long long)a.n, *a.far_count) : 0;
+    const int64_t wave_global = (int64_t)wave * gridDim.x + blockIdx.x, waves_total = (int64_t)kRayWaves * gridDim.x;
+    for (int64_t i0 = a.far_list ? wave_global : wave_global * 64; i0 < (a.far_list ? n_list : p_end); i0 += a.far_list ? waves_total : waves_total * 64) {
+      uint32_t myfl;
+      unsigned long long todo;
+      int64_t listed = 0;
+      if (a.far_list) {
+          listed = (int64_t)a.far_list[i0];
+          myfl = flags32[listed];
+          todo = 1ull;
+      } else {
+          myfl = (i0 + lane < p_end) ? flags32[i0 + lane] : 0u;
+          todo = __ballot(myfl != 0u);
+      }
       while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int64_t p = i0 + src;                                 // particle index, or sorted slot (slot_space)
+        const int64_t p = a.far_list ? listed : i0 + src;           // particle index, or sorted slot (slot_space)
         const int64_t i = a.slot_space ? (int64_t)a.perm[p] : p;
-        const uint32_t fl = (uint32_t)__shfl((int)myfl, src, 64);
+        const uint32_t fl = a.far_list ? myfl : (uint32_t)__shfl((int)myfl, src, 64);
         if (lane == 0) ++cnt_off;
         const double4 pci = a.slot_space ? a.pcs[p] : a.pc[p];
         const double cth = pci.x, sth = pci.y, gpx = pci.z, gpy = pci.w;

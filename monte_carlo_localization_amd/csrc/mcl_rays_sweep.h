@@ -201,7 +201,11 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         const bool inwin = inx && iny;
         uint32_t i = 0xFFFFFFFFu;                                  // particle index, loaded by the rare paths that need it
         if (!inwin && n1 + n2 > 0) {                           // not in this window (or NaN): k_rays_far does this pair
-            atomicOr(reinterpret_cast<unsigned int *>(a.far_flags) + sl, 1u << (8 * q));      // flags, lists and sums are slot-indexed
+            // flags, lists and sums are slot-indexed; the first flag of a slot also lists it for k_rays_far
+            if (atomicOr(reinterpret_cast<unsigned int *>(a.far_flags) + sl, 1u << (8 * q)) == 0u) {
+                const unsigned long long k = atomicAdd(a.far_count, 1ull);
+                if (k < (unsigned long long)a.n) a.far_list[k] = (uint32_t)sl;
+            }
             n1 = 0; n2 = 0;
         }
         const int total = n1 + n2;
