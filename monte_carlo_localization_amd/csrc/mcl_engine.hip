@@ -70,7 +70,7 @@ struct mcl_engine {
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
     int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), rebuilt when (n, workgroups, G) change
     size_t items_capacity = 0;
-    int nitems = 0, plan_g = 0, plan_nwg = 0;
+    int nitems = 0, plan_g = 0, plan_nwg = 0, plan_P = 0;
     int64_t plan_n = 0;
     double4 *d_unit_sums = nullptr;     // per unit of 1024 sorted particles: (sum px, sum py, count, -)
     size_t unit_sums_capacity = 0;
@@ -447,13 +447,15 @@ void unpack_result(mcl_engine *h)
 // group; the persistent workgroups take them in this order, so they finish within one single-unit item of each other.
 int build_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
 {
-    if (h->d_items && h->plan_n == n && h->plan_nwg == nwg && h->plan_g == g) return MCL_OK;
+    if (h->d_items && h->plan_n == n && h->plan_nwg == nwg && h->plan_g == g && h->plan_P == h->P) return MCL_OK;
     const int ngroups = mcl::kWedges / g;
     const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
     std::vector<int4> items;
     for (int64_t u = 0; u < M;) {
         int64_t c = ((M - u) * ngroups) / (3 * (int64_t)std::max(nwg, 1));
-        c = std::max<int64_t>(1, std::min<int64_t>(4, std::min<int64_t>(c, M - u)));
+        // a narrow window (long range: 256 - (P + 2) - 3 cells of play) is centred on one unit at a time
+        const int64_t run_max = mcl::kSwSide - (h->P + 2) - 3 >= 24 ? 4 : 1;
+        c = std::max<int64_t>(1, std::min<int64_t>(run_max, std::min<int64_t>(c, M - u)));
         for (int k = 0; k < ngroups; ++k) items.push_back(make_int4((int)u, (int)c, (int)((k + u) % ngroups), 0));
         u += c;
     }
@@ -464,7 +466,7 @@ int build_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
     }
     HIPCHK(h, hipMemcpyAsync(h->d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));          // `items` goes out of scope
-    h->nitems = (int)items.size(); h->plan_n = n; h->plan_nwg = nwg; h->plan_g = g;
+    h->nitems = (int)items.size(); h->plan_n = n; h->plan_nwg = nwg; h->plan_g = g; h->plan_P = h->P;
     return MCL_OK;
 }
 
@@ -479,13 +481,14 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip)
     const bool windows_ok = h->quad_ok && h->qside > 0;      // monotone beams over less than a turn, room for a byte window
     if (rk == MCL_RAYS_QUAD) return windows_ok ? 3 : 0;
     if (rk == MCL_RAYS_CELL) return windows_ok ? 4 : 0;
-    if (rk == MCL_RAYS_SWEEP) return windows_ok ? 5 : 0;
+    const bool sweep_ok = windows_ok && mcl::sweep_window_fits(h->P);    // its windows are 256 cells wide (mcl_rays_sweep.h)
+    if (rk == MCL_RAYS_SWEEP) return sweep_ok ? 5 : 0;
     // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
     // with 64-particle groups and enough rays to amortise the sort (measured, wall ms skip / quad / cell:
     // 4096 x 1081 0.16/0.28/0.40, 65536 x 1081 0.55/0.56/0.44, 65536 x 61 0.21/0.33/0.25, 262144 x 61 0.47/0.76/0.40);
     // below that the self-contained k_rays_skip (one launch, no work lists) is the quickest
     const int64_t cell_min = h->env_cell_min > 0 ? h->env_cell_min : 65536;
-    if (windows_ok && n >= cell_min && n * (int64_t)h->B >= (8 << 20)) return 5;
+    if (windows_ok && n >= cell_min && n * (int64_t)h->B >= (8 << 20)) return sweep_ok ? 5 : 4;
     return 2;
 }
 
@@ -578,7 +581,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         h->fix_cap = segcap;
         h->fix_segments = nseg;
         a.qr = cell ? nullptr : h->d_qr;
-        a.qside = h->qside;
+        a.qside = sweep ? mcl::kSwSide : h->qside;
         a.nslices = nsl;
         a.fix_list = h->d_fix_list; a.fix_count = h->d_fix_count; a.fix_cap = h->fix_cap; a.fix_segments = nseg;
         a.exact_list = h->d_exact_list; a.exact_count = h->d_result + 14; a.exact_cap = kExactCap;
@@ -642,7 +645,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             if (!h->d_far_list) HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
-        size_t qlds = (size_t)h->qside * h->qside;
+        size_t qlds = sweep ? (size_t)mcl::kSwSide * mcl::kSwSide : (size_t)h->qside * h->qside;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();

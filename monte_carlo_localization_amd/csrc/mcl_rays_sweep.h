@@ -22,7 +22,14 @@ namespace mcl {
 
 constexpr int kSwUnder = 127;            // table rows below "no hit": samples left in [-127, -1] after an over-long jump
 constexpr int kSwUnit = 1024;            // particles per scheduling unit: one pass of the 16 waves of a workgroup
-constexpr int kSwFx = kQFx;              // 22 fractional bits
+constexpr int kSwFx = 24;                // fractional bits of a window-relative position; the cell index is the top byte
+constexpr int kSwSide = 256;             // window side = LDS row pitch: (cell y, cell x) -> address is one v_perm_b32
+constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
+// fixed-point scale of a direction component: 2^24 - 0.625, so that |component| = 1 rounds to 2^24 - 1 (the operand of
+// v_mad_u32_u24 has 24 bits); the guard pays for it with 0.625 unit per sample
+constexpr double kSwDirScale = 16777216.0 - 0.625;
+
+__host__ __device__ inline bool sweep_window_fits(int P) { return kSwSide - (P + 2) - 3 >= kSwMinExtent; }
 
 // rows of the per-update fp64 table of k_rays_sweep: row r = samples left + kSwUnder, plus one all-zero row
 __host__ __device__ inline int sweep_table_rows(int P) { return P + kSwUnder + 2; }
@@ -64,22 +71,82 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
                                        sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2], 0.0);
 }
 
-// One probe trip on window-relative fixed-point positions that carry the guard bias: T = P0 + G + s * U.
+// One probe trip.  Positions are window-relative fixed point [cell:8][fraction:24] and carry the guard bias G; the window
+// is stored MIRRORED per quadrant so that every ray of the wedge runs towards +x and +y, which makes both direction
+// components unsigned 24-bit operands X and lets the position advance by T += skip * X (v_mad_u32_u24: no end point, no
+// sign).  The LDS address of cell (y, x) in a 256-byte pitch is the two top bytes side by side: one v_perm_b32.
 //   frac(T) < 2G  <=>  the unbiased sample lies within G units of a cell boundary (either side);
 // the cell is read at the biased position, which differs from the true cell only for such a sample.
-#define MCL_SW_TRIP(REM, GIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, NUX, NUY, PEX, PEY, STR, MASK, LB) \
-    "v_mad_i32_i24 " TX ", " REM ", " NUX ", " PEX "\n\t"                                              \
-    "v_mad_i32_i24 " TY ", " REM ", " NUY ", " PEY "\n\t"                                              \
-    "v_lshrrev_b32 " T0 ", 22, " TX "\n\t"                                                             \
-    "v_lshrrev_b32 " T1 ", 22, " TY "\n\t"                                                             \
-    "v_mad_u32_u24 " AD ", " T1 ", " STR ", " T0 "\n\t"                                                \
-    "ds_read_i8 " BY ", " AD " offset:" LB "\n\t"                                                      \
-    "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                           \
-    "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                           \
-    "v_min3_u32 " GOUT ", " GIN ", " T0 ", " T1 "\n\t"                                                 \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
-    "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                \
+// BYIN = the skip that leads to this sample (the own cell's on the first trip, the byte just read afterwards).
+#define MCL_SW_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, XX, XY, SEL, MASK, LB) \
+    "v_mad_u32_u24 " TX ", " BYIN ", " XX ", " TXIN "\n\t"                                                \
+    "v_mad_u32_u24 " TY ", " BYIN ", " XY ", " TYIN "\n\t"                                                \
+    "v_perm_b32 " AD ", " TY ", " TX ", " SEL "\n\t"                                                      \
+    "ds_read_i8 " BY ", " AD " offset:" LB "\n\t"                                                         \
+    "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                              \
+    "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                              \
+    "v_min3_u32 " GOUT ", " GIN ", " T0 ", " T1 "\n\t"                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                            \
+    "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                   \
     "s_andn2_b64 exec, exec, vcc\n\t"
+
+// The beam walk over the slots every live lane of the wave has, as one asm block: all 64 lanes active, no per-slot validity
+// tests.  NEGY = "-" in the quadrants where the sign of the y component differs from x's (see aq / bq below).
+//   v[40:43] direction of the beam (cos, sin); v[44:45] / v[46:47] rotated direction + magic: Xx = v44, Xy = v46, and once
+//   those exist v45 / v47 are the trip's scratch; v[48:49] product, then LDS address / cell byte / table offset;
+//   v[50:51] pending table entry; v54 v55 T; v56 guard minimum; v57 samples left
+#define MCL_SW_WALK(NEGY)                                                                                                      \
+    asm volatile(                                                                                                              \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
+        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0: keeps the vmcnt pattern of the steady state */                 \
+        "3:\n\t"                                                                                                               \
+        "s_waitcnt vmcnt(1)\n\t" /* direction landed (the table entry may be in flight) */                                     \
+        "v_mul_f64 v[48:49], %[bq], v[42:43]\n\t"                                                                              \
+        "v_fma_f64 v[44:45], %[aq], v[40:41], -v[48:49]\n\t"                                                                   \
+        "v_mul_f64 v[48:49], %[aq], v[42:43]\n\t"                                                                              \
+        "v_fma_f64 v[46:47], %[bq], v[40:41], v[48:49]\n\t"                                                                    \
+        "v_add_f64 v[44:45], v[44:45], %[magic]\n\t"                                                                           \
+        "v_add_f64 v[46:47], " NEGY "v[46:47], %[magic]\n\t"                                                                   \
+        "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t" /* next beam's direction */                                         \
+        "s_movk_i32 %[cd], 300\n\t"                                                                                            \
+        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[sel]", "%[mask]", "%[lb]") \
+        "s_cbranch_execz 2f\n"                                                                                                 \
+        "1:\n\t"                                                                                                               \
+        MCL_SW_TRIP("v57", "v56", "v49", "v54", "v55", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[sel]", "%[mask]", "%[lb]") \
+        "s_cbranch_execz 2f\n\t"                                                                                               \
+        "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 1b\n\t"                                                                                                \
+        "s_mov_b32 %[expired], 1\n" /* malformed window (impossible): the pass is redone by the fix-up path */                 \
+        "2:\n\t"                                                                                                               \
+        "s_mov_b64 exec, -1\n\t"                                                                                               \
+        "v_cmp_gt_u32 vcc, %[thr], v56\n\t" /* undecided: a sample within the guard of a boundary */                           \
+        "s_cbranch_vccz 4f\n\t"                                                                                                \
+        "s_mov_b64 exec, vcc\n\t"                                                                                              \
+        "v_mov_b32 %[ambj2], %[ambj1]\n\t"                                                                                     \
+        "v_mov_b32 %[ambj1], %[j16]\n\t" /* (beam + 1) << 4 */                                                                 \
+        "v_add_u32 %[ambcnt], 1, %[ambcnt]\n\t"                                                                                \
+        "v_mov_b32 v57, %[zrow]\n\t"                                                                                           \
+        "s_mov_b64 exec, -1\n"                                                                                                 \
+        "4:\n\t"                                                                                                               \
+        "s_waitcnt vmcnt(1)\n\t" /* previous beam's table entry landed */                                                      \
+        "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
+        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
+        "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"                                                                                \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
+        "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 3b\n\t"                                                                                                \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[50:51]"                                                                                   \
+        : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2), \
+          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
+        : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e),       \
+          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_cs), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
+          [sel] "s"(permsel), [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff),          \
+          [lb] "n"(kQLdsBase)                                                                                                  \
+        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
+          "v55", "v56", "v57")
 
 template <bool COUNT>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
@@ -93,17 +160,16 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const int G = a.sweep_g;                                   // wedges per work item (divides kWedges)
     const int nitems = a.nitems;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
-    const int S = a.qside;
-    // level-1 error bound: 0.5 unit for the origin + 0.5 unit per sample for the direction, s <= P samples (+4)
-    const uint32_t guard_units = (uint32_t)(a.P + 1) / 2u + 5u;
+    constexpr int S = kSwSide;
+    // level-1 error bound per axis, in units of 2^-24 px: 0.5 for the origin + (0.5 rounding + 0.625 scale, kSwDirScale)
+    // per sample, s <= P + 1 samples, + 5 for the fp64 rounding of the rotated direction
+    const uint32_t guard_units = (9u * (uint32_t)(a.P + 1) + 7u) / 8u + 6u;
     const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : 2u * guard_units;
     const uint32_t fmask = (1u << kSwFx) - 1u;
-    const int negP = __builtin_amdgcn_readfirstlane(-a.P);
+    const uint32_t permsel = 0x0C0C0703u;                      // v_perm_b32(Ty, Tx): byte 0 = Tx[31:24], byte 1 = Ty[31:24], rest 0
     const uint32_t st8 = (uint32_t)__builtin_amdgcn_readfirstlane(a.ltd_cols * 8);
     const uint32_t zrow = (uint32_t)(a.P + 1);                 // "samples left" that selects the all-zero row
     const unsigned char *ldsb = lds_raw;
-    uint32_t stride_v = (uint32_t)S;
-    asm volatile("" : "+v"(stride_v));
     if (threadIdx.x == 0) fixn_sh = 0u;                        // published by the first barrier of the item loop
     // the segment belongs to this workgroup alone: the append counter lives in LDS and entries are plain stores (the list
     // is read by k_rays_fix, a later kernel); the count goes to memory once, at the end
@@ -132,6 +198,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const int kbin = grp * G + gw;
     const int q = kbin >> kWedgeShift;
     const int sxp = (q == 0 || q == 3), syp = (q == 0 || q == 1);
+    const bool negy = sxp != syp;
     const int mlo = 3;
     int wx0, wy0;
     {
@@ -143,14 +210,14 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         wy0 = syp ? cym - back : cym + back - S;
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
         const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
-        const int wpr = S >> 3;
-        const int nwords = wpr * S;
-        const int drow = kRayThreads / wpr, dcw = kRayThreads - drow * wpr;
-        int row = (int)threadIdx.x / wpr, cw = (int)threadIdx.x - row * wpr;
+        constexpr int wpr = S >> 3, nwords = wpr * S;
         if (gw > 0) __syncthreads();                                       // every wave is done with the previous window
-        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads, row += drow, cw += dcw) {
-            if (cw >= wpr) { cw -= wpr; ++row; }
-            int gy = wy0 + row, gx = wx0 + cw * 8;
+        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
+            const int row = wi / wpr, cw = wi - row * wpr;
+            // LDS cell (row, col) = grid cell (wy0 + row, wx0 + col), mirrored in the axes along which the wedge's rays
+            // run backwards: word cw of a mirrored row is the source word at the far end with its bytes reversed
+            const int gy = syp ? wy0 + row : wy0 + (S - 1) - row;
+            const int gx = sxp ? wx0 + cw * 8 : wx0 + (S - 8) - cw * 8;
             // the wedge fields are stored in the LDS encoding (stop = 0xFF, skips 1..127); outside the grid is stop
             uint64_t b8 = ~0ull;
             if (gy >= 0 && gy < a.Hp) {
@@ -162,7 +229,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         if (gx + k >= 0 && gx + k < a.Wp) b8 = (b8 & ~(0xFFull << (8 * k))) | ((uint64_t)rowp[gx + k] << (8 * k));
                 }
             }
-            win[wi] = b8;
+            win[wi] = sxp ? b8 : __builtin_bswap64(b8);
         }
         __syncthreads();
     }
@@ -212,18 +279,23 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // a lane without rays gets a zero direction and zero samples from the window's cell (2, 2): every probe it
         // makes reads that cell, whose byte is never 0, and leaves the loop at once; its table column is the zero column B
         const bool live = total > 0;
-        const double lpx = live ? wpx : 2.5, lpy = live ? wpy : 2.5;
+        // position in the mirrored window (the rays of the wedge run towards +x, +y there)
+        const double lpx = live ? (sxp ? wpx : (double)S - wpx) : 2.5, lpy = live ? (syp ? wpy : (double)S - wpy) : 2.5;
         const double p0x = lpx + kMagic, p0y = lpy + kMagic;
         const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
         const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
-        const int d0 = ldsb[cy0 * S + cx0];
+        const int d0 = ldsb[((cy0 & (S - 1)) << 8) | (cx0 & (S - 1))];
         const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
+        // no stop within range: look at sample P only (it is free: the skip says so), which ends the walk with "no hit"
+        const uint32_t s0e = (uint32_t)(s0 <= a.P ? s0 : a.P);
         const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
-        // window-relative origin in 2^-22 px, biased by the guard (see MCL_SW_TRIP)
-        const uint32_t P0x = (uint32_t)rint_i32(lpx * 4194304.0 - 2147483648.0) + 0x80000000u + guard_units;
-        const uint32_t P0y = (uint32_t)rint_i32(lpy * 4194304.0 - 2147483648.0) + 0x80000000u + guard_units;
-        const int rem_start = (live && s0 <= a.P) ? a.P - s0 : 0;
-        const double ncth = live ? -pci.x * 4194304.0 : 0.0, sths = live ? pci.y * 4194304.0 : 0.0;
+        // window-relative origin in 2^-24 px, biased by the guard (see MCL_SW_TRIP)
+        const uint32_t P0x = (uint32_t)rint_i32(lpx * 16777216.0 - 2147483648.0) + 0x80000000u + guard_units;
+        const uint32_t P0y = (uint32_t)rint_i32(lpy * 16777216.0 - 2147483648.0) + 0x80000000u + guard_units;
+        const int rem_start = live ? a.P - (int)s0e : 0;
+        // direction components in the mirrored window: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
+        const double dsc = sxp ? kSwDirScale : -kSwDirScale;
+        const double aq = live ? pci.x * dsc : 0.0, bq = live ? pci.y * dsc : 0.0;
         int tmax = total, tmin = live ? total : 0x7fffffff;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { tmax = max(tmax, __shfl_xor(tmax, o, 64)); tmin = min(tmin, __shfl_xor(tmin, o, 64)); }
@@ -237,69 +309,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         int t_done = 0;
         bool expired_fast = false;
         if (!COUNT && !a.steps && !wraps && tmax > 0 && tmin > 0) {
-            // ---- the slots every live lane has: one asm block, all 64 lanes active, no per-slot validity tests ----
-            // v[40:43] direction of the beam (cos, sin); v[44:45] / v[46:47] rotated direction + magic: NUx = v44, NUy = v46, and
-            // once those exist v45 / v47 are the trip's scratch; v[48:49] product, then LDS address / cell byte / table offset;
-            // v[50:51] pending table entry; v52 v53 Pe; v54 v55 T; v56 guard minimum; v57 samples left
             uint32_t j16 = live ? (uint32_t)jfirst << 4 : 0u;
             // table column offset, biased by kSwUnder rows so that (samples left) * row bytes + j8b is never negative
             uint32_t j8b = (uint32_t)kSwUnder * st8 + (live ? (uint32_t)jfirst << 3 : (uint32_t)a.B << 3);
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             uint32_t tc = (uint32_t)tmin - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
-            asm volatile(
-                "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"
-                "v_mov_b32 v48, %[zoff]\n\t"
-                "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"             // 0.0: keeps the vmcnt pattern of the steady state
-                "3:\n\t"
-                "s_waitcnt vmcnt(1)\n\t"                                    // direction landed (the table entry may be in flight)
-                "v_mul_f64 v[48:49], %[sths], v[42:43]\n\t"
-                "v_fma_f64 v[44:45], %[ncth], v[40:41], v[48:49]\n\t"
-                "v_mul_f64 v[48:49], %[sths], v[40:41]\n\t"
-                "v_fma_f64 v[46:47], %[ncth], v[42:43], -v[48:49]\n\t"
-                "v_add_f64 v[44:45], v[44:45], %[magic]\n\t"
-                "v_add_f64 v[46:47], v[46:47], %[magic]\n\t"
-                "v_add_u32 %[j16], %[j16], %[inc16]\n\t"
-                "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"          // next beam's direction
-                "v_mad_i32_i24 v52, %[negp], v44, %[p0x]\n\t"
-                "v_mad_i32_i24 v53, %[negp], v46, %[p0y]\n\t"
-                "s_movk_i32 %[cd], 300\n\t"
-                MCL_SW_TRIP("%[rem0]", "%[g0]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "v52", "v53", "%[str]", "%[mask]", "%[lb]")
-                "s_cbranch_execz 2f\n"
-                "1:\n\t"
-                MCL_SW_TRIP("v57", "v56", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "v52", "v53", "%[str]", "%[mask]", "%[lb]")
-                "s_cbranch_execz 2f\n\t"
-                "s_sub_u32 %[cd], %[cd], 1\n\t"
-                "s_cbranch_scc0 1b\n\t"
-                "s_mov_b32 %[expired], 1\n"                                 // malformed window (impossible): the pass is redone by the fix-up path
-                "2:\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_cmp_gt_u32 vcc, %[thr], v56\n\t"                         // undecided: a sample within the guard of a boundary
-                "s_cbranch_vccz 4f\n\t"
-                "s_mov_b64 exec, vcc\n\t"
-                "v_mov_b32 %[ambj2], %[ambj1]\n\t"
-                "v_mov_b32 %[ambj1], %[j16]\n\t"                            // (beam + 1) << 4
-                "v_add_u32 %[ambcnt], 1, %[ambcnt]\n\t"
-                "v_mov_b32 v57, %[zrow]\n\t"
-                "s_mov_b64 exec, -1\n"
-                "4:\n\t"
-                "s_waitcnt vmcnt(1)\n\t"                                    // previous beam's table entry landed
-                "v_add_f64 %[acc], %[acc], v[50:51]\n\t"
-                "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"
-                "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"
-                "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"
-                "s_sub_u32 %[tc], %[tc], 1\n\t"
-                "s_cbranch_scc0 3b\n\t"
-                "s_waitcnt vmcnt(0)\n\t"
-                "v_add_f64 %[acc], %[acc], v[50:51]"
-                : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2),
-                  [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)
-                : [ncth] "v"(ncth), [sths] "v"(sths), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0),
-                  [inc16] "v"(inc16), [inc8] "v"(inc8), [str] "v"(stride_v), [csb] "s"(a.beam_cs), [ltb] "s"(a.Ltd), [negp] "s"(negP),
-                  [st8] "s"(st8), [mask] "s"(fmask), [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff),
-                  [lb] "n"(kQLdsBase)
-                : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
-                  "v54", "v55", "v56", "v57");
+            if (negy) MCL_SW_WALK("-"); else MCL_SW_WALK("");
             t_done = tmin;
             expired_fast = expired != 0u;
         }
@@ -323,10 +339,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     if (wraps && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
                     j = min(jn, jlast);
                 }
-                const int NUx = rint_i32(__builtin_fma(ncth, cs.x, sths * cs.y));
-                const int NUy = rint_i32(__builtin_fma(ncth, cs.y, -(sths * cs.x)));
+                const uint32_t Xx = (uint32_t)rint_i32(__builtin_fma(aq, cs.x, -(bq * cs.y)));
+                const double yd = __builtin_fma(bq, cs.x, aq * cs.y);
+                const uint32_t Xy = (uint32_t)rint_i32(negy ? -yd : yd);
                 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
-                const uint32_t Pex = mad_i24_s(negP, NUx, P0x), Pey = mad_i24_s(negP, NUy, P0y);
                 int rem;
                 uint32_t g;
                 bool expired = false;
@@ -337,10 +353,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     asm volatile(
                         "s_mov_b64 %[sv], exec\n\t"
                         "s_movk_i32 %[cd], 300\n\t"
-                        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[nux]", "%[nuy]", "%[pex]", "%[pey]", "%[str]", "%[mask]", "%[lb]")
+                        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[sel]", "%[mask]", "%[lb]")
                         "s_cbranch_execz 2f\n"
                         "1:\n\t"
-                        MCL_SW_TRIP("%[rem]", "%[g]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[nux]", "%[nuy]", "%[pex]", "%[pey]", "%[str]", "%[mask]", "%[lb]")
+                        MCL_SW_TRIP("%[rem]", "%[g]", "%[by]", "%[tx]", "%[ty]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[sel]", "%[mask]", "%[lb]")
                         "s_cbranch_execz 2f\n\t"
                         "s_sub_u32 %[cd], %[cd], 1\n\t"
                         "s_cbranch_scc0 1b\n"
@@ -348,8 +364,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         "s_mov_b64 exec, %[sv]"
                         : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
                           [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
-                        : [rem0] "v"(rem_start), [g0] "v"(g0), [nux] "v"(NUx), [nuy] "v"(NUy), [pex] "v"(Pex), [pey] "v"(Pey), [str] "v"(stride_v),
-                          [mask] "s"(fmask), [lb] "n"(kQLdsBase)
+                        : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
+                          [mask] "s"(fmask), [sel] "s"(permsel), [lb] "n"(kQLdsBase)
                         : "memory", "vcc", "scc");
                     // the countdown only expires if the window is malformed (impossible): every ray of the pass to the fix-up list
                     expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
@@ -358,13 +374,15 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     int trips = 0;
                     rem = rem_start;
                     g = g0;
+                    uint32_t Tx = P0x, Ty = P0y, by = s0e;
                     do {
-                        const uint32_t Tx = mad_i24(rem, NUx, Pex), Ty = mad_i24(rem, NUy, Pey);
+                        Tx += (by & 0xFFFFFFu) * (Xx & 0xFFFFFFu);
+                        Ty += (by & 0xFFFFFFu) * (Xy & 0xFFFFFFu);
                         const uint32_t gm = (Tx & fmask) < (Ty & fmask) ? (Tx & fmask) : (Ty & fmask);
                         g = g < gm ? g : gm;
-                        const uint32_t byte = (uint32_t)(int)(int8_t)ldsb[(Ty >> kSwFx) * (uint32_t)S + (Tx >> kSwFx)];
+                        by = (uint32_t)(int)(int8_t)ldsb[((Ty >> kSwFx) << 8) | (Tx >> kSwFx)];
                         uint32_t nr;
-                        const bool over = __builtin_usub_overflow((uint32_t)rem, byte, &nr);
+                        const bool over = __builtin_usub_overflow((uint32_t)rem, by, &nr);
                         go = !over;
                         rem = (int)nr;
                         cnt_probe += (go && valid) ? 1 : 0;

@@ -16,7 +16,9 @@ def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_o
     scan, _ = orc.cast_many(om, np.zeros(ang.size), np.zeros(ang.size), ang.astype(np.float64))
     rng = np.random.default_rng(1)
     N = 777
-    p = tracking_cloud(rng, N)
+    # k_rays_sweep's 256-cell windows leave 44 cells of play on this map: a cloud that stays inside them keeps the ray
+    # counts below exact (off-window pairs are k_rays_far's, which has no level 2)
+    p = tracking_cloud(rng, N, sig=(0.3, 0.3, 0.4)) if kernel[0] == "w" else tracking_cloud(rng, N)
     cfg = dict(keep_ray_steps=1, debug_count_probes=1)
     cfg["ray_kernel"] = {"m": engine_mod.RAYS_MARCH, "s": engine_mod.RAYS_SKIP, "q": engine_mod.RAYS_QUAD, "c": engine_mod.RAYS_CELL,
                          "w": engine_mod.RAYS_SWEEP}[kernel[0]]

@@ -428,7 +428,10 @@ def test_tight_cluster_near_map_corner(orc, engine_mod, sibal1, sibal1_oracle, p
     L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
     logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L, want_steps=True)
     assert np.array_equal(e.ray_steps(), steps)
-    assert e.counters()["off_window_particles"] == 0
+    # k_rays_sweep's windows are 256 cells wide: at this map's 240-px range they leave 11 cells of play, less than the
+    # cluster's 24 cells, and the rest of the cluster goes through k_rays_far (same steps, checked above)
+    if path != "sweep":
+        assert e.counters()["off_window_particles"] == 0
 
 
 # ------------------------------------------------------------------------------------------- cell-sorted path

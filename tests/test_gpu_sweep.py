@@ -43,8 +43,12 @@ def test_tracking_cloud_1081_beams(orc, engine_mod, spielberg, spielberg_oracle,
     overflow of the beam walk into the fix-up list (level 2 / level 3): nothing may be counted twice or lost."""
     ang = orc.beam_angles(angle_step=1)
     n = {0: 8192, 2: 2048, 1: 512}[force]
-    p = tracking_cloud(np.random.default_rng(3), n)
+    # the forced cases count rays: keep every particle inside its window (off-window pairs go to k_rays_far, which traces
+    # in fp64 and never uses the fix-up list)
+    p = tracking_cloud(np.random.default_rng(3), n, sig=(0.5, 0.5, 0.4) if force == 0 else (0.2, 0.2, 0.4))
     got, c = sweep_logw(engine_mod, spielberg, ang, p, scan1081(), debug_force_exact=force)
+    if force:
+        assert c["off_window_particles"] == 0
     assert np.array_equal(got, oracle_logw(orc, spielberg_oracle, p, ang, scan1081()))
     if force == 0:
         assert 0 < c["level2_rays"] < n * ang.size // 100
