@@ -95,9 +95,9 @@ def roofline_block(kernel_name, k_ms, n, B, sbar):
     gfx950 issues a wave64 instruction of the simple classes (v_add/v_sub/v_and/v_or/v_lshrrev/v_mov, fp32 add/mul/fma) in
     2 cycles and everything else the kernel uses (v_mad_*24, 3-operand integer ops, compares, conversions, all fp64) in 4
     (profiles/r02_op_rates.txt).  With I = VALU instructions and T = probe trips per launch (SQ_INSTS_VALU, SQ_INSTS_LDS:
-    one ds_read per trip), a trip is 5 four-cycle + 4 two-cycle instructions and the rest of the stream is 11/13
+    one ds_read per trip), a trip is 5 four-cycle + 2 two-cycle instructions and the rest of the stream is 9/11
     four-cycle (mcl_rays_sweep.h), so the launch needs at least
-        cycles = 4 I - 2 (4 T + (2/13) (I - 9 T))
+        cycles = 4 I - 2 (2 T + (2/11) (I - 7 T))
     SIMD issue cycles; the chip offers SIMDS x clock of them per second.  `frac` prices that against the MAXIMUM clock,
     so it cannot exceed 1; `valu.at_measured_mix_rate` is the same with the rate tools/ubench/valu_rates.hip measures
     for this exact instruction sequence (two-cycle instructions next to four-cycle ones do not reach 2) and the clock the
@@ -115,7 +115,7 @@ def roofline_block(kernel_name, k_ms, n, B, sbar):
             inp = None
     if inp and inp.get("kernel") == kernel_name and inp.get("particles") == n and inp.get("beams") == B:
         I, T = inp["valu_insts_per_launch"], inp["lds_insts_per_launch"]
-        cycles = 4.0 * I - 2.0 * (4.0 * T + (2.0 / 13.0) * (I - 9.0 * T))
+        cycles = 4.0 * I - 2.0 * (2.0 * T + (2.0 / 11.0) * (I - 7.0 * T))
         floor_ms = cycles / (SIMDS * MAX_CLOCK_GHZ * 1e6)
         mix_floor_ms = I * inp["cycles_per_valu_inst"] / (SIMDS * inp["clock_ghz"] * 1e6)
         block.update({"achieved": cycles / (k_ms * 1e-3) / 1e9, "peak": SIMDS * MAX_CLOCK_GHZ, "unit": "G SIMD issue cycles/s",

@@ -11,6 +11,8 @@ R=$(pwd)
 # (cp gpurun_out/profiles_new/* profiles/); bench.py's roofline block needs the inputs file in profiles/ while it runs
 PROF="$OUT/profiles_new"
 mkdir -p "$OUT" "$PROF"
+[ -x tools/ubench/valu_rates ] && [ tools/ubench/valu_rates -nt tools/ubench/valu_rates.hip ] || \
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rates.hip -o tools/ubench/valu_rates
 ./tools/ubench/valu_rates > "$PROF/${TAG}_valu_rates.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o t -- python3 "$R/bench.py" --steps 10 --no-cpu-baseline > "$R/$OUT/prof.log" 2>&1

@@ -21,10 +21,10 @@ enum Kind { FMA_F32, PK_FMA_F32, MAD_I24, FMA_F64, ADD_F64, MUL_F64, ADD_U32, LS
 static const char *kind_name[NKIND] = {"v_fma_f32", "v_pk_fma_f32", "v_mad_i32_i24", "v_fma_f64", "v_add_f64", "v_mul_f64", "v_add_u32",
                                        "v_lshl_add_u32", "v_min3_u32", "v_sub_co_u32", "v_cvt_f64_f32",
                                        "k_rays_cell probe trip, 9 VALU (no LDS read)", "k_rays_cell probe trip, 9 VALU + ds_read_i8 + wait",
-                                       "k_rays_sweep probe trip, 9 VALU (no LDS read)",
-                                       "k_rays_sweep whole beam: 14 per-ray VALU + 5 trips (no memory)"};
+                                       "k_rays_sweep probe trip, 7 VALU (no LDS read)",
+                                       "k_rays_sweep whole beam: 11 per-ray VALU + 5 trips (no memory)"};
 // VALU instructions per "unit" of 32 asm statements (the probe bodies are 9 VALU, repeated 4x per iteration = 36)
-static const int kind_insts[NKIND] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 36, 36, 36, 59};
+static const int kind_insts[NKIND] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 36, 36, 28, 46};
 
 struct Stamp { unsigned long long cyc, ref; unsigned hwid, xcc, sink, pad; };
 
@@ -96,45 +96,43 @@ __global__ __launch_bounds__(1024) void k(Stamp *out, int iters, unsigned seed)
 #undef S
         } else if constexpr (KIND == SWEEP_TRIP || KIND == SWEEP_BEAM) {
             // k_rays_sweep (mcl_rays_sweep.h): MCL_SW_TRIP without the LDS read, and the whole per-beam instruction stream
-            // (direction rotation + rounding, next-beam bookkeeping, Pe, five trips, guard test, table offset, accumulate)
+            // (direction rotation + rounding, next-beam bookkeeping, five trips, guard test, table offset, accumulate)
 #define SW_TRIP                                                \
-    "v_mad_i32_i24 %[tx], %[rem], %[nux], %[pex]\n\t"          \
-    "v_mad_i32_i24 %[ty], %[rem], %[nuy], %[pey]\n\t"          \
-    "v_lshrrev_b32 %[t0], 22, %[tx]\n\t"                        \
-    "v_lshrrev_b32 %[t1], 22, %[ty]\n\t"                        \
-    "v_mad_u32_u24 %[ad], %[t1], %[str], %[t0]\n\t"            \
+    "v_mad_u32_u24 %[tx], %[ad], %[nux], %[tx]\n\t"            \
+    "v_mad_u32_u24 %[ty], %[ad], %[nuy], %[ty]\n\t"            \
+    "v_perm_b32 %[ad], %[ty], %[tx], %[str]\n\t"               \
     "v_and_b32 %[t0], %[gb], %[tx]\n\t"                         \
     "v_and_b32 %[t1], %[gb], %[ty]\n\t"                         \
     "v_min3_u32 %[g], %[g], %[t0], %[t1]\n\t"                  \
     "v_sub_co_u32 %[rem], vcc, %[rem], %[ad]\n\t"
-            unsigned tx, ty, t0v, t1v, ad;
+            unsigned tx = a4, ty = a5, t0v, t1v, ad = a6;
             if constexpr (KIND == SWEEP_TRIP) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     asm volatile(SW_TRIP
-                                 : [tx] "=&v"(tx), [ty] "=&v"(ty), [t0] "=&v"(t0v), [t1] "=&v"(t1v), [ad] "=&v"(ad), [g] "+v"(a1), [rem] "+v"(a0)
-                                 : [nux] "v"(a2), [nuy] "v"(a3), [pex] "v"(a4), [pey] "v"(a5), [str] "v"(stride), [gb] "v"(gb)
+                                 : [tx] "+v"(tx), [ty] "+v"(ty), [t0] "=&v"(t0v), [t1] "=&v"(t1v), [ad] "+v"(ad), [g] "+v"(a1), [rem] "+v"(a0)
+                                 : [nux] "v"(a2), [nuy] "v"(a3), [str] "v"(stride), [gb] "v"(gb)
                                  : "vcc");
+                a4 = tx; a5 = ty; a6 = ad;
             } else {
                 asm volatile(
                     "v_mul_f64 %[p], %[sd], %[dy]\n\t"
-                    "v_fma_f64 %[ax], %[cd], %[dx], %[p]\n\t"
-                    "v_mul_f64 %[p], %[sd], %[dx]\n\t"
-                    "v_fma_f64 %[ay], %[cd], %[dy], -%[p]\n\t"
+                    "v_fma_f64 %[ax], %[cd], %[dx], -%[p]\n\t"
+                    "v_mul_f64 %[p], %[cd], %[dy]\n\t"
+                    "v_fma_f64 %[ay], %[sd], %[dx], %[p]\n\t"
                     "v_add_f64 %[ax], %[ax], %[mg]\n\t"
                     "v_add_f64 %[ay], %[ay], %[mg]\n\t"
                     "v_add_u32 %[j16], %[j16], %[str]\n\t"
-                    "v_mad_i32_i24 %[pex], %[str], %[nux], %[pex]\n\t"
-                    "v_mad_i32_i24 %[pey], %[str], %[nuy], %[pey]\n\t"
                     SW_TRIP SW_TRIP SW_TRIP SW_TRIP SW_TRIP
                     "v_cmp_gt_u32 vcc, %[gb], %[g]\n\t"
                     "v_add_f64 %[acc], %[acc], %[dx]\n\t"
                     "v_mad_i32_i24 %[ad], %[rem], %[str], %[j8]\n\t"
                     "v_add_u32 %[j8], %[j8], %[str]\n\t"
-                    : [tx] "=&v"(tx), [ty] "=&v"(ty), [t0] "=&v"(t0v), [t1] "=&v"(t1v), [ad] "=&v"(ad), [g] "+v"(a1), [rem] "+v"(a0),
-                      [p] "=&v"(d0), [ax] "=&v"(d1), [ay] "=&v"(d2), [acc] "+v"(d3), [j16] "+v"(a6), [j8] "+v"(a7), [pex] "+v"(a4), [pey] "+v"(a5)
+                    : [tx] "+v"(tx), [ty] "+v"(ty), [t0] "=&v"(t0v), [t1] "=&v"(t1v), [ad] "+v"(ad), [g] "+v"(a1), [rem] "+v"(a0),
+                      [p] "=&v"(d0), [ax] "=&v"(d1), [ay] "=&v"(d2), [acc] "+v"(d3), [j16] "+v"(a6), [j8] "+v"(a7)
                     : [nux] "v"(a2), [nuy] "v"(a3), [str] "v"(stride), [gb] "v"(gb), [sd] "v"(d4), [cd] "v"(d5), [dx] "v"(d6), [dy] "v"(d7), [mg] "v"(cd)
                     : "vcc");
+                a4 = tx; a5 = ty;
             }
         } else {
             // the probe loop body of k_rays_cell (mcl_kernels.h): rem in a0, g in a1; 4 trips per iteration
