@@ -45,6 +45,7 @@ struct mcl_engine {
     std::vector<double> table;          // (P+1)^2 column-major (d*(P+1)+r)
     int8_t *d_grid = nullptr;
     uint8_t *d_dist = nullptr;
+    uint8_t *d_dist4 = nullptr;         // nibble-packed copy of d_dist (k_rays_skip's LDS window is a straight copy of it)
     uint8_t *d_distq[4]{};              // directional skip fields, one per quadrant (k_rays_quad / k_rays_far)
     float *d_L = nullptr;               // [r_obs][d]
     double *d_table = nullptr;          // double table (product mode)
@@ -130,6 +131,7 @@ struct mcl_engine {
     size_t slice_mean_capacity = 0;
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell, 5 sweep
+    bool pc_ready = false;              // d_pc already holds the constants of the current particles (written by k_resample_motion)
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
     unsigned long long *d_result = nullptr;   // [0..7] scalars, [8..11] counters, [12..13] overflow flag + work counter: one D2H copy
     unsigned long long *h_result = nullptr;   // pinned mirror of d_result
@@ -509,7 +511,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.steps = h->cfg.keep_ray_steps ? h->d_steps : nullptr;
     a.grid = h->d_grid; a.W = h->W; a.H = h->H;
     a.res = h->res; a.ox = h->ox; a.oy = h->oy;
-    a.dist = h->d_dist; a.Wp = h->Wp; a.Hp = h->Hp; a.Wps = h->Wps;
+    a.dist = h->d_dist; a.dist4 = h->d_dist4; a.Wp = h->Wp; a.Hp = h->Hp; a.Wps = h->Wps;
     for (int q = 0; q < 4; ++q) a.distq[q] = h->d_distq[q];
     a.tw_cells = h->tw_cells;
     a.counters = h->d_counters;
@@ -523,7 +525,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     const bool sweep = mode == 5;
     int64_t want = (n + 15) / 16;
     int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cu, want));
-    if (mode == 2)
+    if (mode == 2 && !h->pc_ready)             // (an update's resampling kernel has already left them in d_pc otherwise)
         hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
                            h->res, h->d_pc, h->d_angle, h->B, (short4 *)nullptr, mcl::PrepClear{});
     const bool count = h->cfg.debug_count_probes != 0;
@@ -700,6 +702,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     }
     if (!windows && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
     h->last_mode = mode;
+    if (!h->capturing) h->pc_ready = false;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -759,8 +762,10 @@ int weights_and_cdf(mcl_engine *h)
 {
     const int64_t n = h->N;
     if (h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0 && n <= mcl::kTinyTailMax) {
-        hipLaunchKernelGGL(mcl::k_tiny_tail, dim3(1), dim3(1024), 0, h->stream, h->d_logw, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n,
-                           h->d_w, h->d_q, h->d_cdf, h->d_scalars);
+        // d_pc holds (cos, sin) of the current headings whenever a ray kernel other than the literal march ran on them
+        const double4 *pc = h->last_mode >= 2 ? h->d_pc : nullptr;
+        hipLaunchKernelGGL(mcl::k_tiny_tail, dim3(1), dim3(1024), (size_t)n * sizeof(uint64_t), h->stream, h->d_logw, h->d_x[h->cur],
+                           h->d_y[h->cur], h->d_th[h->cur], pc, n, h->d_w, h->d_q, h->d_cdf, h->d_scalars);
         HIPCHK(h, hipGetLastError());
         h->max_partials_ready = false;
         h->carry_pending = false;
@@ -900,6 +905,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_tiny_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #undef CRT
@@ -916,7 +922,7 @@ void mcl_destroy(mcl_engine_t *h)
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
-    dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
+    dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
@@ -954,7 +960,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     std::vector<uint8_t> dist;
     build_distance_field(data, h->W, h->H, h->Wp, h->Hp, h->Wps, dist);
     h->have_map = false;                 // until every buffer below exists again: a failure leaves "map not set", never dangling pointers
-    dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_L); dfree(h->d_table);
+    dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     HIPCHK(h, hipMalloc(&h->d_grid, (size_t)h->W * h->H));
     HIPCHK(h, hipMalloc(&h->d_dist, dist.size()));
@@ -962,6 +968,13 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     HIPCHK(h, hipMalloc(&h->d_table, h->table.size() * sizeof(double)));
     HIPCHK(h, hipMemcpy(h->d_grid, data, (size_t)h->W * h->H, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_dist, dist.data(), dist.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<uint8_t> d4(dist.size() / 2);          // Wps is a multiple of 8
+        for (size_t k = 0; k < d4.size(); ++k)
+            d4[k] = (uint8_t)(std::min<int>(dist[2 * k], 15) | (std::min<int>(dist[2 * k + 1], 15) << 4));
+        HIPCHK(h, hipMalloc(&h->d_dist4, d4.size()));
+        HIPCHK(h, hipMemcpy(h->d_dist4, d4.data(), d4.size(), hipMemcpyHostToDevice));
+    }
     if (h->qside > 0) {
         static const int qsx[4] = {1, -1, -1, 1}, qsy[4] = {1, 1, -1, -1};
         std::vector<uint8_t> dq;
@@ -1241,8 +1254,9 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     }
     if (h->cfg.resample_neff_permille > 0 && h->cfg.weight_mode == MCL_WEIGHT_PRODUCT)
         return fail(h, MCL_ERR_UNSUPPORTED, "resample_neff_permille needs weight_mode LOG");
-    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    if (!resample_and_move) HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));   // else: the resampling kernel
     HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
+    h->pc_ready = false;
     if (resample_and_move) {
         const int c = h->cur, nx = c ^ 1;
         mcl::ResampleArgs a{};
@@ -1274,7 +1288,15 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         motion_scalars(action, a.dt, a.v, a.w);
         a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
         a.do_resample = keep ? 0 : 1; a.do_motion = 1;
-        hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+        a.clear_counters = h->d_counters;
+        if (choose_ray_mode(h, n, false) == 2) {
+            // k_rays_skip follows: its per-particle constants come out of this kernel (one launch less per small update)
+            a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
+            h->pc_ready = true;
+        }
+        size_t cdf_lds = 0;
+        if (!a.tile_excl && a.do_resample && n <= mcl::kTinyTailMax) { a.cdf_lds_entries = (int)n; cdf_lds = (size_t)n * sizeof(uint64_t); }
+        hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, a);
         HIPCHK(h, hipGetLastError());
         h->cur = nx;                       // cpp:689 as a pointer swap
         h->resampled_last = !keep;
@@ -1288,7 +1310,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     // particle buffer (observation upload, table build, rays, weights, CDF, result read-back: all arguments are fixed).
     // Eligibility is a pure function of the configuration and the sizes (choose_ray_mode), never of what the previous
     // update happened to run: k_rays_skip chosen outright has no work lists, no allocation and no fallback.
-    bool graph_ok = h->cfg.graph_mode != 1 && h->graph_warm && choose_ray_mode(h, n, false) == 2 && !keep && !h->cfg.debug_count_probes &&
+    bool graph_ok = h->cfg.graph_mode != 1 && h->graph_warm && resample_and_move && choose_ray_mode(h, n, false) == 2 && !keep && !h->cfg.debug_count_probes &&
                     h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0;
     if (graph_ok) {
         stage_observation(h, obs, obs_stride);
@@ -1324,6 +1346,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     if (graph_ok) {
         const int gi = h->cur;
         HIPCHK(h, hipGraphLaunch(h->graph_exec[gi], h->stream));
+        h->pc_ready = false;
         HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         unpack_result(h);

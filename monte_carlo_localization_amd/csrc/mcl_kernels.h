@@ -153,11 +153,39 @@ struct ResampleArgs {
     unsigned long long *remote_count; // += children whose parent lives in another shard (exchange accounting), or null
     const int32_t *idx_in;            // parent of every child decided earlier (index-only pass + exchange), or null
     int index_only;                   // 1: write idx_out and stop (the host fetches the selected parents, then calls again)
+    // small updates (one launch less each): the per-particle constants k_particle_prep would compute, the CDF staged in
+    // LDS (cdf_lds_entries = n_parents when the launch has n_parents * 8 bytes of dynamic LDS, else 0), counters to zero
+    double4 *pc_out;                  // (cos, sin, pixel x, pixel y) per child, or null
+    double ox, oy, res;
+    int cdf_lds_entries;
+    unsigned long long *clear_counters;   // 4 words zeroed by the first thread, or null
 };
+
+// per-particle constants of the ray stage: (cos, sin, pixel x, pixel y); a garbage heading gets a NaN pixel position (the
+// pair fails every window test and is marched literally)
+__device__ __forceinline__ double4 particle_constants(double x, double y, double t, double ox, double oy, double res)
+{
+    double s, c;
+    sincos(t, &s, &c);
+    const bool heading_ok = t == t && fabs(t) < 1e6;
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    return make_double4(c, s, heading_ok ? (x - ox) / res : nanv, heading_ok ? (y - oy) / res : nanv);
+}
 
 __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char resample_lds[];
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.clear_counters && m == 0) { a.clear_counters[0] = 0ull; a.clear_counters[1] = 0ull; a.clear_counters[2] = 0ull; a.clear_counters[3] = 0ull; }
+    const uint64_t *cdf = a.cdf;
+    if (a.cdf_lds_entries > 0) {
+        // a small CDF: one coalesced pass into LDS, then the bisection runs at LDS latency (11 dependent L2 round trips
+        // were most of this kernel at the stock 2000 particles)
+        uint64_t *c_sh = reinterpret_cast<uint64_t *>(resample_lds);
+        for (int i = threadIdx.x; i < a.cdf_lds_entries; i += blockDim.x) c_sh[i] = a.cdf[i];
+        __syncthreads();
+        cdf = c_sh;
+    }
     if (m >= a.n_children) return;
     uint64_t g = (uint64_t)(a.child_first + m);
     int64_t idx = m;
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
             }
             while (len > 0) {
                 int64_t half = len >> 1, mid = lo + half;
-                if (!mul_gt(a.cdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
+                if (!mul_gt(cdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
                 else len = half;
             }
             idx = (lo >= a.n_parents) ? a.n_parents - 1 : lo;
@@ -274,6 +302,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     }
     a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
     if (a.cpack) a.cpack[m] = make_double4(x, y, th, 0.0);
+    if (a.pc_out) a.pc_out[m] = particle_constants(x, y, th, a.ox, a.oy, a.res);
 }
 
 // (x, y, theta) columns -> packed records (the form k_resample_motion gathers parents from)
@@ -419,6 +448,7 @@ struct RayArgs {
     const int8_t *grid; int W, H;
     double res, ox, oy;
     const uint8_t *dist;           // padded distance field Hp x Wps bytes (0 = stop), cap 255
+    const uint8_t *dist4;          // the same field as nibbles min(d, 15), two cells per byte, Hp x Wps/2 bytes (k_rays_skip's window)
     const uint8_t *distq[4];       // directional fields per quadrant (k_rays_quad, k_rays_far)
     int Wp, Hp, Wps;
     int tw_cells;                  // LDS window side (multiple of 8)
@@ -510,13 +540,8 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     if (clr.bbox) for (int64_t k = i; k < 4; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (int)0x80000000;
     if (clr.hist) for (int64_t k = i; k < clr.hist_n; k += n) clr.hist[k] = 0u;
     const double t = th[i];
-    double s, c;
-    sincos(t, &s, &c);
-    const bool heading_ok = t == t && fabs(t) < 1e6;
-    // a garbage heading gets a NaN pixel position: the pair fails every window test and k_rays_far marches it literally
-    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
-    pc[i] = make_double4(c, s, heading_ok ? (x[i] - ox) / res : nanv, heading_ok ? (y[i] - oy) / res : nanv);
-    if (qr) qr[i] = quadrant_ranges_of(t, heading_ok, beam_angle, B);
+    pc[i] = particle_constants(x[i], y[i], t, ox, oy, res);
+    if (qr) qr[i] = quadrant_ranges_of(t, t == t && fabs(t) < 1e6, beam_angle, B);
 }
 
 // D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
@@ -651,6 +676,12 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     const int TW = a.tw_cells;
     const int strideB = TW >> 1;
     const int wpr = TW >> 3;                 // 32-bit words (8 cells) per window row
+    // requested before the window is loaded, needed after: this wave's first particle and the lane's first beam direction
+    // (a small update is one particle per wave: these two round trips would otherwise follow the fill)
+    const int64_t i_first = p_begin + wave;
+    double4 pci_first = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (i_first < p_end) pci_first = a.pc[i_first];
+    const double2 cs_first = a.beam_cs[lane];          // beam_cs is padded to a multiple of 64 * R entries
     int wx0, wy0;
     {
         // ---- window placement: centred on the mean padded-pixel position of this slice ----
@@ -671,23 +702,27 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
         wx0 = (((int)floor(mx) + 1 - TW / 2)) & ~7;      // padded coordinate = global + 1
         wy0 = (int)floor(my) + 1 - TW / 2;
         __syncthreads();
-        // ---- load the window: 8 cells (8 bytes of the distance field) -> one 32-bit word ----
+        // ---- load the window: a straight copy of the nibble field, 8 cells per 32-bit word, twenty independent loads in
+        //      flight per thread (at the stock 2000 x 61 the fill is a third of the kernel: dependent round trips to L2) ----
         uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw);
-        const int nwords = wpr * TW;
-        for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
-            int row = wi / wpr, cw = wi - row * wpr;
-            int gy = wy0 + row, gx = wx0 + cw * 8;
-            uint32_t word = 0;
-            if (gy >= 0 && gy < a.Hp && gx >= 0 && gx < a.Wps) {
-                uint64_t b8 = *reinterpret_cast<const uint64_t *>(a.dist + (size_t)gy * a.Wps + gx);
+        const uint32_t *src4 = reinterpret_cast<const uint32_t *>(a.dist4);
+        const int nwords = wpr * TW, spw = a.Wps >> 3, gxw0 = wx0 >> 3;        // wx0 is a multiple of 8 (possibly negative)
+        constexpr int kBatch = 20;
+        for (int wi0 = threadIdx.x; wi0 < nwords; wi0 += kRayThreads * kBatch) {
+            uint32_t v[kBatch];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    uint32_t d = (uint32_t)(b8 >> (8 * k)) & 0xFFu;
-                    d = d > 15u ? 15u : d;           // nibble = skip distance, 0 = stop
-                    word |= d << (4 * k);
-                }
+            for (int k = 0; k < kBatch; ++k) {
+                const int wi = wi0 + k * kRayThreads;
+                const int row = wi / wpr, cw = wi - row * wpr;
+                const int gy = wy0 + row, gxw = gxw0 + cw;
+                v[k] = 0u;
+                if (wi < nwords && gy >= 0 && gy < a.Hp && gxw >= 0 && gxw < spw) v[k] = src4[(size_t)gy * spw + gxw];
             }
-            win[wi] = word;
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int wi = wi0 + k * kRayThreads;
+                if (wi < nwords) win[wi] = v[k];
+            }
         }
         __syncthreads();
     }
@@ -699,7 +734,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     asm volatile("" : "+v"(strideB_v), "+v"(gbias_v));   // keep both in VGPRs across the loop
 
     for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
-        const double4 pci = a.pc[i];
+        const double4 pci = (i == i_first) ? pci_first : a.pc[i];
         double acc = 0.0;
         const double cth = pci.x, sth = pci.y;
         const double gpx = pci.z;                     // global pixel coordinate of the particle
@@ -745,7 +780,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     int j = (grp * R + k) * 64 + lane;        // beam_cs is padded: no clamp needed
-                    double2 cs = a.beam_cs[j];
+                    double2 cs = (grp == 0 && k == 0) ? cs_first : a.beam_cs[j];
                     // -U = -rint(2^22 * (cos, sin)(theta + a_j)); T(s) = P0 + s*U = Pe - rem*U with rem = P - s
                     NUx[k] = rint_i32(__builtin_fma(ncth22, cs.x, sth22 * cs.y));
                     NUy[k] = rint_i32(__builtin_fma(ncth22, cs.y, -(sth22 * cs.x)));
@@ -2005,23 +2040,25 @@ __global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__rest
 
 // The whole tail of a SMALL update (N <= kTinyTailMax) by ONE workgroup: maximum, max-subtracted weights, fixed-point
 // weights, the seven sums and the inclusive CDF -- seven launches of ~4 us each otherwise, and no cross-workgroup
-// reduction is needed at this size.  Same formulas as k_reduce_max / k_weights / k_scan_*; the sums are reduced in this
-// kernel's own fixed order (thread-strided, wave butterflies, waves in order), so they are deterministic for a given N.
+// reduction is needed at this size.  Same formulas as k_reduce_max / k_weights / k_scan_*.  The per-particle work (the
+// deterministic exp, the weighted sums) is dealt thread-strided so that all 1024 threads work at the stock 2000-4000
+// particles; the fixed-point weights wait in LDS for the scan, which needs consecutive runs per thread.  The sums are
+// reduced in this kernel's own fixed order (thread-strided, wave butterflies, waves in order): deterministic for a given N.
+// pc: (cos, sin, ., .) of every heading as k_particle_prep left them (the same sincos call), or null.
 constexpr int64_t kTinyTailMax = 8192;
 __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ logw, const double *__restrict__ x, const double *__restrict__ y,
-                                                   const double *__restrict__ th, int64_t n, double *__restrict__ w_out,
-                                                   uint64_t *__restrict__ q_out, uint64_t *__restrict__ cdf_out, double *__restrict__ scalars)
+                                                   const double *__restrict__ th, const double4 *__restrict__ pc, int64_t n,
+                                                   double *__restrict__ w_out, uint64_t *__restrict__ q_out, uint64_t *__restrict__ cdf_out,
+                                                   double *__restrict__ scalars)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
+    uint64_t *q_sh = reinterpret_cast<uint64_t *>(tail_lds);       // n entries
     __shared__ double sm[16][7];
     __shared__ uint64_t wave_tot[16];
     __shared__ double mx_sh;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int kPer = (int)(kTinyTailMax / 1024);             // consecutive entries per thread
-    const int64_t c0 = (int64_t)threadIdx.x * kPer;
-    double lw[kPer];
     double m = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) { lw[k] = (c0 + k < n) ? logw[c0 + k] : -INFINITY; m = fmax(m, lw[k]); }
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, logw[i]);
     m = wave_max(m);
     if (lane == 0) sm[wv][0] = m;
     __syncthreads();
@@ -2033,32 +2070,32 @@ __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ l
     __syncthreads();
     const double mx = mx_sh;
     double sw = 0, swx = 0, swy = 0, sws = 0, swc = 0, sww = 0;
-    uint64_t q[kPer], tot = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        q[k] = 0;
-        if (c0 + k < n) {
-            const int64_t i = c0 + k;
-            const double w = det_exp(lw[k] - mx);
-            q[k] = (uint64_t)(w * kWeightScale);
-            w_out[i] = w;
-            q_out[i] = q[k];
-            double s, c;
-            sincos(th[i], &s, &c);
-            sw += w; swx += w * x[i]; swy += w * y[i]; sws += w * s; swc += w * c; sww += w * w;
-        }
-        tot += q[k];
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double w = det_exp(logw[i] - mx);
+        const uint64_t q = (uint64_t)(w * kWeightScale);
+        w_out[i] = w;
+        q_out[i] = q;
+        q_sh[i] = q;
+        double s, c;
+        if (pc) { const double4 r = pc[i]; c = r.x; s = r.y; }
+        else sincos(th[i], &s, &c);
+        sw += w; swx += w * x[i]; swy += w * y[i]; sws += w * s; swc += w * c; sww += w * w;
     }
     sw = wave_sum(sw); swx = wave_sum(swx); swy = wave_sum(swy); sws = wave_sum(sws); swc = wave_sum(swc); sww = wave_sum(sww);
-    const uint64_t inc = wave_incl_scan_u64(tot, lane);
-    __syncthreads();
+    __syncthreads();                            // every q_sh entry written; sm[.][0] (the maxima) read by everyone
     if (lane == 0) { sm[wv][0] = sw; sm[wv][2] = swx; sm[wv][3] = swy; sm[wv][4] = sws; sm[wv][5] = swc; sm[wv][6] = sww; }
+    // inclusive scan: thread t owns the `per` consecutive entries from t * per
+    const int per = (int)((n + 1023) / 1024);
+    const int64_t c0 = (int64_t)threadIdx.x * per;
+    uint64_t tot = 0;
+    for (int k = 0; k < per; ++k) tot += (c0 + k < n) ? q_sh[c0 + k] : 0ull;
+    const uint64_t inc = wave_incl_scan_u64(tot, lane);
     if (lane == 63) wave_tot[wv] = inc;
     __syncthreads();
     uint64_t run = inc - tot;
     for (int k = 0; k < wv; ++k) run += wave_tot[k];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) { run += q[k]; if (c0 + k < n) cdf_out[c0 + k] = run; }
+    for (int k = 0; k < per; ++k)
+        if (c0 + k < n) { run += q_sh[c0 + k]; cdf_out[c0 + k] = run; }
     if (threadIdx.x == 0) {
         double r[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t rq = 0;
