@@ -494,7 +494,7 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip)
     return 2;
 }
 
-int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n, bool force_skip = false)
+int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n, bool force_skip = false, bool direct_table = false)
 {
     mcl::RayArgs a{};
     a.x = x; a.y = y; a.th = th; a.n = n;
@@ -511,6 +511,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.steps = h->cfg.keep_ray_steps ? h->d_steps : nullptr;
     a.grid = h->d_grid; a.W = h->W; a.H = h->H;
     a.res = h->res; a.ox = h->ox; a.oy = h->oy;
+    if (direct_table) { a.Ldirect = h->d_L; a.obs_idx = h->d_obs_idx; }       // small updates: no per-update table (do_update)
     a.dist = h->d_dist; a.dist4 = h->d_dist4; a.Wp = h->Wp; a.Hp = h->Hp; a.Wps = h->Wps;
     for (int q = 0; q < 4; ++q) a.distq[q] = h->d_distq[q];
     a.tw_cells = h->tw_cells;
@@ -533,7 +534,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     dim3 g(grid), b(mcl::kRayThreads);
     int R = h->cfg.rays_per_lane;
     if (R <= 0) R = 1;   // measured on MI355X: the kernel is VALU-issue-bound, extra chains per lane only add idle slots
-    if (!windows && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
+    if (!windows && !h->capturing && !direct_table) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
     if (mode == 1) {
         if (count) hipLaunchKernelGGL((mcl::k_rays_march<true>), g, b, 0, h->stream, a);
         else hipLaunchKernelGGL((mcl::k_rays_march<false>), g, b, 0, h->stream, a);
@@ -700,7 +701,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         default: hipLaunchKernelGGL((mcl::k_rays_skip<4, false>), g, b, lds, h->stream, a); break;
         }
     }
-    if (!windows && !h->capturing) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+    if (!windows && !h->capturing && !direct_table) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
     h->last_mode = mode;
     if (!h->capturing) h->pc_ready = false;
     HIPCHK(h, hipGetLastError());
@@ -758,14 +759,15 @@ int sensor_and_weights(mcl_engine *h, const double *d_global_max)
 }
 
 // weights, sums and the CDF of the current log-weights (the tail of an update).  Small updates take one launch.
-int weights_and_cdf(mcl_engine *h)
+int weights_and_cdf(mcl_engine *h, bool result_to_host = false)
 {
     const int64_t n = h->N;
     if (h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0 && n <= mcl::kTinyTailMax) {
         // d_pc holds (cos, sin) of the current headings whenever a ray kernel other than the literal march ran on them
         const double4 *pc = h->last_mode >= 2 ? h->d_pc : nullptr;
         hipLaunchKernelGGL(mcl::k_tiny_tail, dim3(1), dim3(1024), (size_t)n * sizeof(uint64_t), h->stream, h->d_logw, h->d_x[h->cur],
-                           h->d_y[h->cur], h->d_th[h->cur], pc, n, h->d_w, h->d_q, h->d_cdf, h->d_scalars);
+                           h->d_y[h->cur], h->d_th[h->cur], pc, n, h->d_w, h->d_q, h->d_cdf, h->d_scalars,
+                           result_to_host ? h->h_result : (unsigned long long *)nullptr);
         HIPCHK(h, hipGetLastError());
         h->max_partials_ready = false;
         h->carry_pending = false;
@@ -1257,6 +1259,11 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     if (!resample_and_move) HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));   // else: the resampling kernel
     HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
     h->pc_ready = false;
+    // A small update (k_rays_skip, the whole tail in one workgroup) is three launches and no copy: resampling + motion +
+    // per-particle constants + table rows of the scan | rays against the static table | weights, sums, CDF and the result
+    // block written straight to pinned host memory.  Every buffer exists once a regular update has run (graph_warm).
+    const bool tiny = resample_and_move && h->cfg.graph_mode != 1 && h->graph_warm && n <= mcl::kTinyTailMax && !keep &&
+                      choose_ray_mode(h, n, false) == 2 && h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0;
     if (resample_and_move) {
         const int c = h->cur, nx = c ^ 1;
         mcl::ResampleArgs a{};
@@ -1289,6 +1296,11 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
         a.do_resample = keep ? 0 : 1; a.do_motion = 1;
         a.clear_counters = h->d_counters;
+        if (tiny) {
+            // the scan goes from the pinned staging buffer to table rows inside this kernel (no copy node, no table build)
+            stage_observation(h, obs, obs_stride);
+            a.obs_src = h->h_obs; a.obs_idx_out = h->d_obs_idx; a.obs_B = h->B; a.obs_P = h->P; a.res = h->res;
+        }
         if (choose_ray_mode(h, n, false) == 2) {
             // k_rays_skip follows: its per-particle constants come out of this kernel (one launch less per small update)
             a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
@@ -1303,8 +1315,27 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->pack_valid[nx] = true;
         h->have_idx = true;
     }
-    HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
     int rc;
+    if (tiny) {
+        rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, false, true);
+        if (!rc) rc = weights_and_cdf(h, true);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        unpack_result(h);
+        h->have_logw = true;
+        h->have_steps = h->cfg.keep_ray_steps != 0;
+        h->update_idx++;
+        // one unit, reported as the ray-cast stage (resampling, query prep and the tail are inside it), so that the six
+        // stages still add up to the total the host uses for delay compensation
+        h->timings[0] = 0.0; h->timings[1] = 0.0; h->timings[2] = 0.0; h->timings[4] = 0.0;
+        h->timings[3] = elapsed(h->ev[EV_START], h->ev[EV_SENSOR]);
+        h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        h->ray_ms = h->timings[3];
+        h->ray_ms_is_graph_tail = true;
+        return MCL_OK;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
     // Small updates are launch-bound (about twenty launches for ~0.06 ms of kernels): once a regular update has run with
     // these sizes on the k_rays_skip path, everything after the resampling kernel is replayed as one hipGraph per
     // particle buffer (observation upload, table build, rays, weights, CDF, result read-back: all arguments are fixed).

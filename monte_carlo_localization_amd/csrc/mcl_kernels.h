@@ -159,7 +159,12 @@ struct ResampleArgs {
     double ox, oy, res;
     int cdf_lds_entries;
     unsigned long long *clear_counters;   // 4 words zeroed by the first thread, or null
+    const float *obs_src;             // this update's ranges (pinned host memory, read once by the first workgroup), or null
+    int32_t *obs_idx_out;             // their table rows (obs_index_of), for a ray kernel that reads the static table directly
+    int obs_B, obs_P;
 };
+
+__device__ __forceinline__ int obs_index_of(float obs, double res, int P);
 
 // per-particle constants of the ray stage: (cos, sin, pixel x, pixel y); a garbage heading gets a NaN pixel position (the
 // pair fails every window test and is marched literally)
@@ -177,6 +182,8 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char resample_lds[];
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.clear_counters && m == 0) { a.clear_counters[0] = 0ull; a.clear_counters[1] = 0ull; a.clear_counters[2] = 0ull; a.clear_counters[3] = 0ull; }
+    if (a.obs_src && blockIdx.x == 0)
+        for (int j = threadIdx.x; j < a.obs_B; j += blockDim.x) a.obs_idx_out[j] = obs_index_of(a.obs_src[j], a.res, a.obs_P);
     const uint64_t *cdf = a.cdf;
     if (a.cdf_lds_entries > 0) {
         // a small CDF: one coalesced pass into LDS, then the bisection runs at LDS latency (11 dependent L2 round trips
@@ -448,6 +455,8 @@ struct RayArgs {
     const int8_t *grid; int W, H;
     double res, ox, oy;
     const uint8_t *dist;           // padded distance field Hp x Wps bytes (0 = stop), cap 255
+    const float *Ldirect;          // k_rays_skip, small updates: the static table L[row][step] read through obs_idx (no per-update
+    const int32_t *obs_idx;        //   transposed copy is built); null = use Lt
     const uint8_t *dist4;          // the same field as nibbles min(d, 15), two cells per byte, Hp x Wps/2 bytes (k_rays_skip's window)
     const uint8_t *distq[4];       // directional fields per quadrant (k_rays_quad, k_rays_far)
     int Wp, Hp, Wps;
@@ -682,6 +691,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     double4 pci_first = make_double4(0.0, 0.0, 0.0, 0.0);
     if (i_first < p_end) pci_first = a.pc[i_first];
     const double2 cs_first = a.beam_cs[lane];          // beam_cs is padded to a multiple of 64 * R entries
+    const int tw = a.P + 1;
     int wx0, wy0;
     {
         // ---- window placement: centred on the mean padded-pixel position of this slice ----
@@ -855,7 +865,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                                 ++cnt_exact;
                             }
                         }
-                        acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                        acc += a.Ldirect ? (double)a.Ldirect[(size_t)a.obs_idx[j] * tw + r] : (double)a.Lt[(size_t)r * a.bpad + j];
                         if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
                     }
                 }
@@ -877,7 +887,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                         r = march_exact(a, a.x[i], a.y[i], a.th[i] + (double)a.beam_angle[j]);
                         ++cnt_exact;
                     }
-                    acc += (double)a.Lt[(size_t)r * a.bpad + j];
+                    acc += a.Ldirect ? (double)a.Ldirect[(size_t)a.obs_idx[j] * tw + r] : (double)a.Lt[(size_t)r * a.bpad + j];
                     if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
                     if (COUNT) cnt_probe += np;
                 }
@@ -2049,7 +2059,7 @@ constexpr int64_t kTinyTailMax = 8192;
 __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ logw, const double *__restrict__ x, const double *__restrict__ y,
                                                    const double *__restrict__ th, const double4 *__restrict__ pc, int64_t n,
                                                    double *__restrict__ w_out, uint64_t *__restrict__ q_out, uint64_t *__restrict__ cdf_out,
-                                                   double *__restrict__ scalars)
+                                                   double *__restrict__ scalars, unsigned long long *__restrict__ host_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
     uint64_t *q_sh = reinterpret_cast<uint64_t *>(tail_lds);       // n entries
@@ -2104,6 +2114,13 @@ __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ l
         scalars[1] = r[0]; scalars[2] = __longlong_as_double((long long)rq);
         scalars[3] = r[2]; scalars[4] = r[3]; scalars[5] = r[4]; scalars[6] = r[5];
         scalars[7] = r[6];
+        if (host_out) {
+            // the result block (8 scalars, then the counters and flags the ray kernels left behind them in the same
+            // allocation) straight into pinned host memory: no copy node, no hand-over to a DMA engine
+            const unsigned long long *blk = reinterpret_cast<const unsigned long long *>(scalars);
+            for (int k = 0; k < 8; ++k) host_out[k] = (unsigned long long)__double_as_longlong(scalars[k]);
+            for (int k = 8; k < 14; ++k) host_out[k] = blk[k];
+        }
     }
 }
 
