@@ -2059,7 +2059,8 @@ constexpr int64_t kTinyTailMax = 8192;
 __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ logw, const double *__restrict__ x, const double *__restrict__ y,
                                                    const double *__restrict__ th, const double4 *__restrict__ pc, int64_t n,
                                                    double *__restrict__ w_out, uint64_t *__restrict__ q_out, uint64_t *__restrict__ cdf_out,
-                                                   double *__restrict__ scalars, unsigned long long *__restrict__ host_out)
+                                                   double *__restrict__ scalars, unsigned long long *__restrict__ host_out,
+                                                   unsigned long long host_seq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
     uint64_t *q_sh = reinterpret_cast<uint64_t *>(tail_lds);       // n entries
@@ -2106,6 +2107,7 @@ __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ l
     for (int k = 0; k < wv; ++k) run += wave_tot[k];
     for (int k = 0; k < per; ++k)
         if (c0 + k < n) { run += q_sh[c0 + k]; cdf_out[c0 + k] = run; }
+    if (host_out) __syncthreads();              // every store of this kernel is out before the host is told it may look
     if (threadIdx.x == 0) {
         double r[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t rq = 0;
@@ -2120,6 +2122,9 @@ __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ l
             const unsigned long long *blk = reinterpret_cast<const unsigned long long *>(scalars);
             for (int k = 0; k < 8; ++k) host_out[k] = (unsigned long long)__double_as_longlong(scalars[k]);
             for (int k = 8; k < 14; ++k) host_out[k] = blk[k];
+            // the host may be polling word 16 instead of waiting for the stream's completion signal
+            __threadfence_system();
+            __hip_atomic_store(&host_out[16], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
