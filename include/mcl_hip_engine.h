@@ -248,6 +248,16 @@ int mcl_stage_resample_records(mcl_engine_t *h, const void *d_records, const uin
  * whatever transport the host has (torch.distributed all-to-all in dist.py), and hands the compact record table plus the
  * per-child position in it to mcl_stage_motion_records, which gathers, applies the motion model and makes the children
  * current.  Same random streams as the fused call: bit-identical children. */
+/* Helpers of that exchange, so that the host needs no pass over n_total elements of its own:
+ *   mcl_stage_distinct_parents: d_parent[n_children] (global indices < n_total, DEVICE) -> the distinct ones in ascending
+ *     order (= grouped by owning shard) in d_distinct (DEVICE, room for n_children int64), the position of every child's
+ *     parent among them in d_slot (DEVICE, n_children int32) and their number in *count (host).  A bitmap over the
+ *     global indices and its popcount prefix: every pass but the marking runs over n_total / 32 words.
+ *   mcl_export_records_at: the packed records {x, y, theta, unused} of the listed local particles (indices into this
+ *     engine's current set, DEVICE int64) -> d_out[count] (DEVICE): what a shard answers a request with. */
+int mcl_stage_distinct_parents(mcl_engine_t *h, const int32_t *d_parent, int64_t n_children, int64_t n_total,
+                               int64_t *d_distinct, int32_t *d_slot, int64_t *count);
+int mcl_export_records_at(mcl_engine_t *h, const int64_t *d_index, int64_t count, void *d_out);
 int mcl_stage_resample_indices(mcl_engine_t *h, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total, int64_t child_first,
                                int64_t n_children_total, int32_t *d_parent_idx);
 int mcl_stage_motion_records(mcl_engine_t *h, const void *d_records, int64_t n_records, const int32_t *d_record_of_child,

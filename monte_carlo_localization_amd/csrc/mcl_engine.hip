@@ -71,7 +71,7 @@ struct mcl_engine {
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
     int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), rebuilt when (n, workgroups, G) change
     size_t items_capacity = 0;
-    int nitems = 0, plan_g = 0, plan_nwg = 0, plan_P = 0;
+    int *d_nitems = nullptr;            // number of work items (written by k_sweep_plan)
     int64_t plan_n = 0;
     double4 *d_unit_sums = nullptr;     // per unit of 1024 sorted particles: (sum px, sum py, count, -)
     size_t unit_sums_capacity = 0;
@@ -96,6 +96,9 @@ struct mcl_engine {
     bool capturing = false;
     double *d_logw_acc = nullptr;       // k_rays_quad/far/fix accumulate here with atomics; k_gather_logw copies to d_logw
     uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
+    uint32_t *d_bm = nullptr;           // mcl_stage_distinct_parents: bitmap over the global particle indices, its popcounts and their prefix
+    uint64_t *d_bm_pop = nullptr, *d_bm_pref = nullptr;
+    size_t bm_capacity = 0;
     uint64_t *d_leaders = nullptr;      // last CDF entry of every 16-entry group of the array d_blocktot describes
     size_t leaders_capacity = 0;
     double4 *d_pack[2]{};               // (x, y, theta, -) records of buffer 0/1, written by k_resample_motion
@@ -446,31 +449,23 @@ void unpack_result(mcl_engine *h)
     h->global_sums[4] = h->h_scalars[6];
 }
 
-// Work items of k_rays_sweep: (first unit, units, wedge group).  Guided schedule: runs of up to four units (4096 particles
-// share one window per wedge) while plenty of work is left, single units for the last third, every run once per wedge
-// group; the persistent workgroups take them in this order, so they finish within one single-unit item of each other.
-int build_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
+// Work items of k_rays_sweep: made on the device from this update's unit statistics (k_sweep_plan, mcl_rays_sweep.h);
+// the host only sizes the list (every unit on its own, once per wedge group, is the longest it can get).
+int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
 {
-    if (h->d_items && h->plan_n == n && h->plan_nwg == nwg && h->plan_g == g && h->plan_P == h->P) return MCL_OK;
     const int ngroups = mcl::kWedges / g;
     const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
-    std::vector<int4> items;
-    for (int64_t u = 0; u < M;) {
-        int64_t c = ((M - u) * ngroups) / (3 * (int64_t)std::max(nwg, 1));
-        // a narrow window (long range: 256 - (P + 2) - 3 cells of play) is centred on one unit at a time
-        const int64_t run_max = mcl::kSwSide - (h->P + 2) - 3 >= 24 ? 4 : 1;
-        c = std::max<int64_t>(1, std::min<int64_t>(run_max, std::min<int64_t>(c, M - u)));
-        for (int k = 0; k < ngroups; ++k) items.push_back(make_int4((int)u, (int)c, (int)((k + u) % ngroups), 0));
-        u += c;
-    }
-    if (items.size() > h->items_capacity) {
+    const size_t need = (size_t)M * ngroups;
+    if (need > h->items_capacity) {
         dfree(h->d_items);
-        HIPCHK(h, hipMalloc(&h->d_items, items.size() * sizeof(int4)));
-        h->items_capacity = items.size();
+        HIPCHK(h, hipMalloc(&h->d_items, need * sizeof(int4)));
+        h->items_capacity = need;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));          // `items` goes out of scope
-    h->nitems = (int)items.size(); h->plan_n = n; h->plan_nwg = nwg; h->plan_g = g; h->plan_P = h->P;
+    if (!h->d_nitems) HIPCHK(h, hipMalloc(&h->d_nitems, sizeof(int)));
+    const int play = mcl::kSwSide - (h->P + 2) - 3;                     // cells a window leaves for the particles of an item
+    hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), 0, h->stream, h->d_unit_sums, (int)M, ngroups, nwg, (double)(play / 2 - 1),
+                       h->d_items, h->d_nitems);
+    HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
 
@@ -620,7 +615,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             if (sweep) {
                 if ((size_t)nsl > h->unit_sums_capacity) {
                     dfree(h->d_unit_sums);
-                    HIPCHK(h, hipMalloc(&h->d_unit_sums, (size_t)nsl * sizeof(double4)));
+                    HIPCHK(h, hipMalloc(&h->d_unit_sums, (size_t)nsl * 2 * sizeof(double4)));
                     h->unit_sums_capacity = nsl;
                 }
                 hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)nsl), dim3(256), 0, h->stream, h->d_pcs, n, h->d_unit_sums);
@@ -643,10 +638,10 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                 h->partial_capacity = need;
             }
             if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not built (internal)");
-            const int rc_plan = build_sweep_plan(h, n, nseg, sweep_g);
+            const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
             if (rc_plan) return rc_plan;
             a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
-            a.items = h->d_items; a.nitems = h->nitems; a.unit_sums = h->d_unit_sums; a.slot_space = 1;
+            a.items = h->d_items; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.slot_space = 1;
             if (!h->d_far_list) HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
@@ -926,11 +921,11 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     graph_reset(h);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
-    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot);
+    dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1660,6 +1655,64 @@ int mcl_export_records(mcl_engine_t *h, void *d_records)
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_export_records_at(mcl_engine_t *h, const int64_t *d_index, int64_t count, void *d_out)
+{
+    if (!h || count < 0 || (count > 0 && (!d_index || !d_out))) return MCL_ERR_INVALID_ARG;
+    if (!h->have_particles) return MCL_ERR_NOT_READY;
+    if (count == 0) return MCL_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int c = h->cur;
+    const int64_t n = h->N;
+    if (!h->pack_valid[c]) {
+        hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_x[c], h->d_y[c], h->d_th[c], n, h->d_pack[c]);
+        h->pack_valid[c] = true;
+    }
+    hipLaunchKernelGGL(mcl::k_gather_records, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, h->d_pack[c], d_index, count, n,
+                       reinterpret_cast<double4 *>(d_out));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_stage_distinct_parents(mcl_engine_t *h, const int32_t *d_parent, int64_t n_children, int64_t n_total, int64_t *d_distinct,
+                               int32_t *d_slot, int64_t *count)
+{
+    if (!h || !d_parent || !d_distinct || !d_slot || !count || n_children <= 0 || n_total <= 0) return MCL_ERR_INVALID_ARG;
+    if (n_total > MCL_MAX_TOTAL_PARTICLES) return fail(h, MCL_ERR_INVALID_ARG, "n_total exceeds MCL_MAX_TOTAL_PARTICLES");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int64_t nwords = (n_total + 31) / 32;
+    if ((size_t)nwords > h->bm_capacity) {
+        dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
+        h->bm_capacity = 0;
+        HIPCHK(h, hipMalloc(&h->d_bm, (size_t)nwords * 4));
+        HIPCHK(h, hipMalloc(&h->d_bm_pop, (size_t)nwords * 8));
+        HIPCHK(h, hipMalloc(&h->d_bm_pref, (size_t)nwords * 8));
+        h->bm_capacity = (size_t)nwords;
+    }
+    size_t need = (size_t)nwords / mcl::kScanTile + 2;
+    if (need > h->blocktot_capacity) {
+        graph_reset(h);
+        dfree(h->d_blocktot);
+        HIPCHK(h, hipMalloc(&h->d_blocktot, need * 8));
+        h->blocktot_capacity = need;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_bm, 0, (size_t)nwords * 4, h->stream));
+    hipLaunchKernelGGL(mcl::k_bm_mark, dim3((unsigned)((n_children + 255) / 256)), dim3(256), 0, h->stream, d_parent, n_children, n_total, h->d_bm);
+    hipLaunchKernelGGL(mcl::k_bm_pop, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, h->stream, h->d_bm, nwords, h->d_bm_pop);
+    int rc = scan_weights(h, h->d_bm_pop, h->d_bm_pref, nwords, 0, nullptr);
+    if (rc) return rc;
+    h->blocktot_for = nullptr;                  // the spine now describes the bitmap's prefix, not a CDF
+    hipLaunchKernelGGL(mcl::k_bm_expand, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, h->stream, h->d_bm, h->d_bm_pref, nwords, d_distinct);
+    hipLaunchKernelGGL(mcl::k_bm_slot, dim3((unsigned)((n_children + 255) / 256)), dim3(256), 0, h->stream, d_parent, n_children, n_total, h->d_bm,
+                       h->d_bm_pref, d_slot);
+    HIPCHK(h, hipGetLastError());
+    uint64_t c = 0;
+    HIPCHK(h, hipMemcpyAsync(&c, h->d_bm_pref + (nwords - 1), 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *count = (int64_t)c;
     return MCL_OK;
 }
 

@@ -312,6 +312,53 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     if (a.pc_out) a.pc_out[m] = particle_constants(x, y, th, a.ox, a.oy, a.res);
 }
 
+// ---- distinct parents of a shard's children (sharded resampling): a bitmap over the GLOBAL particle indices, its popcount
+//      prefix and two expansions.  Every pass but the marking is over n_total / 32 words. ----
+__global__ void k_bm_mark(const int32_t *__restrict__ parent, int64_t n, int64_t n_total, uint32_t *__restrict__ bm)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = (uint32_t)parent[i];
+    if ((int64_t)p < n_total) atomicOr(&bm[p >> 5], 1u << (p & 31u));
+}
+__global__ void k_bm_pop(const uint32_t *__restrict__ bm, int64_t nwords, uint64_t *__restrict__ pop)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) pop[w] = (uint64_t)__popc(bm[w]);
+}
+// pref = inclusive prefix of pop: the set bits of word w are distinct parents pref[w] - popc(word) ... pref[w] - 1
+__global__ void k_bm_expand(const uint32_t *__restrict__ bm, const uint64_t *__restrict__ pref, int64_t nwords, int64_t *__restrict__ distinct)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t word = bm[w];
+    int64_t at = (int64_t)pref[w] - __popc(word);
+    while (word) {
+        const int b = __ffs((int)word) - 1;
+        distinct[at++] = w * 32 + b;
+        word &= word - 1u;
+    }
+}
+__global__ void k_bm_slot(const int32_t *__restrict__ parent, int64_t n, int64_t n_total, const uint32_t *__restrict__ bm,
+                          const uint64_t *__restrict__ pref, int32_t *__restrict__ slot)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = (uint32_t)parent[i];
+    if ((int64_t)p >= n_total) { slot[i] = 0; return; }
+    const uint32_t word = bm[p >> 5];
+    slot[i] = (int32_t)((int64_t)pref[p >> 5] - __popc(word) + __popc(word & ((1u << (p & 31u)) - 1u)));
+}
+// records of the listed particles (indices into the packed records of one shard)
+__global__ void k_gather_records(const double4 *__restrict__ rec, const int64_t *__restrict__ index, int64_t count, int64_t n,
+                                 double4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t k = index[i];
+    out[i] = (k >= 0 && k < n) ? rec[k] : make_double4(0.0, 0.0, 0.0, 0.0);
+}
+
 // (x, y, theta) columns -> packed records (the form k_resample_motion gathers parents from)
 __global__ void k_pack_records(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ th, int64_t n,
                                double4 *__restrict__ out)
@@ -444,6 +491,7 @@ struct RayArgs {
     int sweep_g;                   // k_rays_sweep: wedges per work item
     const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, -), big first (guided schedule)
     int nitems;
+    const int *nitems_ptr;          // k_rays_sweep: number of work items, written by k_sweep_plan
     const double4 *unit_sums;      // k_rays_sweep: per unit of kSwUnit sorted particles (sum px, sum py, count, -), k_slice_means
     uint32_t *far_list;            // k_rays_sweep -> k_rays_far: slots with at least one flagged quadrant (appended once each), or null
     unsigned long long *far_count; // entries in far_list

@@ -51,24 +51,107 @@ __global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restri
     Ltd[(size_t)r * cols + j] = v;
 }
 
-// (sum of pixel x, sum of pixel y, count) of the finite positions of every unit of kSwUnit sorted particles: a work item
-// centres its windows on the mean over its units
+// Per unit of kSwUnit sorted particles, over its finite positions: out[2u] = (sum of pixel x, sum of pixel y, count, -) and
+// out[2u + 1] = (min x, max x, min y, max y).  A work item centres its windows on the mean over its units; k_sweep_plan
+// joins neighbouring units into one item while their particles still fit one window.
 __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ pcs, int64_t n, double4 *__restrict__ out)
 {
-    __shared__ double sm[4][3];
+    __shared__ double sm[4][7];
     const int64_t p_begin = (int64_t)blockIdx.x * kSwUnit;
     const int64_t p_end = (p_begin + kSwUnit < n) ? p_begin + kSwUnit : n;
-    double sx = 0.0, sy = 0.0, cnt = 0.0;
+    double sx = 0.0, sy = 0.0, cnt = 0.0, x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
     for (int64_t s = p_begin + threadIdx.x; s < p_end; s += blockDim.x) {
         const double4 c = pcs[s];
-        if (c.z == c.z && c.w == c.w && fabs(c.z) < 1e9 && fabs(c.w) < 1e9) { sx += c.z; sy += c.w; cnt += 1.0; }
+        if (c.z == c.z && c.w == c.w && fabs(c.z) < 1e9 && fabs(c.w) < 1e9) {
+            sx += c.z; sy += c.w; cnt += 1.0;
+            x0 = fmin(x0, c.z); x1 = fmax(x1, c.z); y0 = fmin(y0, c.w); y1 = fmax(y1, c.w);
+        }
     }
     sx = wave_sum(sx); sy = wave_sum(sy); cnt = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = sx; sm[threadIdx.x >> 6][1] = sy; sm[threadIdx.x >> 6][2] = cnt; }
+    x0 = -wave_max(-x0); x1 = wave_max(x1); y0 = -wave_max(-y0); y1 = wave_max(y1);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w][0] = sx; sm[w][1] = sy; sm[w][2] = cnt; sm[w][3] = x0; sm[w][4] = x1; sm[w][5] = y0; sm[w][6] = y1; }
     __syncthreads();
-    if (threadIdx.x == 0)
-        out[blockIdx.x] = make_double4(sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0], sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1],
-                                       sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2], 0.0);
+    if (threadIdx.x == 0) {
+        out[2 * (size_t)blockIdx.x] = make_double4(sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0], sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1],
+                                                  sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2], 0.0);
+        out[2 * (size_t)blockIdx.x + 1] = make_double4(fmin(fmin(sm[0][3], sm[1][3]), fmin(sm[2][3], sm[3][3])), fmax(fmax(sm[0][4], sm[1][4]), fmax(sm[2][4], sm[3][4])),
+                                                      fmin(fmin(sm[0][5], sm[1][5]), fmin(sm[2][5], sm[3][5])), fmax(fmax(sm[0][6], sm[1][6]), fmax(sm[2][6], sm[3][6])));
+    }
+}
+
+// Work items of k_rays_sweep: (first unit, units, wedge group).  One thread looks at an aligned block of kSwRunMax units:
+// the run length the guided schedule wants there (long runs while plenty of work is left -- fewer window loads and fewer
+// workgroup barriers per particle --, single units for the last third, so that the persistent workgroups finish within
+// one small item of each other) is halved until the particles of every run fit one window (`half_play` cells either side of
+// the run's mean position, both axes; a sparse cloud or a long range thus gets shorter runs instead of off-window
+// particles).  Every run is listed once per wedge group.  One workgroup; items come out in unit order.
+constexpr int kSwRunMax = 8;
+__global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, int M, int ngroups, int nwg, double half_play,
+                                                    int4 *__restrict__ items, int *__restrict__ nitems_out)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry_sh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    const int nblocks = (M + kSwRunMax - 1) / kSwRunMax;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int b = b0 + (int)threadIdx.x;
+        const int u0 = b * kSwRunMax;
+        int len[kSwRunMax];                       // len[k] = units of the run that starts at u0 + k (0: inside another run)
+        int nruns = 0;
+        if (b < nblocks) {
+            long long want = ((long long)(M - u0) * ngroups) / (3ll * (nwg > 0 ? nwg : 1));
+            int c = 1;
+            while (c * 2 <= kSwRunMax && c * 2 <= want) c *= 2;
+#pragma unroll
+            for (int k = 0; k < kSwRunMax; ++k) len[k] = 0;
+            // runs of c units, each halved until it fits
+            for (int k0 = 0; k0 < kSwRunMax && u0 + k0 < M; k0 += c) {
+                int cc = c;
+                int k = k0;
+                while (k < k0 + c && u0 + k < M) {
+                    const int avail = (u0 + k + cc <= M) ? cc : M - (u0 + k);
+                    bool fits = true;
+                    if (cc > 1) {
+                        double sx = 0.0, sy = 0.0, cnt = 0.0, x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+                        for (int j = 0; j < avail; ++j) {
+                            const double4 s4 = unit_stats[2 * (size_t)(u0 + k + j)], bb = unit_stats[2 * (size_t)(u0 + k + j) + 1];
+                            sx += s4.x; sy += s4.y; cnt += s4.z;
+                            x0 = fmin(x0, bb.x); x1 = fmax(x1, bb.y); y0 = fmin(y0, bb.z); y1 = fmax(y1, bb.w);
+                        }
+                        if (cnt > 0.0) {
+                            const double mx = sx / cnt, my = sy / cnt;
+                            fits = (x1 - mx) < half_play && (mx - x0) < half_play && (y1 - my) < half_play && (my - y0) < half_play;
+                        }
+                    }
+                    if (fits || cc == 1) { len[k] = avail; ++nruns; k += cc; }
+                    else cc >>= 1;                      // try the first half; the second half is tried at the same (halved) length
+                }
+            }
+        }
+        // position of this block's first run: exclusive scan of nruns over the workgroup, carried across passes
+        int inc = nruns;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        int at = carry_sh + inc - nruns;
+        for (int k = 0; k < wv; ++k) at += wave_tot[k];
+        if (b < nblocks) {
+#pragma unroll
+            for (int k = 0; k < kSwRunMax; ++k)
+                if (len[k] > 0) {
+                    for (int g = 0; g < ngroups; ++g) items[(size_t)at * ngroups + g] = make_int4(u0 + k, len[k], (g + u0 + k) % ngroups, 0);
+                    ++at;
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = at;      // the last thread's end position = the total so far
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nitems_out[0] = carry_sh * ngroups;
 }
 
 // One probe trip.  Positions are window-relative fixed point [cell:8][fraction:24] and carry the guard bias G; the window
@@ -158,7 +241,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long cnt_probe = 0;
     const int G = a.sweep_g;                                   // wedges per work item (divides kWedges)
-    const int nitems = a.nitems;
+    const int nitems = a.nitems_ptr ? a.nitems_ptr[0] : a.nitems;       // the plan is made on the device (k_sweep_plan)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
     constexpr int S = kSwSide;
     // level-1 error bound per axis, in units of 2^-24 px: 0.5 for the origin + (0.5 rounding + 0.625 scale, kSwDirScale)
@@ -191,7 +274,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     double2 mm = make_double2(0.0, 0.0);
     {
         double sx = 0.0, sy = 0.0, cnt = 0.0;
-        for (int u = 0; u < it.y; ++u) { const double4 us = a.unit_sums[it.x + u]; sx += us.x; sy += us.y; cnt += us.z; }
+        for (int u = 0; u < it.y; ++u) { const double4 us = a.unit_sums[2 * (size_t)(it.x + u)]; sx += us.x; sy += us.y; cnt += us.z; }
         if (cnt > 0.0) mm = make_double2(sx / cnt, sy / cnt);
     }
     for (int gw = 0; gw < G; ++gw) {

@@ -50,14 +50,18 @@ class ShardedFilter:
         f64, i64, i32 = torch.float64, torch.int64, torch.int32
         n, nt = self.n, self.n * self.world
         self.n_total = nt
-        self.loc = torch.empty((n, 4), dtype=f64, device=device)        # (x, y, theta, -) records of this shard
+        # (x, y, theta, -) records of this shard: only a shard without export_records_at needs the whole copy
+        self.loc = None if hasattr(shard, "export_records_at") else torch.empty((n, 4), dtype=f64, device=device)
         self.loc_q = torch.empty(n, dtype=i64, device=device)           # uint64 bits
         self.q_total = None                                              # global fixed-point weight total, once known
         self.pending_q = None                                            # async gather of the weights issued by the previous update
         self.glob_q = torch.empty(nt, dtype=i64, device=device)
         self.glob_cdf = torch.empty(nt, dtype=i64, device=device)
         self.parent = torch.empty(n, dtype=i32, device=device)          # global parent index of every local child
-        self.mark = torch.zeros(nt, dtype=torch.bool, device=device)    # parents some local child selected
+        self.uniq_buf = torch.empty(n, dtype=i64, device=device)        # distinct parents of the local children (ascending)
+        self.slot_buf = torch.empty(n, dtype=i32, device=device)        # every child's position among them
+        # only a shard without stage_distinct_parents (the tests' CPU stand-in) needs the n_total-sized flags
+        self.mark = None if hasattr(shard, "stage_distinct_parents") else torch.zeros(nt, dtype=torch.bool, device=device)
         self.pose = np.zeros(3)
         self.exchange_bytes = dict(weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
 
@@ -73,38 +77,62 @@ class ShardedFilter:
         self.pending_q = None
         self.q_total = None
 
-    def _fetch_parents(self):
-        """self.parent (global indices) -> (compact record table, position of every child's parent in it).  Distinct
-        parents only; the ones this rank owns are copied locally, the others requested from their owners."""
-        n, world = self.n, self.world
-        # distinct parents in ascending order (= grouped by owner) and every child's position among them: mark, prefix-sum,
-        # compact -- streaming passes over n_total flags instead of a sort of the children's indices
+    def _distinct(self):
+        """self.parent (global indices) -> (distinct parents ascending = grouped by owner, position of every child's parent
+        among them).  The engine does it with a bitmap over the global indices (passes over n_total / 32 words); a shard
+        without that call (the CPU stand-in of the tests) gets the same by mark / prefix-sum / compact on tensors."""
+        s = self.shard
+        if hasattr(s, "stage_distinct_parents"):
+            k = s.stage_distinct_parents(self.parent.data_ptr(), self.n, self.n_total, self.uniq_buf.data_ptr(), self.slot_buf.data_ptr())
+            return self.uniq_buf[:k], self.slot_buf
         par = self.parent.to(torch.int64)
         self.mark.zero_()
         self.mark[par] = True
         pos = torch.cumsum(self.mark, 0, dtype=torch.int32)
         uniq = self.mark.nonzero(as_tuple=False).squeeze(1)
-        inv = pos[par] - 1
-        self.shard.export_records(self.loc.data_ptr())
-        self._sync()
-        owner = torch.div(uniq, n, rounding_mode="floor")
-        local = uniq - owner * n
-        send_counts = torch.bincount(owner, minlength=world)
+        return uniq, (pos[par] - 1).to(torch.int32).contiguous()
+
+    def _records_at(self, local_idx, out):
+        """Records of this shard's particles `local_idx` (int64 tensor) -> `out` ((k, 4) float64 tensor)."""
+        s = self.shard
+        if local_idx.numel() == 0:
+            return out
+        if hasattr(s, "export_records_at"):
+            s.export_records_at(local_idx.data_ptr(), int(local_idx.numel()), out.data_ptr())
+        else:
+            s.export_records(self.loc.data_ptr())
+            self._sync()
+            out.copy_(self.loc[local_idx])
+        return out
+
+    def _fetch_parents(self):
+        """self.parent (global indices) -> (compact record table, position of every child's parent in it).  Distinct
+        parents only; the ones this rank owns are read locally, the others requested from their owners."""
+        n, world = self.n, self.world
+        uniq, inv = self._distinct()
+        k = int(uniq.numel())
+        table = torch.empty((k, 4), dtype=torch.float64, device=self.device)
+        # owners' shares of the ascending list: world + 1 boundaries
+        bounds = torch.searchsorted(uniq, torch.arange(world + 1, dtype=torch.int64, device=self.device) * n)
+        sc = (bounds[1:] - bounds[:-1]).tolist()
+        local = (uniq - torch.div(uniq, n, rounding_mode="floor") * n).contiguous()
         if world == 1:
-            table = self.loc[local]
+            self._records_at(local, table)
             self.exchange_bytes.update(requests_sent=0, records_received=0, distinct_remote_parents=0)
-            return table.contiguous(), inv.to(torch.int32).contiguous()
+            return table, inv
+        send_counts = torch.tensor(sc, dtype=torch.int64, device=self.device)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        sc, rcv = send_counts.tolist(), recv_counts.tolist()
+        rcv = recv_counts.tolist()
         req_in = torch.empty(int(sum(rcv)), dtype=torch.int64, device=self.device)
-        dist.all_to_all_single(req_in, local.contiguous(), output_split_sizes=rcv, input_split_sizes=sc, group=self.group)
-        reply = self.loc[req_in].contiguous()                            # the records the other ranks asked this one for
-        table = torch.empty((int(uniq.numel()), 4), dtype=torch.float64, device=self.device)
+        dist.all_to_all_single(req_in, local, output_split_sizes=rcv, input_split_sizes=sc, group=self.group)
+        reply = torch.empty((int(req_in.numel()), 4), dtype=torch.float64, device=self.device)
+        self._records_at(req_in, reply)                                  # the records the other ranks asked this one for
+        self._sync()
         dist.all_to_all_single(table, reply, output_split_sizes=sc, input_split_sizes=rcv, group=self.group)
-        remote = int(uniq.numel()) - sc[self.rank]
+        remote = k - sc[self.rank]
         self.exchange_bytes.update(requests_sent=8 * remote, records_received=32 * remote, distinct_remote_parents=remote)
-        return table, inv.to(torch.int32).contiguous()
+        return table, inv
 
     def update(self, action, obs):
         s = self.shard

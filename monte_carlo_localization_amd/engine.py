@@ -28,7 +28,7 @@ EXPORTS = [
     "mcl_stage_propagate", "mcl_stage_weights", "mcl_stage_finish", "mcl_scan_weights", "mcl_export_state",
     "mcl_get_scalars", "mcl_host_sensor_table", "mcl_host_skip_field", "mcl_init_particles_pose", "mcl_init_global",
     "mcl_update_scan", "mcl_get_ray_kernel_id", "mcl_host_skip_field_dir", "mcl_host_skip_field_wedge", "mcl_export_records", "mcl_get_effective_sample_size", "mcl_get_host_scalars", "mcl_stage_resample_records", "mcl_stage_resample", "mcl_stage_rays",
-    "mcl_set_reserved_cus", "mcl_stage_resample_indices", "mcl_stage_motion_records",
+    "mcl_set_reserved_cus", "mcl_stage_resample_indices", "mcl_stage_motion_records", "mcl_stage_distinct_parents", "mcl_export_records_at",
     "mcl_group_create", "mcl_group_destroy", "mcl_group_last_error", "mcl_group_size", "mcl_group_engine", "mcl_group_set_map",
     "mcl_group_set_beam_angles", "mcl_group_set_particles", "mcl_group_init_particles_pose", "mcl_group_init_global",
     "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
@@ -357,6 +357,18 @@ class Engine:
         self._chk(self.lib.mcl_stage_resample_indices(self._h, C.c_void_p(d_cdf), C.c_int64(n_parents), C.c_uint64(q_total),
                                                       C.c_int64(child_first), C.c_int64(n_children_total), C.c_void_p(d_parent_idx)),
                   "mcl_stage_resample_indices")
+
+    def stage_distinct_parents(self, d_parent, n_children, n_total, d_distinct, d_slot) -> int:
+        """Distinct parents (ascending) of `n_children` global parent indices + every child's position among them; returns
+        their number.  All pointers are device memory (int32 in, int64 / int32 out)."""
+        cnt = C.c_int64(0)
+        self._chk(self.lib.mcl_stage_distinct_parents(self._h, C.c_void_p(d_parent), C.c_int64(n_children), C.c_int64(n_total),
+                                                      C.c_void_p(d_distinct), C.c_void_p(d_slot), C.byref(cnt)), "mcl_stage_distinct_parents")
+        return int(cnt.value)
+
+    def export_records_at(self, d_index, count, d_out):
+        """Packed records of the listed local particles (device int64 indices) -> d_out[count] (device)."""
+        self._chk(self.lib.mcl_export_records_at(self._h, C.c_void_p(d_index), C.c_int64(count), C.c_void_p(d_out)), "mcl_export_records_at")
 
     def stage_motion_records(self, d_records, n_records, d_record_of_child, child_first, n_children_total, action):
         a = _c(action, np.float64)

@@ -591,15 +591,20 @@ def test_random_maps_every_kernel(orc, engine_mod, maps_mod, seed):
         assert np.array_equal(e.log_weights(), logw), rk
 
 
-def test_update_graph_replay_is_bit_identical(orc, engine_mod, spielberg):
-    """graph_mode: from the second update on the small-update path replays everything after the resampling kernel as one
-    hipGraph.  Same seed with and without it: identical particles, weights, pose and resample indices over many updates,
-    including sensor_update calls, a new scan every update and a change of the particle set in between."""
+@pytest.mark.parametrize("n,poll", [(3000, None), (3000, "0"), (9000, None)])
+def test_update_graph_replay_is_bit_identical(orc, engine_mod, spielberg, n, poll, monkeypatch):
+    """graph_mode 0 (the default) shortens small updates from the second one on: up to 8192 particles an update is three
+    launches (scan -> table rows inside the resampling kernel, k_rays_skip on the static table, k_tiny_tail writing the
+    result block to pinned memory, the host spinning on its stamp unless MCL_TINY_POLL=0); above that everything after
+    the resampling kernel is replayed as one hipGraph.  graph_mode 1 is the launch-by-launch path.  Same seed on both:
+    identical particles, weights, pose and resample indices over many updates, including sensor_update calls, a new scan
+    every update and a change of the particle set in between."""
+    if poll is not None:
+        monkeypatch.setenv("MCL_TINY_POLL", poll)
     ang = orc.beam_angles(angle_step=18)                      # 61 beams: the stock configuration
     base = load("scan_Spielberg_map_origin.npz")["ranges"][::18].copy()
     rng = np.random.default_rng(8)
     scans = [np.clip(base + rng.normal(0, 0.05, base.size), 0.0, 30.0).astype(np.float32) for _ in range(12)]
-    n = 3000
     out = {}
     for gm in (1, 0):
         e = make_engine(engine_mod, spielberg, ang, n, seed=3, graph_mode=gm)
