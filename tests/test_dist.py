@@ -61,3 +61,42 @@ def test_two_ranks_equal_one_rank_hip_engine(tmp_path, mode, overlap):
     two = run_world("engine", d2, 2, 4096, 4, mode, overlap)
     one = run_world("engine", d1, 1, 8192, 4, mode)
     check_equal(two, one, 4096)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_children,n_total,span", [(5000, 40000, 40000), (70000, 1 << 20, 3000), (4096, 4096, 4096), (1000, 33, 33)])
+def test_engine_distinct_parents_and_records_at(n_children, n_total, span):
+    """mcl_stage_distinct_parents (bitmap + popcount prefix) against numpy.unique, and mcl_export_records_at against the
+    particles themselves: what dist.py's exchange is built from."""
+    import torch
+    from conftest import GOLDEN
+    from monte_carlo_localization_amd import engine, maps
+    import __graft_entry__ as g
+    g.build()
+    rng = np.random.default_rng(n_children)
+    dev = torch.device("cuda", 0)
+    m = maps.load_npz(os.path.join(GOLDEN, "map_Spielberg_map.npz"))
+    n = 6000
+    e = engine.Engine(max_particles=n, seed=1)
+    e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+    e.set_beam_angles(np.linspace(-2.0, 2.0, 31).astype(np.float32))
+    p = rng.normal(0, 1.0, (3, n))
+    e.set_particles(p, np.full(n, 1.0 / n))
+    par = rng.integers(0, span, n_children).astype(np.int32)
+    if span > 100:
+        par[: n_children // 2] = par[0]                      # a heavy parent, as after a peaked update
+        par[-1] = n_total - 1                                # the last bit of the last word
+    d_par = torch.from_numpy(par).to(dev)
+    uniq = torch.empty(n_children, dtype=torch.int64, device=dev)
+    slot = torch.empty(n_children, dtype=torch.int32, device=dev)
+    k = e.stage_distinct_parents(d_par.data_ptr(), n_children, n_total, uniq.data_ptr(), slot.data_ptr())
+    want_u, want_inv = np.unique(par, return_inverse=True)
+    assert k == want_u.size
+    assert np.array_equal(uniq[:k].cpu().numpy(), want_u)
+    assert np.array_equal(slot.cpu().numpy(), want_inv.astype(np.int32))
+    idx = torch.from_numpy(rng.integers(0, n, 777)).to(dev)
+    out = torch.empty((777, 4), dtype=torch.float64, device=dev)
+    e.export_records_at(idx.data_ptr(), 777, out.data_ptr())
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :3], p[:, idx.cpu().numpy()].T)
+    e.close()
