@@ -165,3 +165,46 @@ def test_work_list_overflow_falls_back_on_every_update(orc, engine_mod, spielber
     assert out["auto"][0] == ["k_rays_skip"] * 4          # what finally produced each update's log-weights
     for k in (1, 2, 3):
         assert np.array_equal(out["auto"][k], out["skip"][k])
+
+
+def test_range_beyond_the_windowed_kernels_takes_k_rays_skip(orc, engine_mod, spielberg):
+    """k_rays_sweep's windows are 256 cells wide, k_rays_cell's 280: a range of more than 243 px leaves neither enough
+    play (mcl_rays_sweep.h sweep_window_fits; mcl_set_map's qside).  AUTO then stays on k_rays_skip at any size, an
+    explicit MCL_RAYS_SWEEP is refused; the log-weights equal the oracle's."""
+    res = 0.0485                                                     # 12 m / 0.0485 = 247 px
+    om = orc.OracleMap(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
+    assert 243 < om.max_range_px <= 255
+    ang = orc.beam_angles(angle_step=8)                              # 136 beams: 65 536 x 136 > 2^23 rays
+    n = 65536
+    p = tracking_cloud(np.random.default_rng(12), n, sig=(0.2, 0.2, 0.3))
+    obs = scan1081()[::8].copy()
+    e = engine_mod.Engine(max_particles=n, seed=1)
+    e.set_map(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
+    e.set_beam_angles(ang)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(obs)
+    assert e.ray_kernel_name() == "k_rays_skip"
+    assert np.array_equal(e.log_weights(), oracle_logw(orc, om, p, ang, obs))
+    e.close()
+    e = engine_mod.Engine(max_particles=n, seed=1, ray_kernel=engine_mod.RAYS_SWEEP)
+    e.set_map(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
+    e.set_beam_angles(ang)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    with pytest.raises(engine_mod.EngineError):
+        e.sensor_update(obs)
+    e.close()
+
+
+def test_long_range_map_single_unit_runs_and_sparse_cloud(orc, engine_mod, sibal1, sibal1_oracle):
+    """240-px range (0.05 m map, 12 m): 11 cells of play per window.  A cloud spread over many cells makes k_sweep_plan
+    cut the runs down (and still leaves some particles to k_rays_far); a tight one keeps long runs.  Same sums as the
+    oracle in both."""
+    om = sibal1_oracle
+    ang = orc.beam_angles(angle_step=8)
+    obs = np.full(ang.size, 4.0, np.float32)
+    rng = np.random.default_rng(77)
+    n = 70000
+    for spread in (0.05, 1.5):
+        p = np.stack([rng.normal(0.3, spread, n), rng.normal(0.1, spread, n), rng.uniform(-np.pi, np.pi, n)])
+        got, c = sweep_logw(engine_mod, sibal1, ang, p, obs)
+        assert np.array_equal(got, oracle_logw(orc, om, p, ang, obs)), spread
