@@ -89,7 +89,7 @@ MAX_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md chip table: max clock 2400 
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 
 
-def roofline_block(kernel_name, k_ms, n, B, sbar):
+def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True):
     """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time.
 
     gfx950 issues a wave64 instruction of the simple classes (v_add/v_sub/v_and/v_or/v_lshrrev/v_mov, fp32 add/mul/fma) in
@@ -113,7 +113,9 @@ def roofline_block(kernel_name, k_ms, n, B, sbar):
             inp = json.load(open(ROOFLINE_INPUTS))
         except Exception:
             inp = None
-    if inp and inp.get("kernel") == kernel_name and inp.get("particles") == n and inp.get("beams") == B:
+    # the committed instruction counts are those of the DEFAULT workload (Spielberg_map, tracking-regime cloud): another map
+    # or cloud executes a different number of probe trips, so nothing is priced for it
+    if inp and profiled_workload and inp.get("kernel") == kernel_name and inp.get("particles") == n and inp.get("beams") == B:
         I, T = inp["valu_insts_per_launch"], inp["lds_insts_per_launch"]
         cycles = 4.0 * I - 2.0 * (2.0 * T + (2.0 / 11.0) * (I - 7.0 * T))
         floor_ms = cycles / (SIMDS * MAX_CLOCK_GHZ * 1e6)
@@ -131,7 +133,7 @@ def roofline_block(kernel_name, k_ms, n, B, sbar):
                       "traffic_source": inp.get("hbm_bytes_source")})
     else:
         block.update({"achieved": None, "peak": SIMDS * MAX_CLOCK_GHZ, "unit": "G SIMD issue cycles/s", "frac": None,
-                      "note": "no profile inputs for this kernel / size under profiles/: VALU bound not priced"})
+                      "note": "no profile inputs for this kernel / size / workload under profiles/: VALU bound not priced"})
     return block
 
 
@@ -270,7 +272,8 @@ def main():
         except Exception:
             sbar_timed = sbar_first = None       # no oracle on this box: the algorithmic figure falls back to the survey's value
         k_ms = float(np.mean(ray_ms))
-        roof = roofline_block(e.ray_kernel_name(), k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4)
+        roof = roofline_block(e.ray_kernel_name(), k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4,
+                              profiled_workload=(args.map == "spielberg" and args.regime == "tracking"))
         roof["algorithmic"]["s_bar_first_update"] = sbar_first
         line = {
             "metric": "MCL updates/sec (particle*beam/s)",
