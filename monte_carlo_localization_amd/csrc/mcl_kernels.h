@@ -1294,11 +1294,15 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int c
     const int tx0 = bbox[0] >> 5, ty0 = bbox[1] >> 5;
     const uint32_t ntx = (uint32_t)((bbox[2] >> 5) - tx0 + 1), nty = (uint32_t)((bbox[3] >> 5) - ty0 + 1);
     const uint64_t ntiles = (uint64_t)ntx * nty;
-    int cs = 0;                                           // coarsen the in-tile resolution until the cells fit
-    while (cs < 5 && ((ntiles << (10 - 2 * cs)) > kSortKeySpace)) ++cs;
+    // Heading first: the lanes of a wave must agree on which wedge their beams are in, so six heading bits (5.6 degrees)
+    // are kept while the in-tile resolution is coarsened to make room (a particle set spread over a large bounding box
+    // -- several far-apart clusters -- otherwise spends the whole key space on empty cells: 80 % slower ray stage);
+    // only a bounding box of more than 2^14 tiles gives heading bits up.  What is left over goes to the heading.
+    int cs = 0, tb = 6;
+    while (cs < 5 && ((ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) ++cs;
+    while (tb > 0 && ((ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) --tb;
     const int inner = 5 - cs;                             // log2 of the bucket grid inside one tile
     uint64_t ncell = ntiles << (2 * inner);
-    int tb = 0;                                           // heading bits that still fit (at most 8)
     while (tb < 8 && (ncell << (tb + 1)) <= kSortKeySpace) ++tb;
     const uint32_t tile = (uint32_t)((cy >> 5) - ty0) * ntx + (uint32_t)((cx >> 5) - tx0);
     const uint32_t ix = (uint32_t)(cx & 31) >> cs, iy = (uint32_t)(cy & 31) >> cs;
