@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, make_engine
+from conftest import GOLDEN, make_engine, tracking_cloud
 
 pytestmark = pytest.mark.gpu
 ACTION = (0.05, 0.0, 0.01)
@@ -126,3 +126,28 @@ def test_determinism_same_seed_same_bits(orc, engine_mod, spielberg):
         outs.append((e.get_particles(), e.get_weights(), e.resample_indices(), e.expected_pose()))
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+def test_nine_million_particles_plan_in_two_passes(orc, engine_mod, spielberg):
+    """k_sweep_plan handles 1024 blocks of 8 units per pass: 9 000 000 particles are 8790 units = 1099 blocks, i.e. the
+    second pass and its carry.  Every log-weight of k_rays_sweep equals k_rays_cell's (a run the plan lost would leave
+    its slots' sums unwritten), and a sample equals the oracle's."""
+    n = 9_000_000
+    ang = orc.beam_angles(angle_step=18)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].astype(np.float32).copy()
+    rng = np.random.default_rng(99)
+    p = tracking_cloud(rng, n, sig=(0.4, 0.4, 0.4))
+    out = {}
+    for name, rk in (("sweep", engine_mod.RAYS_SWEEP), ("cell", engine_mod.RAYS_CELL)):
+        e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=rk)
+        e.set_particles(p, np.full(n, 1.0 / n))
+        e.sensor_update(obs)
+        assert e.ray_kernel_name() == "k_rays_" + name
+        out[name] = e.log_weights()
+        e.close()
+    assert np.array_equal(out["sweep"], out["cell"])
+    om = orc.OracleMap(spielberg.data, spielberg.resolution, spielberg.origin_x, spielberg.origin_y)
+    pick = rng.choice(n, 4096, replace=False)
+    T = orc.sensor_table(om.max_range_px)
+    logw, _, _ = orc.eng_log_weights(om, p[:, pick], ang, orc.obs_index(obs, om), orc.eng_log_table(T))
+    assert np.array_equal(out["sweep"][pick], logw)
