@@ -554,13 +554,12 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (sweep) {
             // k_rays_sweep: a work item is (run of 1024-particle units, G wedges); the G wedges of a group share one
             // partial-sum array.  G = 2 (measured at 4M x 1081, ray kernel / update ms, same device: G = 1 6.50 / 7.87,
-            // 2 6.54 / 7.86, 4 6.69 / 7.97, 8 6.99 / 8.27, 16 7.62 / 8.90: a longer item is a longer tail) unless that
-            // leaves fewer than four items per workgroup.
+            // 2 6.54 / 7.86, 4 6.69 / 7.97, 8 6.99 / 8.27, 16 7.62 / 8.90: a longer item is a longer tail); G = 1 up to 2M
+            // particles, where the finer items balance better than the sixteen partial-sum arrays cost (262 144 x 1081:
+            // 0.58 / 0.80 -> 0.53 / 0.77, 1M: 1.72 / 2.13 -> 1.63 / 2.07; at 4M G = 1 and 2 are level).
             const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
-            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : 2;
+            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : (M <= 2048 ? 1 : 2);
             if (sweep_g > mcl::kWedges || (mcl::kWedges % sweep_g) != 0) sweep_g = 2;
-            if (h->env_sweep_g <= 0)
-                while (sweep_g > 1 && M * (mcl::kWedges / sweep_g) < 4 * (int64_t)max_wg) sweep_g >>= 1;
             nsl = (int)M;
         }
         const int items_per_slice = sweep ? mcl::kWedges / sweep_g : (cell ? mcl::kWedges : 4);
