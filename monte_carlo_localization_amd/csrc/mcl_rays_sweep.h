@@ -1,21 +1,24 @@
 // mcl_rays_sweep.h — K3e: k_rays_sweep, the default ray-cast + likelihood kernel from 65 536 particles (MCL_RAYS_SWEEP).
 //
-// Same algorithm and the same bits as k_rays_cell (cell-sorted particles, one particle per lane, 16 wedge fields, 22-bit
-// fixed point with a boundary guard, fix-up list, far flags; reference rows Q, C, E = cpp:524-650).  What changed, and why:
+// Same algorithm and the same results as k_rays_cell (cell-sorted particles, one particle per lane, 16 wedge fields, fixed
+// point with a boundary guard, fix-up list, far flags; reference rows Q, C, E = cpp:524-650).  What is different, and why:
 //
 //   * gfx950 issues v_add/v_and/v_lshrrev/v_mov and the fp32 add/mul/fma every 2 cycles per wave64 but v_mad_*24,
 //     every three-operand integer op, v_min/v_max, shifts left, conversions, compares and all fp64 every 4
-//     (profiles/r02_op_rates.txt).  The probe trip and the per-ray code are rebuilt around that table:
+//     (profiles/r02_op_rates.txt).  The probe trip and the per-ray code are built around that table:
+//       - positions are [cell:8][fraction:24] in a 256 x 256-cell window stored MIRRORED per quadrant (every ray of a
+//         wedge runs towards +x, +y): both direction components are unsigned 24-bit operands, the position advances by
+//         T += skip * X (no end point), and the LDS address of a cell is its two top bytes: one v_perm_b32;
 //       - the guard bias is folded into the window-relative origin, so the fraction test is two v_and (2 cycles each)
-//         and one v_min3 instead of two v_lshl_add and one v_min3;
+//         and one v_min3;
 //       - the table is read as fp64 (no v_cvt_f64_f32), has 127 extra rows below "no hit" (no clamp of the samples
 //         left) and one all-zero row that undecided rays are pointed at (no select, no exec juggling);
 //       - the beam walk of the slots every live lane of the wave has is ONE asm block with its own vmcnt counting,
 //         induction variables advanced by per-lane increments (0 for a lane without rays) and undecided rays parked in
 //         two registers until the pass is over.
-//   * A work item is (slice, group of G wedges): the workgroup keeps the running sum of a particle in part[group][slot]
-//     (sorted order, plain loads and stores by the one lane that owns the slot), so the 16 fp64 atomics per particle of
-//     k_rays_cell are gone and k_combine_logw reads G-fold fewer partial sums.
+//   * A work item is (run of units, group of G wedges), planned on the device per update (k_sweep_plan): the workgroup
+//     keeps the running sum of a particle in part[group][slot] (sorted order, plain loads and stores by the one lane
+//     that owns the slot), so the 16 fp64 atomics per particle of k_rays_cell are gone.
 #pragma once
 
 namespace mcl {
