@@ -1,8 +1,10 @@
 """First end-to-end GPU parity checks through the C ABI (expanded in the other test_gpu_* files)."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import make_engine, tracking_cloud
+from conftest import GOLDEN, make_engine, tracking_cloud
 
 pytestmark = pytest.mark.gpu
 
@@ -51,3 +53,30 @@ def test_ray_steps_and_logw_match_oracle(orc, engine_mod, spielberg, spielberg_o
 def test_full_step_matches_reference_chain(orc, engine_mod, spielberg, spielberg_oracle):
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_small_update_path_against_the_oracle(orc, engine_mod, spielberg, spielberg_oracle):
+    """From the second update on a small update takes the three-launch path (table rows of the scan computed inside the
+    resampling kernel, k_rays_skip reading the static table through them, result block written to pinned memory): ray
+    steps and log-weights of the particles it produced equal the oracle's, and the scalars it reports equal what the
+    log-weights imply."""
+    om = spielberg_oracle
+    ang = orc.beam_angles(angle_step=18)
+    base = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].astype(np.float32)
+    rng = np.random.default_rng(4)
+    n = 1500
+    e = make_engine(engine_mod, spielberg, ang, n, seed=11, keep_ray_steps=1)
+    e.init_particles_pose((0.0, 0.0, 0.0), n)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    for k in range(4):
+        scan = np.clip(base + rng.normal(0, 0.05, base.size), 0.0, 30.0).astype(np.float32)
+        e.update((0.05, 0.0, 0.01), scan)
+        p = e.get_particles()
+        logw, steps, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(scan, om), L, want_steps=True)
+        assert np.array_equal(e.ray_steps(), steps), k
+        assert np.array_equal(e.log_weights(), logw), k
+        w = e.get_weights()
+        ref = np.exp(logw - logw.max())
+        assert np.allclose(w * (ref.sum() / w.sum()), ref, rtol=1e-12, atol=0.0), k
+        assert e.ray_kernel_name() == "k_rays_skip"
+    e.close()
