@@ -70,9 +70,10 @@ typedef enum {
                                      windows, two workgroups per CU                                    */
     MCL_RAYS_CELL = 4,            /* QUAD on particles ordered by grid cell and heading, one particle per
                                      lane: the lanes of a wave trace near-identical rays               */
-    MCL_RAYS_SWEEP = 5            /* CELL with a workgroup walking several wedges of a slice (partial sums kept by
-                                     the owning lane instead of 16 atomics per particle) and the probe / per-ray
-                                     code rebuilt around gfx950's 2-cycle and 4-cycle VALU classes     */
+    MCL_RAYS_SWEEP = 5            /* CELL with work items planned on the device (runs of units x wedge groups, partial
+                                     sums kept by the owning lane instead of 16 atomics per particle), 256-cell
+                                     mirrored windows addressed by one v_perm_b32 and the probe / per-ray code
+                                     built around gfx950's 2-cycle and 4-cycle VALU classes; ranges up to 243 px */
 } mcl_ray_kernel;
 
 /* Upper bound (exclusive) on max_particles and on the particle total of a sharded set: weights are quantised to 2^-36 and
@@ -100,9 +101,13 @@ typedef struct {
                                        r in 1..1000: resample only when the effective sample size
                                        (sum w)^2 / sum w^2 of the previous update is below r/1000 * N, otherwise the
                                        particles keep their identity and their weights multiply */
-    int32_t graph_mode;             /* small updates are launch-bound (about twenty launches): 0 (default) and 2 = replay
-                                       the part of mcl_update after the resampling kernel as one hipGraph once a first
-                                       update has run with the same sizes (k_rays_skip path only); 1 = never */
+    int32_t graph_mode;             /* small updates are a chain of dependent launches: 0 (default) and 2 = shorten it once
+                                       a first update has run with the same sizes (k_rays_skip path only): up to 8192
+                                       particles mcl_update is three launches whose last one writes the result block to
+                                       pinned host memory, where the host polls a stamp (MCL_TINY_POLL=0 in the
+                                       environment at mcl_create: wait for the stream instead); above that the part after
+                                       the resampling kernel is replayed as one hipGraph.  1 = launch by launch.  The
+                                       results do not depend on it. */
     int32_t reserved[3];
 } mcl_config_t;
 
