@@ -98,6 +98,7 @@ class ShardedFilter:
         if local_idx.numel() == 0:
             return out
         if hasattr(s, "export_records_at"):
+            self._sync()             # the engine has its own stream: the indices (tensor ops / a collective) must be complete
             s.export_records_at(local_idx.data_ptr(), int(local_idx.numel()), out.data_ptr())
         else:
             s.export_records(self.loc.data_ptr())
