@@ -18,9 +18,9 @@ integer scan and the log-weights are exact fp64 sums, resample indices and weigh
 for any number of ranks.  (Several GPUs driven by ONE process do the same through `mcl_group_*` in the
 library itself, with peer copies and peer pointers instead of collectives.)
 
-`shard` is anything with the staging interface of engine.Engine (export_state / export_records /
-scan_weights / stage_resample_indices / stage_motion_records / stage_rays / scalars / stage_weights /
-stage_finish); tests drive this class on CPU tensors over gloo with an oracle-backed stand-in that lives
+`shard` is anything with the staging interface of engine.Engine (export_state / scan_weights /
+stage_resample_indices / stage_distinct_parents / export_records_at / stage_motion_records / stage_rays / scalars /
+stage_weights / stage_finish); tests drive this class on CPU tensors over gloo with an oracle-backed stand-in that lives
 under tests/.
 """
 from __future__ import annotations
@@ -50,8 +50,6 @@ class ShardedFilter:
         f64, i64, i32 = torch.float64, torch.int64, torch.int32
         n, nt = self.n, self.n * self.world
         self.n_total = nt
-        # (x, y, theta, -) records of this shard: only a shard without export_records_at needs the whole copy
-        self.loc = None if hasattr(shard, "export_records_at") else torch.empty((n, 4), dtype=f64, device=device)
         self.loc_q = torch.empty(n, dtype=i64, device=device)           # uint64 bits
         self.q_total = None                                              # global fixed-point weight total, once known
         self.pending_q = None                                            # async gather of the weights issued by the previous update
@@ -60,8 +58,6 @@ class ShardedFilter:
         self.parent = torch.empty(n, dtype=i32, device=device)          # global parent index of every local child
         self.uniq_buf = torch.empty(n, dtype=i64, device=device)        # distinct parents of the local children (ascending)
         self.slot_buf = torch.empty(n, dtype=i32, device=device)        # every child's position among them
-        # only a shard without stage_distinct_parents (the tests' CPU stand-in) needs the n_total-sized flags
-        self.mark = None if hasattr(shard, "stage_distinct_parents") else torch.zeros(nt, dtype=torch.bool, device=device)
         self.pose = np.zeros(3)
         self.exchange_bytes = dict(weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
 
@@ -79,31 +75,17 @@ class ShardedFilter:
 
     def _distinct(self):
         """self.parent (global indices) -> (distinct parents ascending = grouped by owner, position of every child's parent
-        among them).  The engine does it with a bitmap over the global indices (passes over n_total / 32 words); a shard
-        without that call (the CPU stand-in of the tests) gets the same by mark / prefix-sum / compact on tensors."""
-        s = self.shard
-        if hasattr(s, "stage_distinct_parents"):
-            k = s.stage_distinct_parents(self.parent.data_ptr(), self.n, self.n_total, self.uniq_buf.data_ptr(), self.slot_buf.data_ptr())
-            return self.uniq_buf[:k], self.slot_buf
-        par = self.parent.to(torch.int64)
-        self.mark.zero_()
-        self.mark[par] = True
-        pos = torch.cumsum(self.mark, 0, dtype=torch.int32)
-        uniq = self.mark.nonzero(as_tuple=False).squeeze(1)
-        return uniq, (pos[par] - 1).to(torch.int32).contiguous()
+        among them): a bitmap over the global indices and its popcount prefix inside the engine (passes over
+        n_total / 32 words, not n_total elements)."""
+        k = self.shard.stage_distinct_parents(self.parent.data_ptr(), self.n, self.n_total, self.uniq_buf.data_ptr(), self.slot_buf.data_ptr())
+        return self.uniq_buf[:k], self.slot_buf
 
     def _records_at(self, local_idx, out):
         """Records of this shard's particles `local_idx` (int64 tensor) -> `out` ((k, 4) float64 tensor)."""
-        s = self.shard
         if local_idx.numel() == 0:
             return out
-        if hasattr(s, "export_records_at"):
-            self._sync()             # the engine has its own stream: the indices (tensor ops / a collective) must be complete
-            s.export_records_at(local_idx.data_ptr(), int(local_idx.numel()), out.data_ptr())
-        else:
-            s.export_records(self.loc.data_ptr())
-            self._sync()
-            out.copy_(self.loc[local_idx])
+        self._sync()                 # the engine has its own stream: the indices (tensor ops / a collective) must be complete
+        self.shard.export_records_at(local_idx.data_ptr(), int(local_idx.numel()), out.data_ptr())
         return out
 
     def _fetch_parents(self):

@@ -91,6 +91,18 @@ class OracleShard:
         self.idx = self._draw(d_cdf, n_parents, q_total, child_first, n_children_total)
         _view(d_parent_idx, self.n, ctypes.c_int32, np.int32)[:] = self.idx
 
+    def stage_distinct_parents(self, d_parent, n_children, n_total, d_distinct, d_slot):
+        par = _view(d_parent, n_children, ctypes.c_int32, np.int32)
+        uniq, inv = np.unique(par, return_inverse=True)
+        _view(d_distinct, n_children, ctypes.c_int64, np.int64)[:uniq.size] = uniq
+        _view(d_slot, n_children, ctypes.c_int32, np.int32)[:] = inv.astype(np.int32)
+        return int(uniq.size)
+
+    def export_records_at(self, d_index, count, d_out):
+        idx = _view(d_index, count, ctypes.c_int64, np.int64)
+        out = _view(d_out, 4 * count, ctypes.c_double, np.float64).reshape(count, 4)
+        out[:, 0] = self.p[0, idx]; out[:, 1] = self.p[1, idx]; out[:, 2] = self.p[2, idx]; out[:, 3] = 0.0
+
     def stage_motion_records(self, d_records, n_records, d_record_of_child, child_first, n_children_total, action):
         rec = _view(d_records, 4 * n_records, ctypes.c_double, np.float64).reshape(n_records, 4)
         slot = _view(d_record_of_child, self.n, ctypes.c_int32, np.int32)
