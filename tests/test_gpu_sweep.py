@@ -208,3 +208,26 @@ def test_long_range_map_single_unit_runs_and_sparse_cloud(orc, engine_mod, sibal
         p = np.stack([rng.normal(0.3, spread, n), rng.normal(0.1, spread, n), rng.uniform(-np.pi, np.pi, n)])
         got, c = sweep_logw(engine_mod, sibal1, ang, p, obs)
         assert np.array_equal(got, oracle_logw(orc, om, p, ang, obs)), spread
+
+
+def test_three_updates_each_checked_against_the_oracle(orc, engine_mod, spielberg, spielberg_oracle):
+    """The sort keeps its histogram all-zero between updates by clearing the used tiles only (k_hist_clear); a residue
+    would misplace particles in the sorted order of the NEXT update and leave their sums unwritten.  Three updates of
+    k_rays_sweep, the log-weights of the particles each produced compared with the oracle's."""
+    om = spielberg_oracle
+    ang = orc.beam_angles(angle_step=8)
+    base = scan1081()[::8].copy()
+    rng = np.random.default_rng(6)
+    n = 70000
+    e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=engine_mod.RAYS_SWEEP, seed=5)
+    e.init_particles_pose((0.0, 0.0, 0.0), n)
+    T = orc.sensor_table(om.max_range_px)
+    L = orc.eng_log_table(T)
+    for k in range(3):
+        obs = np.clip(base + rng.normal(0, 0.03, base.size), 0.0, 30.0).astype(np.float32)
+        e.update((0.05, 0.0, 0.01), obs)
+        p = e.get_particles()
+        logw, _, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L)
+        assert e.ray_kernel_name() == "k_rays_sweep"
+        assert np.array_equal(e.log_weights(), logw), k
+    e.close()
