@@ -130,7 +130,8 @@ struct mcl_engine {
     uint32_t *d_perm = nullptr, *d_skey = nullptr, *d_srank = nullptr;   // cap each
     uint32_t *d_tile_used = nullptr;    // one mark per kHistTile buckets of the sort histogram: touched by this update's sort
     uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
-    int *d_bbox = nullptr;              // 4
+    int *d_bbox = nullptr;              // 6: bounding box, occupied tiles, numbering in use
+    int *d_tilemap = nullptr, *d_tilemark = nullptr;   // kSortMaxTiles each: tile of the map -> compact id; marks of the occupied tiles (zero between sorts)
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
     size_t slice_mean_capacity = 0;
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
@@ -603,10 +604,15 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const unsigned nb256 = (unsigned)((n + 255) / 256);
             const int nparts = (int)(mcl::kSortKeySpace / mcl::kHistTile);
             const int bstride = n >= (1 << 20) ? 16 : 1;
+            // occupied tiles of the map are numbered compactly when the map has at most kSortMaxTiles of them (bbox[5] says so)
+            const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
+            const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
             hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0,
-                               h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox);
+                               h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox, tiles_ok ? h->d_tilemark : (int *)nullptr, ntx_abs);
+            if (tiles_ok)
+                hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, h->d_tilemark, h->d_tilemap, ntx_abs * nty_abs);
             hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
-                               h->d_skey, h->d_srank, h->d_tile_used);
+                               h->d_skey, h->d_srank, h->d_tile_used, h->d_tilemap, ntx_abs);
             hipLaunchKernelGGL(mcl::k_hist_partials, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
             hipLaunchKernelGGL(mcl::k_hist_spine, dim3(1), dim3(1024), 0, h->stream, h->d_histpart, nparts);
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
@@ -896,7 +902,10 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_tile_used, (size_t)(mcl::kSortKeySpace / mcl::kHistTile) * 4));
     CRT(hipMemset(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4));          // kept all-zero between sorts (k_hist_clear)
     CRT(hipMemset(h->d_tile_used, 0, (size_t)(mcl::kSortKeySpace / mcl::kHistTile) * 4));
-    CRT(hipMalloc(&h->d_bbox, 4 * sizeof(int)));
+    CRT(hipMalloc(&h->d_bbox, 8 * sizeof(int)));
+    CRT(hipMalloc(&h->d_tilemap, (size_t)mcl::kSortMaxTiles * sizeof(int)));
+    CRT(hipMalloc(&h->d_tilemark, (size_t)mcl::kSortMaxTiles * sizeof(int)));
+    CRT(hipMemset(h->d_tilemark, 0, (size_t)mcl::kSortMaxTiles * sizeof(int)));
     CRT(hipMemset(h->d_fix_over, 0, 16));
     CRT(hipMemset(h->d_scalars, 0, 8 * sizeof(double)));
     CRT(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)));
@@ -926,7 +935,7 @@ void mcl_destroy(mcl_engine_t *h)
     graph_reset(h);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     if (clr.fix_over) for (int64_t k = i; k < 2; k += n) clr.fix_over[k] = 0ull;
     if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
     if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
-    if (clr.bbox) for (int64_t k = i; k < 4; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (int)0x80000000;
+    if (clr.bbox) for (int64_t k = i; k < 6; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (k < 4 ? (int)0x80000000 : 0);
     if (clr.hist) for (int64_t k = i; k < clr.hist_n; k += n) clr.hist[k] = 0u;
     const double t = th[i];
     pc[i] = particle_constants(x[i], y[i], t, ox, oy, res);
@@ -1265,7 +1265,8 @@ __device__ __forceinline__ int cell_of(double g, int hi)
 // bbox[0..3] = min cx, min cy, max cx, max cy over every `stride`-th particle (initialised to +big / -big by the
 // host).  A sample is enough: sort_key clamps cells into the box, so a particle outside it merely lands in an
 // edge bucket (the order is a performance matter only).
-__global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ pc, int64_t n, int stride, int Wp, int Hp, int *__restrict__ bbox)
+__global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ pc, int64_t n, int stride, int Wp, int Hp, int *__restrict__ bbox,
+                                                  int *__restrict__ tilemark = nullptr, int ntx_abs = 0)
 {
     int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
     const int64_t ns = (n + stride - 1) / stride;
@@ -1273,6 +1274,7 @@ __global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ p
         const double4 c = pc[k * stride];
         const int cx = cell_of(c.z * kSortSub, Wp * kSortSub - 1), cy = cell_of(c.w * kSortSub, Hp * kSortSub - 1);
         x0 = min(x0, cx); y0 = min(y0, cy); x1 = max(x1, cx); y1 = max(y1, cy);
+        if (tilemark) tilemark[(cy >> 5) * ntx_abs + (cx >> 5)] = 1;      // occupied tiles of the map (k_tile_compact)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1290,14 +1292,55 @@ __global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ p
     }
 }
 
+// Occupied tiles.  The key of a particle starts with its 32 x 32-cell tile; numbering only the tiles that hold (sampled)
+// particles instead of every tile of the bounding box gives the bits of the empty ones -- most of them when the set sits on
+// a few far-apart clusters -- back to cells and heading.  bbox[4] = number of occupied tiles T, bbox[5] = 1 when the
+// numbering is in use (a bounding box of at most kSortMaxTiles tiles); tilemap[t] = compact id, T for a tile no sampled
+// particle fell into (its particles share one overflow tile: the order is a performance matter only).
+constexpr int kSortMaxTiles = 8192;
+// tilemark[t] (set by k_cell_bbox for the tiles of the MAP its sampled particles fall into) -> tilemap[t] = compact id,
+// T for an unmarked tile; the marks are zeroed for the next update.  One workgroup, ntiles_abs <= kSortMaxTiles.
+__global__ __launch_bounds__(1024) void k_tile_compact(int *__restrict__ bbox, int *__restrict__ tilemark, int *__restrict__ tilemap, int ntiles_abs)
+{
+    __shared__ int ws[16];
+    __shared__ int carry_sh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles_abs; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        const int m = (t < ntiles_abs && tilemark[t] != 0) ? 1 : 0;
+        int inc = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        int id = carry_sh + inc - m;
+        for (int k = 0; k < wv; ++k) id += ws[k];
+        if (t < ntiles_abs) { tilemap[t] = m ? id : -1; tilemark[t] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = id + m;
+        __syncthreads();
+    }
+    const int T = carry_sh;
+    for (int t = threadIdx.x; t < ntiles_abs; t += 1024)
+        if (tilemap[t] < 0) tilemap[t] = T;           // (written by this thread in the loop above: t = t0 + threadIdx.x)
+    if (threadIdx.x == 0) { bbox[4] = T; bbox[5] = 1; }
+}
+
 constexpr int kSortMaxSub = MCL_SORT_MAX_SUB;        // sub-cell bits per axis a dense set may get (0: none)
-__device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int cx, int cy, double th, int64_t n, double fx = 0.0, double fy = 0.0)
+__device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const int *__restrict__ tilemap, int ntx_abs, int cx, int cy, double th,
+                                         int64_t n, double fx = 0.0, double fy = 0.0)
 {
     cx = cx < bbox[0] ? bbox[0] : (cx > bbox[2] ? bbox[2] : cx);
     cy = cy < bbox[1] ? bbox[1] : (cy > bbox[3] ? bbox[3] : cy);
     const int tx0 = bbox[0] >> 5, ty0 = bbox[1] >> 5;
     const uint32_t ntx = (uint32_t)((bbox[2] >> 5) - tx0 + 1), nty = (uint32_t)((bbox[3] >> 5) - ty0 + 1);
-    const uint64_t ntiles = (uint64_t)ntx * nty;
+    const bool compact = bbox[5] != 0;
+    const uint64_t ntiles = compact ? (uint64_t)bbox[4] + 1u : (uint64_t)ntx * nty;       // + 1: the overflow tile
+    // cells the set can be taken to live on: its bounding box, or its occupied tiles if that is less
+    double cells_est = (double)(bbox[2] - bbox[0] + 1) * (double)(bbox[3] - bbox[1] + 1);
+    if (compact && (double)bbox[4] * 1024.0 < cells_est) cells_est = (double)bbox[4] * 1024.0;
     // Heading first: the lanes of a wave must agree on which wedge their beams are in, so six heading bits (5.6 degrees)
     // are kept while the in-tile resolution is coarsened to make room (a particle set spread over a large bounding box
     // -- several far-apart clusters -- otherwise spends the whole key space on empty cells: 80 % slower ray stage);
@@ -1308,16 +1351,14 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int c
     // (first update of the global regime: ray kernel 13.8 -> 11.4 ms).  A dense set keeps single cells: there the
     // compactness of a unit is what the windows and the probe loop live on (coarser buckets cost 4-30 %).
     int cs = 0, tb = 6;
-    {
-        const double cells = (double)(bbox[2] - bbox[0] + 1) * (double)(bbox[3] - bbox[1] + 1);
-        if (cells > 0.0 && (double)n < 8.0 * cells) cs = 5;
-    }
+    if (cells_est > 0.0 && (double)n < 8.0 * cells_est) cs = 5;
     while (cs < 5 && ((ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) ++cs;
     while (tb > 0 && ((ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) --tb;
     const int inner = 5 - cs;                             // log2 of the bucket grid inside one tile
     uint64_t ncell = ntiles << (2 * inner);
     while (tb < 8 && (ncell << (tb + 1)) <= kSortKeySpace) ++tb;
-    const uint32_t tile = (uint32_t)((cy >> 5) - ty0) * ntx + (uint32_t)((cx >> 5) - tx0);
+    uint32_t tile = (uint32_t)((cy >> 5) - ty0) * ntx + (uint32_t)((cx >> 5) - tx0);
+    if (compact) tile = (uint32_t)tilemap[(cy >> 5) * ntx_abs + (cx >> 5)];
     const uint32_t ix = (uint32_t)(cx & 31) >> cs, iy = (uint32_t)(cy & 31) >> cs;
     uint64_t key = ((((uint64_t)tile << inner) | iy) << inner) | ix;
     // Bits left over once the cells have their full resolution and the heading its eight bits go to the position inside
@@ -1327,8 +1368,7 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int c
     if (cs == 0 && tb == 8) {
         // ... as long as a bucket still holds a few waves' worth: particles per cell of the bounding box, an eighth of the
         // heading bins taken as occupied (262 144 particles on 25 cells are better off without: 43 per bucket)
-        const double cells = (double)(bbox[2] - bbox[0] + 1) * (double)(bbox[3] - bbox[1] + 1);
-        double per_bucket = cells > 0.0 ? (double)n / cells / 32.0 : 0.0;
+        double per_bucket = cells_est > 0.0 ? (double)n / cells_est / 32.0 : 0.0;
         while (ss < kSortMaxSub && (ncell << (tb + 2 * (ss + 1))) <= kSortKeySpace && per_bucket >= 4.0 * 8.0) { ++ss; per_bucket *= 0.25; }
     }
     if (ss > 0) {
@@ -1346,13 +1386,14 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, int c
 
 __global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n, int Wp, int Hp,
                                                   const int *__restrict__ bbox, uint32_t *__restrict__ hist,
-                                                  uint32_t *__restrict__ key_out, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ tile_used)
+                                                  uint32_t *__restrict__ key_out, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ tile_used,
+                                                  const int *__restrict__ tilemap, int ntx_abs)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & (kSortXcds - 1);   // HW_REG_XCC_ID[3:0]
     const double4 c = pc[i];
-    const uint32_t key = sort_key(bbox, cell_of(c.z * kSortSub, Wp * kSortSub - 1), cell_of(c.w * kSortSub, Hp * kSortSub - 1), th[i], n,
+    const uint32_t key = sort_key(bbox, tilemap, ntx_abs, cell_of(c.z * kSortSub, Wp * kSortSub - 1), cell_of(c.w * kSortSub, Hp * kSortSub - 1), th[i], n,
                                   c.z * kSortSub - floor(c.z * kSortSub), c.w * kSortSub - floor(c.w * kSortSub));
     key_out[i] = key;
     // this XCD's private copy: workgroup scope keeps the read-modify-write in the local L2
