@@ -42,47 +42,70 @@ TRUE_POSE = (0.0, 0.0, 0.0)
 ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")
 
 
-def mean_probes_per_ray(m, ang, scan, p):
-    """S-bar of SURVEY.md §8(d): mean number of grid samples the reference's fixed-step march (cpp:611-650) reads per
-    ray, measured by the oracle on the given particles (3 x n, column-major)."""
-    from oracle import oracle as orc
-    om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
-    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
-    _, _, probes = orc.eng_log_weights(om, np.ascontiguousarray(p), ang, orc.obs_index(scan, om), L)
-    return probes / float(p.shape[1] * ang.size)
+def host_cpu():
+    """CPU model string and the cores this process may run on (affinity), for the cpu_baseline block."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, cores, os.cpu_count() or cores
 
 
-def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0):
-    """Oracle (kind 'port'): BASELINE config #1 = 4000 particles x 1081 beams, all host cores,
-    plus the 1-thread figure because the reference's chunk-1 dynamic schedule does not scale
-    (SURVEY D11)."""
+def cpu_baseline(m, ang, scan, true_pose=TRUE_POSE, budget_s=20.0, big=False):
+    """Oracle (kind 'port'): BASELINE config #1 = 4000 particles x 1081 beams, the as-reference step (same materialised
+    arrays, same `omp parallel for schedule(dynamic)` ray loop as cpp:593).  The figure of record is the ONE-thread one:
+    the reference's chunk-1 dynamic schedule does not scale, so more threads are reported beside it, never
+    instead of it.  Also: the reference's own six-stage split (TimingStats order, utils.hpp:51-57) and, with `big`, one
+    update at 262 144 x 1081 (~11 GB of temporaries, about a minute)."""
     from oracle import oracle as orc
     om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
     n = 4000
     T = orc.sensor_table(om.max_range_px)
     s = orc.RefStream(42)
     p, w = orc.init_particles_pose(s, true_pose, n)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))
-    out = {}
-    for label, thr, share in (("all", cores, 0.5), ("three", min(3, cores), 0.2), ("one", 1, 0.3)):   # 3 = stock num_threads (yaml:40)
+    model, cores, logical = host_cpu()
+    out, stages = {}, {}
+    for label, thr, share in (("one", 1, 0.4), ("three", min(3, cores), 0.2), ("all", cores, 0.4)):   # 3 = stock num_threads (yaml:40)
         orc.omp_threads(thr)
         pp, ww = p.copy(), w.copy()
-        times, t_start = [], time.perf_counter()
+        times, split, t_start = [], [], time.perf_counter()
         while True:
             u, nrm = s.uniforms(n), s.normals(3 * n).reshape(n, 3)
             t0 = time.perf_counter()
             r = orc.mcl_step(om, pp, ww, ACTION, ang, scan, T, u, nrm, use_omp=True, want_steps=False)
             times.append(time.perf_counter() - t0)
+            split.append(r["timing_ms"])
             pp, ww = r["particles"], np.full(n, 1.0 / n)   # the reference product underflows at 1081 beams (D4)
             if len(times) >= 2 and time.perf_counter() - t_start > budget_s * share:
                 break
-        out[label] = (n * ang.size / float(np.median(times)), len(times))
+        out[label] = (n * ang.size / float(np.median(times)), len(times), thr)
+        stages[label] = [float(v) for v in np.median(np.array(split), axis=0)]
+    base = {"value": out["one"][0], "unit": "particle*beam/s", "cores": 1, "kind": "port",
+            "sample": f"{out['one'][1]} updates of 4000 particles x {ang.size} beams (BASELINE config #1), Spielberg_map, "
+                      f"tracking-regime cloud, one thread (figure of record: the reference's omp schedule(dynamic) chunk-1 ray "
+                      f"loop, cpp:593, does not scale)",
+            "cpu_model": model, "cores_available": cores, "logical_cpus": logical,
+            "three_thread_value": out["three"][0], "all_cores_value": out["all"][0], "all_cores_threads": out["all"][2],
+            "stage_ms_one_thread": dict(zip(("resample", "motion", "query_prep", "ray_cast", "table_eval", "total"), stages["one"])),
+            "stage_ms_all_cores": dict(zip(("resample", "motion", "query_prep", "ray_cast", "table_eval", "total"), stages["all"]))}
+    if big:
+        nb = 262144
+        orc.omp_threads(1)
+        pb = np.tile(p, (1, nb // n + 1))[:, :nb].copy()
+        u, nrm = s.uniforms(nb), s.normals(3 * nb).reshape(nb, 3)
+        t0 = time.perf_counter()
+        r = orc.mcl_step(om, pb, np.full(nb, 1.0 / nb), ACTION, ang, scan, T, u, nrm, use_omp=True, want_steps=False)
+        dt = time.perf_counter() - t0
+        base["config_262144"] = {"value": nb * ang.size / dt, "seconds": dt, "threads": 1,
+                                 "stage_ms": dict(zip(("resample", "motion", "query_prep", "ray_cast", "table_eval", "total"),
+                                                      [float(v) for v in r["timing_ms"]]))}
     orc.omp_threads(cores)
-    return {"value": out["all"][0], "unit": "particle*beam/s", "cores": cores, "kind": "port",
-            "sample": f"{out['all'][1]} updates of 4000 particles x {ang.size} beams (BASELINE config #1), "
-                      f"Spielberg_map, tracking-regime cloud, omp schedule(dynamic) as cpp:593",
-            "single_thread_value": out["one"][0], "three_thread_value": out["three"][0]}
+    return base
 
 
 MAX_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md chip table: max clock 2400 MHz
@@ -137,34 +160,87 @@ def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True):
     return block
 
 
-def main():
-    # the contract is ONE JSON line on stdout: libraries that write there (RCCL prints a version banner when its first
-    # communicator is created) are pointed at stderr, the line goes to the real stdout at the end
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--beam-step", type=int, default=1, help="keep every k-th of the 1081 beams (angle_step, cpp:307-310)")
     ap.add_argument("--map", choices=["spielberg", "levine"], default="spielberg",
                     help="levine = the synthetic 2049x2049 @0.05 stand-in (maps/levine.pgm is absent from the reference)")
     ap.add_argument("--regime", choices=["tracking", "global"], default="tracking")
     ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: gather the weights synchronously")
+    ap.add_argument("--cpu-baseline-256k", action="store_true",
+                    help="also time one oracle update at 262 144 x 1081 on one thread (SURVEY 8(d); about a minute, 11 GB)")
+    ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded runs: gather the exchange synchronously")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the sharded (torch.distributed/RCCL) path even with one rank (rehearsal)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks (one per GPU) as children BEFORE
+    anything here has touched the GPU, stays GPU-free itself, hands rank 0's JSON line through and fails if any rank
+    fails.  (Under torch.distributed.run the ranks arrive with WORLD_SIZE set and this function is never reached.)"""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    live = set(range(n_ranks))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in live:                       # exactly the children started above
+            procs[r].send_signal(signal.SIGTERM)
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
+        raise SystemExit(1)
+    out = procs[0].stdout.read().decode()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if not out.strip():
+        raise SystemExit("bench.py: rank 0 printed no result line")
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
+    # the contract is ONE JSON line on stdout: libraries that write there (RCCL prints a version banner when its first
+    # communicator is created) are pointed at stderr, the line goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch
@@ -177,7 +253,7 @@ def main():
     else:
         m = maps.synthetic_levine()
         true_pose = (-34.0, -34.9, 0.0)          # corridor centre near the lower-left corner of the loop
-    ang = synth.beam_angles()
+    ang = synth.beam_angles(angle_step=args.beam_step)
     B = ang.size
     mode = engine.RESAMPLE_MULTINOMIAL if args.resample == "multinomial" else engine.RESAMPLE_SYSTEMATIC
 
@@ -198,7 +274,7 @@ def main():
     # noise-free scan from the true pose: the committed fixture (tests assert the engine regenerates it
     # bit for bit); keeps the profiled run free of a stray 1-particle k_rays launch
     if args.map == "spielberg":
-        scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
+        scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)[::args.beam_step].copy()
     else:
         scan = synth.scan_from_pose(e, m, ang, true_pose)
     rng = np.random.default_rng(42 + rank)
@@ -210,12 +286,14 @@ def main():
     # put back: first_update_ms below is the cost of an update on the spread cloud, not of hipMalloc
     e.update(ACTION, scan)
     e.set_particles(p, w0)
+    n_updates = 1                             # updates this engine has run: the Philox counter of the next one (E7)
 
     if use_dist:
         from monte_carlo_localization_amd.dist import ShardedFilter
         dev = torch.device("cuda", local_rank)
         sf = ShardedFilter(e, n, dev, overlap=not args.no_overlap)
         sf.update(ACTION, scan)               # the same for the exchange: RCCL builds its communicators on first use
+        n_updates += 1
         e.set_particles(p, w0)
         sf.reset()
 
@@ -238,6 +316,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         step()
+        n_updates += 1
         fence()
         if k == 0:
             first_ms, first_ray_ms = (time.perf_counter() - t0) * 1e3, e.ray_kernel_ms()
@@ -249,32 +328,61 @@ def main():
         ray_ms.append(e.ray_kernel_ms())
     fence()
     elapsed = time.perf_counter() - t0
+    n_updates += args.steps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     pose = sf.expected_pose() if use_dist else e.expected_pose()
     counters = e.counters()
+    exit_code = 0
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
         value = n * world * B / (elapsed / args.steps)
         base, sbar_first, sbar_timed = None, None, None
         if world == 1 and not args.no_cpu_baseline:
-            base = cpu_baseline(m, ang, scan, true_pose)
+            base = cpu_baseline(m, ang, scan, true_pose, big=args.cpu_baseline_256k)
+        parity, probes_live, sbar_err = None, None, None
         try:
-            # S-bar on a sample of the particles actually timed (after the last update) and on the spread cloud
-            pt = e.get_particles()
+            # The oracle as the CHECKER of the run that was just timed (never inside the timed region): the log-weights the
+            # last timed update left for 4000 sampled particles against orc_eng_log_weights on those particles (which also
+            # gives S-bar, the reference's samples per ray, cpp:622-647), then one more UNTIMED update -- with the probe
+            # counter on, for the live trips per ray -- whose resample indices are compared with the oracle's exact-CDF
+            # draw from the weights the timed update left (all children; single-engine path).
+            from oracle import oracle as orc
+            om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
+            L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+            oi = orc.obs_index(scan, om)
+            pt, lw = e.get_particles(), e.log_weights()
             pick = np.random.default_rng(7).choice(n, size=min(4000, n), replace=False)
-            sbar_timed = mean_probes_per_ray(m, ang, scan, pt[:, pick])
-            sbar_first = mean_probes_per_ray(m, ang, scan, sample_first)
+            logw_o, _, probes_o = orc.eng_log_weights(om, np.ascontiguousarray(pt[:, pick]), ang, oi, L)
+            sbar_timed = probes_o / float(pick.size * B)
+            _, _, probes_f = orc.eng_log_weights(om, sample_first, ang, oi, L)
+            sbar_first = probes_f / float(sample_first.shape[1] * B)
+            parity = {"n": int(pick.size), "logw_mismatches": int(np.count_nonzero(lw[pick] != logw_o))}
             del pt
-        except Exception:
-            sbar_timed = sbar_first = None       # no oracle on this box: the algorithmic figure falls back to the survey's value
+            if not args.no_parity_check and not use_dist:
+                _, q_prev, _ = orc.eng_weights_from_log(lw)
+                e.set_debug_count_probes(1)
+                e.update(ACTION, scan)
+                e.set_debug_count_probes(0)
+                probes_live = e.counters()["probes"] / float(n * B)
+                if mode == engine.RESAMPLE_MULTINOMIAL:
+                    want = orc.eng_resample_indices(q_prev, 0, k53=orc.eng_philox_k53(42, n_updates, 0, n))
+                else:
+                    want = orc.eng_resample_indices(q_prev, 1, k0=orc.eng_philox_k0(42, n_updates))
+                parity.update({"idx_n": int(n), "idx_mismatches": int(np.count_nonzero(e.resample_indices() != want))})
+                del q_prev, want
+            del lw
+        except ImportError as ex:
+            sbar_err = repr(ex)                  # no oracle on this box: the algorithmic figure falls back to the survey's value
         k_ms = float(np.mean(ray_ms))
         roof = roofline_block(e.ray_kernel_name(), k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4,
                               profiled_workload=(args.map == "spielberg" and args.regime == "tracking"))
         roof["algorithmic"]["s_bar_first_update"] = sbar_first
+        # what the kernel itself examines: loop trips per ray counted by an extra, untimed update (debug_count_probes)
+        roof["probe_trips_per_ray_live"] = probes_live
         line = {
             "metric": "MCL updates/sec (particle*beam/s)",
             "value": value, "unit": "particle*beam/s", "n_gpus": world, "steps": args.steps,
@@ -296,15 +404,21 @@ def main():
             "cpu_baseline": base,
             "pose": [float(v) for v in pose],
             "counters_last_update": counters,
+            "parity_check": parity if parity is not None else {"skipped": sbar_err},
         }
         if use_dist:
             line["exchange_bytes_per_update_per_gpu"] = sf.exchange_bytes
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        if parity and (parity["logw_mismatches"] or parity.get("idx_mismatches", 0)):
+            sys.stderr.write(f"bench.py: PARITY CHECK FAILED {parity}\n")
+            exit_code = 3
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     e.close()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

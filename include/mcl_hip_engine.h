@@ -140,6 +140,9 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams);
 /* After initialize_particles_pose / initialize_global rewrote the host copies (cpp:388-398,
  * 433-443).  n must be <= max_particles and becomes the active particle count. */
 int mcl_set_particles(mcl_engine_t *h, const double *xyz_colmajor, const double *weights, int64_t n);
+/* The same for one shard of a larger set: the fixed-point weights are scaled by the maximum weight of the WHOLE set (every
+ * shard must be given the same value), so that the shards' weights are comparable. */
+int mcl_set_particles_shard(mcl_engine_t *h, const double *xyz_colmajor, const double *weights, int64_t n, double max_weight_of_the_whole_set);
 /* Device-side versions of the two initialisers (Philox draws instead of the host's rng_; same formulas):
  * Gaussian cloud (0.5 m, 0.5 m, 0.4 rad) around `pose` (cpp:388-398) / uniform over free cells with
  * theta ~ U[0,2pi) (cpp:408-443).  n particles become active with weights 1/n_total; first_global_index is
@@ -186,6 +189,8 @@ int mcl_get_log_weights(mcl_engine_t *h, double *logw, int64_t n);           /* 
  * [1] particles that did not fit the LDS window (global-memory path), [2] grid probes examined
  * (only with debug_count_probes), [3] rays re-run by the fp64 loop (level 2) */
 int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
+/* switches cfg.debug_count_probes on an existing engine (the next update tallies counters[2]; bench.py's untimed probe count) */
+int mcl_set_debug_count_probes(mcl_engine_t *h, int32_t on);
 /* duration (ms) of the dominant kernel (ray cast + likelihood) in the last update, measured
  * with HIP events on the engine's own stream */
 int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
@@ -296,8 +301,8 @@ int mcl_group_engine(mcl_group_t *g, int32_t i, mcl_engine_t **out);           /
 int mcl_group_set_map(mcl_group_t *g, const int8_t *data, uint32_t width, uint32_t height, float resolution, double origin_x,
                       double origin_y);
 int mcl_group_set_beam_angles(mcl_group_t *g, const float *angles, int32_t n_beams);
-/* xyz: n_total x 3 column-major, weights: n_total (all shards must see the same weight scale: uniform weights, as both
- * of the reference's initialisers produce, cpp:388 / 443); n_total a multiple of the device count */
+/* xyz: n_total x 3 column-major, weights: n_total (any non-negative weights with a positive maximum: every shard is scaled
+ * by the maximum of the whole set); n_total a multiple of the device count */
 int mcl_group_set_particles(mcl_group_t *g, const double *xyz, const double *weights, int64_t n_total);
 int mcl_group_init_particles_pose(mcl_group_t *g, const double pose[3], int64_t n_total);
 int mcl_group_init_global(mcl_group_t *g, int64_t n_total);

@@ -66,6 +66,8 @@ struct mcl_engine {
     double *d_Ltd = nullptr;            // k_rays_sweep's fp64 table (mcl_rays_sweep.h), built per update when that kernel runs
     size_t ltd_capacity = 0;
     int ltd_cols = 0;
+    bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
+    bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
     double *d_partial = nullptr;        // k_rays_sweep: [kWedges / sweep_g][cap] partial log-weights in sorted-slot order
     size_t partial_capacity = 0;
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
@@ -380,11 +382,13 @@ int ensure_lt(mcl_engine *h)
         dfree(h->d_Ltd);
         HIPCHK(h, hipMalloc(&h->d_Ltd, need_d * sizeof(double)));
         h->ltd_capacity = need_d;
+        h->ltd_ready = false;
     }
     return MCL_OK;
 }
 
 void graph_reset(mcl_engine *h);
+void build_ltd(mcl_engine *h);
 
 int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset, uint64_t *d_total)
 {
@@ -482,7 +486,8 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip)
     const bool windows_ok = h->quad_ok && h->qside > 0;      // monotone beams over less than a turn, room for a byte window
     if (rk == MCL_RAYS_QUAD) return windows_ok ? 3 : 0;
     if (rk == MCL_RAYS_CELL) return windows_ok ? 4 : 0;
-    const bool sweep_ok = windows_ok && mcl::sweep_window_fits(h->P);    // its windows are 256 cells wide (mcl_rays_sweep.h)
+    // its windows are 256 cells wide (mcl_rays_sweep.h) and addressed from a raw LDS offset checked at mcl_create
+    const bool sweep_ok = windows_ok && mcl::sweep_window_fits(h->P) && h->sweep_layout_ok;
     if (rk == MCL_RAYS_SWEEP) return sweep_ok ? 5 : 0;
     // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
     // with 64-particle groups and enough rays to amortise the sort (measured, wall ms skip / quad / cell:
@@ -644,7 +649,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                 HIPCHK(h, hipMalloc(&h->d_partial, need * sizeof(double)));
                 h->partial_capacity = need;
             }
-            if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not built (internal)");
+            if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not allocated (internal)");
+            if (!h->ltd_ready) build_ltd(h);          // a caller whose table decision was made for another particle count
             const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
             if (rc_plan) return rc_plan;
             a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
@@ -715,7 +721,16 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
 // obs -> obs_idx upload + per-update transposed log table
 void stage_observation(mcl_engine *h, const float *obs, int stride)
 {
+    h->ltd_ready = false;
     for (int j = 0; j < h->B; ++j) h->h_obs[j] = obs[(size_t)j * stride];   // cpp:316-320 when stride = ANGLE_STEP
+}
+
+// k_rays_sweep's fp64 table of the observation whose table rows are in d_obs_idx
+void build_ltd(mcl_engine *h)
+{
+    dim3 gd((h->ltd_cols + 255) / 256, mcl::sweep_table_rows(h->P));
+    hipLaunchKernelGGL(mcl::k_build_ltd, gd, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->ltd_cols, h->P, h->d_Ltd);
+    h->ltd_ready = true;
 }
 
 // the pinned staging buffer -> obs_idx + per-update transposed log table
@@ -727,10 +742,7 @@ int upload_observation(mcl_engine *h)
     dim3 g((h->bpad + 255) / 256, h->P + 1);
     hipLaunchKernelGGL(mcl::k_obs_build_lt, g, dim3(256), 0, h->stream, h->d_obs, h->res, h->P, h->d_L, h->B, h->bpad, h->d_obs_idx, h->d_Lt,
                        h->d_Lt + (size_t)(h->P + 1) * h->bpad);
-    if (choose_ray_mode(h, h->N, false) == 5) {
-        dim3 gd((h->ltd_cols + 255) / 256, mcl::sweep_table_rows(h->P));
-        hipLaunchKernelGGL(mcl::k_build_ltd, gd, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->ltd_cols, h->P, h->d_Ltd);
-    }
+    if (choose_ray_mode(h, h->N, false) == 5) build_ltd(h);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -922,6 +934,14 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_tiny_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    {   // k_rays_sweep addresses its window from the raw LDS offset kQLdsBase: its static LDS must end exactly there.  A
+        // toolchain that lays the two static words out differently turns AUTO back to k_rays_cell instead of a device trap
+        hipFuncAttributes fa0{}, fa1{};
+        const bool ok0 = hipFuncGetAttributes(&fa0, reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>)) == hipSuccess;
+        const bool ok1 = hipFuncGetAttributes(&fa1, reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>)) == hipSuccess;
+        h->sweep_layout_ok = ok0 && ok1 && fa0.sharedSizeBytes == (size_t)mcl::kQLdsBase && fa1.sharedSizeBytes == (size_t)mcl::kQLdsBase;
+        (void)hipGetLastError();
+    }
 #undef CRT
     *out = h;
     return MCL_OK;
@@ -1025,7 +1045,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     }
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
-    h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd);
+    h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd); h->ltd_ready = false;
     {   // free-space list for initialize_global (cpp:199-213, 411-421): row-major order of data == 0
         std::vector<uint32_t> fr;
         for (size_t i = 0; i < (size_t)h->W * h->H; ++i)
@@ -1071,7 +1091,9 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
         if (!(angles[j] > angles[j - 1])) h->quad_ok = false;
     if (h->quad_ok && !((double)angles[n_beams - 1] - (double)angles[0] < 2.0 * M_PI - 1e-3)) h->quad_ok = false;
     h->angles.assign(angles, angles + n_beams);
-    const int ncs = (n_beams + 255) & ~255;           // padded so that k_rays_skip never clamps its beam index
+    // padded so that k_rays_skip never clamps its beam index, with at least one entry after the last beam: k_rays_sweep's
+    // beam walk requests the NEXT beam's direction on every trip, the last one included
+    const int ncs = (n_beams + 1 + 255) & ~255;
     std::vector<double2> cs(ncs);
     for (int j = 0; j < ncs; ++j) {
         double a = (double)angles[j < n_beams ? j : n_beams - 1];   // cpp:533 widens the float angle
@@ -1086,7 +1108,7 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     HIPCHK(h, hipMalloc(&h->d_obs_idx, (size_t)n_beams * sizeof(int32_t)));
     HIPCHK(h, hipMemcpy(h->d_angle, angles, (size_t)n_beams * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)ncs * sizeof(double2), hipMemcpyHostToDevice));
-    h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd);
+    h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd); h->ltd_ready = false;
     if (h->cfg.keep_ray_steps) {
         size_t need = (size_t)h->cap * n_beams;
         if (need > h->steps_capacity) {
@@ -1099,11 +1121,14 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     return MCL_OK;
 }
 
-int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n)
+// weight_scale: the weight the fixed-point values are scaled by (null: this call's own maximum).  A shard of a larger set
+// must use the maximum over the WHOLE set, or the shards' fixed-point weights are not comparable.
+static int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n, const double *weight_scale)
 {
     if (h) graph_reset(h);
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!xyz || !weights || n <= 0 || n > h->cap) return fail(h, MCL_ERR_INVALID_ARG, "bad particle arrays / count");
+    if (weight_scale && !(*weight_scale > 0.0)) return fail(h, MCL_ERR_INVALID_ARG, "weight scale must be positive");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t nb = (size_t)n * sizeof(double);
     const int c = h->cur;
@@ -1112,7 +1137,11 @@ int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights,
     HIPCHK(h, hipMemcpyAsync(h->d_th[c], xyz + 2 * n, nb, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_w, weights, nb, hipMemcpyHostToDevice, h->stream));
     h->N = n;
-    int rc = weight_stats(h, false, nullptr);
+    if (weight_scale) {
+        std::memcpy(&h->h_result[15], weight_scale, sizeof(double));        // pinned: stays valid until the copy has run
+        HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[15], sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = weight_stats(h, false, weight_scale ? h->d_scalars : nullptr);
     if (rc) return rc;
     rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
     if (rc) return rc;
@@ -1122,6 +1151,16 @@ int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights,
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     return MCL_OK;
+}
+
+int mcl_set_particles(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n)
+{
+    return set_particles_impl(h, xyz, weights, n, nullptr);
+}
+
+int mcl_set_particles_shard(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n, double max_weight_of_the_whole_set)
+{
+    return set_particles_impl(h, xyz, weights, n, &max_weight_of_the_whole_set);
 }
 
 static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
@@ -1542,6 +1581,14 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4])
 {
     if (!h || !out) return MCL_ERR_INVALID_ARG;
     for (int i = 0; i < 4; ++i) out[i] = h->h_counters[i];
+    return MCL_OK;
+}
+
+int mcl_set_debug_count_probes(mcl_engine_t *h, int32_t on)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    graph_reset(h);                        // a captured tail holds the non-counting kernel
+    h->cfg.debug_count_probes = on ? 1 : 0;
     return MCL_OK;
 }
 
@@ -2151,13 +2198,16 @@ int mcl_group_set_particles(mcl_group_t *g, const double *xyz, const double *wei
     if (!g || !xyz || !weights) return MCL_ERR_INVALID_ARG;
     int rc = group_check_total(g, n_total);
     if (rc) return rc;
-    // all shards must quantise their weights against the same scale: the reference's initialisers (cpp:388, 443) and
-    // every caller of this path hand over uniform weights; the global maximum is what a single engine would use
+    // all shards quantise their weights against the same scale: the maximum over the whole set, which is what a single
+    // engine holding all particles would use
+    double wmax = 0.0;
+    for (int64_t i = 0; i < n_total; ++i) wmax = std::max(wmax, weights[i]);
+    if (!(wmax > 0.0)) return gfail(g, MCL_ERR_INVALID_ARG, "weights must have a positive maximum");
     std::vector<double> shard((size_t)g->n_per * 3);
     for (size_t d = 0; d < g->eng.size(); ++d) {
         for (int c = 0; c < 3; ++c)
             std::memcpy(shard.data() + (size_t)c * g->n_per, xyz + (size_t)c * n_total + d * (size_t)g->n_per, (size_t)g->n_per * 8);
-        rc = mcl_set_particles(g->eng[d], shard.data(), weights + d * (size_t)g->n_per, g->n_per);
+        rc = set_particles_impl(g->eng[d], shard.data(), weights + d * (size_t)g->n_per, g->n_per, &wmax);
         if (rc) return gfail(g, rc, g->eng[d]->err);
     }
     return group_sync_q_total(g);
@@ -2224,6 +2274,7 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
         mcl_engine *e = g->eng[d];
         GHIP(g, hipSetDevice(e->cfg.device));
         if ((size_t)nt / mcl::kScanTile + 2 > e->blocktot_capacity) {
+            graph_reset(e);                // a captured update graph of this engine holds the old pointer
             dfree(e->d_blocktot);
             GHIP(g, hipMalloc(&e->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8));
             e->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;

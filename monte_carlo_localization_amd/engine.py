@@ -33,6 +33,7 @@ EXPORTS = [
     "mcl_group_set_beam_angles", "mcl_group_set_particles", "mcl_group_init_particles_pose", "mcl_group_init_global",
     "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
     "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
+    "mcl_set_debug_count_probes", "mcl_set_particles_shard",
 ]
 
 
@@ -210,6 +211,16 @@ class Engine:
         self._chk(self.lib.mcl_set_particles(self._h, _p(p), _p(w), C.c_int64(n)), "mcl_set_particles")
         self.n = n
 
+    def set_particles_shard(self, xyz_colmajor, weights, max_weight_of_the_whole_set):
+        """set_particles for one shard of a larger set: weights are quantised against the whole set's maximum weight."""
+        p = _c(xyz_colmajor, np.float64)
+        w = _c(weights, np.float64)
+        n = p.shape[1]
+        assert p.ndim == 2 and p.shape[0] == 3 and w.size == n
+        self._chk(self.lib.mcl_set_particles_shard(self._h, _p(p), _p(w), C.c_int64(n), C.c_double(max_weight_of_the_whole_set)),
+                  "mcl_set_particles_shard")
+        self.n = n
+
     def init_particles_pose(self, pose, n, first_global_index=0, n_total=None):
         p = _c(pose, np.float64)
         self._chk(self.lib.mcl_init_particles_pose(self._h, _p(p), C.c_int64(n), C.c_int64(first_global_index),
@@ -292,6 +303,9 @@ class Engine:
         self._chk(self.lib.mcl_get_counters(self._h, _p(out)), "mcl_get_counters")
         return dict(exact_fallback_rays=int(out[0]), off_window_particles=int(out[1]), probes=int(out[2]),
                     level2_rays=int(out[3]))
+
+    def set_debug_count_probes(self, on):
+        self._chk(self.lib.mcl_set_debug_count_probes(self._h, C.c_int32(1 if on else 0)), "mcl_set_debug_count_probes")
 
     def ray_kernel_ms(self):
         v = C.c_double()

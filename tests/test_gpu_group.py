@@ -70,6 +70,33 @@ def test_group_with_the_sweep_kernel_and_set_particles(orc, engine_mod, spielber
     grp.close(); one.close()
 
 
+def test_group_set_particles_with_non_uniform_weights(orc, engine_mod, spielberg):
+    """Host-supplied weights that differ between the shards (the second shard holds most of the mass): every shard is
+    quantised against the maximum of the WHOLE set, so the global CDF -- and with it every child -- equals one engine's."""
+    from conftest import tracking_cloud
+    ang = orc.beam_angles(angle_step=18)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].astype(np.float32).copy()
+    n = 8192
+    rng = np.random.default_rng(8)
+    p = tracking_cloud(rng, n)
+    w = rng.random(n) * np.where(np.arange(n) < n // 2, 1e-3, 1.0)
+    w /= w.sum()
+    for mode in (engine_mod.RESAMPLE_MULTINOMIAL, engine_mod.RESAMPLE_SYSTEMATIC):
+        one = make_engine(engine_mod, spielberg, ang, n, seed=5, resample_mode=mode)
+        one.set_particles(p, w)
+        grp = make_group(engine_mod, spielberg, ang, n // 2, 2, seed=5, resample_mode=mode)
+        grp.set_particles(p, w)
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        idx = one.resample_indices()
+        assert np.array_equal(grp.resample_indices(), idx)
+        assert np.array_equal(idx, orc.eng_resample_indices(orc.eng_quantize_weights(w), mode, k53=orc.eng_philox_k53(5, 0, 0, n),
+                                                            k0=orc.eng_philox_k0(5, 0)))
+        assert (idx >= n // 2).mean() > 0.99                 # the children come from the heavy shard
+        assert np.array_equal(grp.get_particles(), one.get_particles())
+        grp.close(); one.close()
+
+
 def test_shard_cdf_follows_the_staged_weights(orc, engine_mod, spielberg):
     """After a staged (sharded) update the shard's own CDF must describe its NEW weights: mcl_sample_particles (the
     reference's visualize(), cpp:946-958) on a one-shard group equals the same call on a plain engine."""

@@ -231,3 +231,25 @@ def test_three_updates_each_checked_against_the_oracle(orc, engine_mod, spielber
         assert e.ray_kernel_name() == "k_rays_sweep"
         assert np.array_equal(e.log_weights(), logw), k
     e.close()
+
+
+@pytest.mark.parametrize("n_beams", [1024, 256])
+def test_beam_count_multiple_of_256(orc, engine_mod, spielberg, spielberg_oracle, n_beams):
+    """The beam walk requests the NEXT beam's direction on every trip, the last beam's included: with a beam count that is a
+    multiple of 256 that entry used to lie past the end of the direction table (mcl_set_beam_angles now pads it by at
+    least one entry).  65 536 particles through the default kernel choice, against the oracle."""
+    n = 65536
+    amin, amax = -3.0 * np.pi / 4.0, 3.0 * np.pi / 4.0
+    ang = (np.float32(amin) + np.arange(n_beams, dtype=np.float32) * np.float32((amax - amin) / (n_beams - 1))).astype(np.float32)
+    obs = np.interp(np.linspace(0, 1080, n_beams), np.arange(1081), scan1081()).astype(np.float32)
+    p = tracking_cloud(np.random.default_rng(31), n, sig=(0.4, 0.4, 0.4))
+    e = make_engine(engine_mod, spielberg, ang, n)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(obs)
+    assert e.ray_kernel_name() == ("k_rays_sweep" if n * n_beams >= (8 << 20) else "k_rays_skip")
+    got = e.log_weights()
+    e.close()
+    if n * n_beams < (8 << 20):           # AUTO stays on k_rays_skip at this ray count: force the walk
+        got, _ = sweep_logw(engine_mod, spielberg, ang, p, obs)
+    pick = np.random.default_rng(5).choice(n, 8192, replace=False)
+    assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs))
