@@ -189,6 +189,13 @@ int mcl_get_log_weights(mcl_engine_t *h, double *logw, int64_t n);           /* 
  * [1] particles that did not fit the LDS window (global-memory path), [2] grid probes examined
  * (only with debug_count_probes), [3] rays re-run by the fp64 loop (level 2) */
 int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
+/* The compact parent list: the scan of an update's fixed-point weights also lists, in index order, the
+ * particles whose weight is not zero -- after an update with many beams a few per cent of the set -- and the next
+ * resampling searches and gathers from that list instead of the full CDF and record arrays (same draw: a particle with a
+ * zero fixed-point weight is never selected).  n_entries: length of the list that describes the current weights, -1 when
+ * there is none (more than max_particles / 8 particles carry weight, or a small update); used_by_last_update: whether the
+ * last mcl_update / staged resampling drew from a list.  MCL_NO_COMPACT=1 in the environment at mcl_create disables it. */
+int mcl_get_compact_list(const mcl_engine_t *h, int64_t *n_entries, int32_t *used_by_last_update);
 /* switches cfg.debug_count_probes on an existing engine (the next update tallies counters[2]; bench.py's untimed probe count) */
 int mcl_set_debug_count_probes(mcl_engine_t *h, int32_t on);
 /* duration (ms) of the dominant kernel (ray cast + likelihood) in the last update, measured
@@ -272,6 +279,21 @@ int mcl_stage_resample_indices(mcl_engine_t *h, const uint64_t *d_cdf, int64_t n
                                int64_t n_children_total, int32_t *d_parent_idx);
 int mcl_stage_motion_records(mcl_engine_t *h, const void *d_records, int64_t n_records, const int32_t *d_record_of_child,
                              int64_t child_first, int64_t n_children_total, const double action[3]);
+/* The exchange of a sharded set when every shard has a compact parent list (mcl_get_compact_list; the usual case after an
+ * update with many beams): the shards gather their LISTS -- 44 B per particle that carries weight, a few per cent of the set --
+ * instead of every weight, and nothing else has to travel: the merged lists are the whole parent population.
+ *   mcl_compact_chunk_bytes: size of a chunk of chunk_entries list entries (a multiple of 64, the same on every shard and at
+ *     least the longest list); mcl_export_compact copies this engine's list into d_chunk (DEVICE memory of that size); the
+ *     host gathers the chunks in shard order (all-gather) into d_chunks;
+ *   mcl_stage_resample_compact: counts[r] = length of shard r's list, totals[r] = its fixed-point weight total (SCALARS[2] of
+ *     shard r as uint64); merges the chunks into one CDF, draws this shard's children from it (same thresholds as every other
+ *     path: bit-identical children), applies the motion model and makes the children current.  Global parent index =
+ *     shard * n_per_shard + local index. */
+int mcl_compact_chunk_bytes(int64_t chunk_entries, int64_t *bytes);
+int mcl_export_compact(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries);
+int mcl_stage_resample_compact(mcl_engine_t *h, const void *d_chunks, int32_t n_shards, int64_t chunk_entries, const int64_t *counts,
+                               const uint64_t *totals, int64_t n_per_shard, int32_t self_shard, int64_t child_first, int64_t n_children_total,
+                               const double action[3]);
 int mcl_stage_rays(mcl_engine_t *h, const float *obs, int32_t n_beams);
 /* Leave n_cus compute units out of k_rays_quad's persistent grid (it otherwise occupies every CU for the
  * whole kernel, which would serialise a collective launched beside it). */

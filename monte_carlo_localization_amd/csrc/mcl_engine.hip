@@ -27,9 +27,14 @@ enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_K0, EV_K1, EV
 
 }  // namespace
 
-static_assert(MCL_WEDGES == mcl::kWedges, "include/mcl_hip_engine.h and csrc/mcl_wedge.h disagree");
+static_assert(MCL_WEDGES == mcl::kWedges || MCL_KWEDGES != 16, "include/mcl_hip_engine.h and csrc/mcl_wedge.h disagree");
 
 constexpr unsigned long long kExactCap = 1ull << 16;   // level-3 rays per launch handled by k_rays_exact (more: inline)
+// d_result / h_result: [0..7] scalars, [8..11] counters, [12] work-list overflow flag, [13] work counter, [14] level-3 list
+// length, [15] far-list length (and the staging word of a global maximum), [16] length of the compact parent list
+constexpr int kResultWords = 17;
+constexpr int kResultStage = 40;             // h_result word that stages a host value on its way to the device
+constexpr int kResultStamp = 32;             // h_result word a small update's last kernel stamps (the host polls it)
 
 struct mcl_engine {
     mcl_config_t cfg{};
@@ -101,6 +106,18 @@ struct mcl_engine {
     uint32_t *d_bm = nullptr;           // mcl_stage_distinct_parents: bitmap over the global particle indices, its popcounts and their prefix
     uint64_t *d_bm_pop = nullptr, *d_bm_pref = nullptr;
     size_t bm_capacity = 0;
+    // compact list of the particles with a non-zero fixed-point weight, written by the scan of d_q (mcl::CompactOut)
+    uint32_t *d_blockcnt = nullptr;     // per scan tile (blocktot_capacity entries)
+    uint64_t *d_ccdf = nullptr, *d_ctop = nullptr;
+    uint32_t *d_cidx = nullptr;
+    double4 *d_crec = nullptr;
+    int64_t compact_cap = 0;            // room in the list (cap / 8, at least 4096)
+    int64_t compact_n = -1;             // entries of the list that describes d_cdf / the current particles; -1: none
+    bool compact_pending = false;       // the last scan wrote a list; its length arrives with the next result read-back
+    bool compact_used = false;          // the last resampling drew from a compact list
+    uint64_t *d_gcdf = nullptr, *d_gtop = nullptr;   // merged CDF of the shards' gathered lists (mcl_stage_resample_compact)
+    size_t gcdf_capacity = 0;
+    int env_no_compact = 0;
     uint64_t *d_leaders = nullptr;      // last CDF entry of every 16-entry group of the array d_blocktot describes
     size_t leaders_capacity = 0;
     double4 *d_pack[2]{};               // (x, y, theta, -) records of buffer 0/1, written by k_resample_motion
@@ -138,7 +155,7 @@ struct mcl_engine {
     size_t slice_mean_capacity = 0;
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell, 5 sweep
-    unsigned long long result_seq = 0;  // stamps the result block a small update writes to pinned memory (h_result[16])
+    unsigned long long result_seq = 0;  // stamps the result block a small update writes to pinned memory (h_result[kResultStamp])
     int env_tiny_poll = 1;
     bool pc_ready = false;              // d_pc already holds the constants of the current particles (written by k_resample_motion)
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
@@ -393,8 +410,16 @@ void build_ltd(mcl_engine *h);
 int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset, uint64_t *d_total)
 {
     int nb = (int)((n + mcl::kScanTile - 1) / mcl::kScanTile);
-    hipLaunchKernelGGL(mcl::k_scan_partials, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot);
-    hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total);
+    // the scan of the engine's own weights also leaves the compact list of the particles that carry weight
+    mcl::CompactOut co{};
+    const bool own = d_q == h->d_q && d_cdf == h->d_cdf && offset == 0 && !h->env_no_compact && h->d_ccdf;
+    if (own) {
+        co.block_cnt = h->d_blockcnt; co.ccdf = h->d_ccdf; co.cidx = h->d_cidx; co.crec = h->d_crec; co.ctop = h->d_ctop;
+        co.x = h->d_x[h->cur]; co.y = h->d_y[h->cur]; co.th = h->d_th[h->cur];
+        co.cap = (uint32_t)h->compact_cap; co.total = h->d_result + 16;
+    }
+    hipLaunchKernelGGL(mcl::k_scan_partials, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, co.block_cnt);
+    hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total, co.block_cnt, co.total);
     const size_t nlead = (size_t)((n + 15) >> mcl::kLeaderShift) + 1;
     if (nlead > h->leaders_capacity) {
         graph_reset(h);                    // a captured update graph holds the old pointer
@@ -402,9 +427,10 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
         HIPCHK(h, hipMalloc(&h->d_leaders, nlead * 8));
         h->leaders_capacity = nlead;
     }
-    hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf, h->d_leaders);
+    hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf, h->d_leaders, co);
     HIPCHK(h, hipGetLastError());
     h->blocktot_for = d_cdf; h->blocktot_n = n;
+    if (d_cdf == h->d_cdf) { h->compact_n = -1; h->compact_pending = own; }
     return MCL_OK;
 }
 
@@ -434,7 +460,7 @@ void unpack_result(mcl_engine *h);
 int fetch_scalars(mcl_engine *h)
 {
     // scalars, counters and the work-list overflow flag in one copy into pinned memory
-    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     unpack_result(h);
     return MCL_OK;
@@ -453,6 +479,12 @@ void unpack_result(mcl_engine *h)
     h->global_sums[2] = h->h_scalars[4];
     h->global_sums[3] = h->h_scalars[5];
     h->global_sums[4] = h->h_scalars[6];
+    // length of the compact list the scan of this update's weights wrote (word 16); unusable when it outgrew its arrays
+    if (h->compact_pending) {
+        const unsigned long long na = h->h_result[16];
+        h->compact_n = (na > 0 && na <= (unsigned long long)h->compact_cap) ? (int64_t)na : -1;
+        h->compact_pending = false;
+    }
 }
 
 // Work items of k_rays_sweep: made on the device from this update's unit statistics (k_sweep_plan, mcl_rays_sweep.h);
@@ -788,6 +820,7 @@ int weights_and_cdf(mcl_engine *h, bool result_to_host = false)
         h->max_partials_ready = false;
         h->carry_pending = false;
         h->blocktot_for = nullptr;             // no spine / leaders for this CDF: the resampling search bisects it directly
+        h->compact_n = -1; h->compact_pending = false;
         return MCL_OK;
     }
     int rc = sensor_and_weights(h, nullptr);
@@ -865,6 +898,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     if (const char *e = getenv("MCL_QSIDE")) h->env_qside = atoi(e);
     if (const char *e = getenv("MCL_SWEEP_G")) h->env_sweep_g = atoi(e);
     if (const char *e = getenv("MCL_TINY_POLL")) h->env_tiny_poll = atoi(e);
+    if (const char *e = getenv("MCL_NO_COMPACT")) h->env_no_compact = atoi(e);
     if (const char *e = getenv("MCL_DEBUG_WG")) h->env_debug_wg = e;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
@@ -891,11 +925,18 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_q, (size_t)h->cap * 8)); CRT(hipMalloc(&h->d_cdf, (size_t)h->cap * 8));
     h->blocktot_capacity = (size_t)h->cap / mcl::kScanTile + 2;
     CRT(hipMalloc(&h->d_blocktot, h->blocktot_capacity * 8));
+    CRT(hipMalloc(&h->d_blockcnt, h->blocktot_capacity * 4));
+    h->compact_cap = std::max<int64_t>(4096, ((h->cap / 8 + 63) / 64) * 64);
+    CRT(hipMalloc(&h->d_ccdf, (size_t)h->compact_cap * 8));
+    CRT(hipMalloc(&h->d_ctop, ((size_t)h->compact_cap / 64 + 1) * 8));
+    CRT(hipMalloc(&h->d_cidx, (size_t)h->compact_cap * 4));
+    CRT(hipMalloc(&h->d_crec, (size_t)h->compact_cap * sizeof(double4)));
     CRT(hipMalloc(&h->d_idx, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_part, (size_t)mcl::kRedBlocks * 8 * sizeof(double)));
-    CRT(hipMalloc(&h->d_result, 16 * 8));
-    CRT(hipHostMalloc(&h->h_result, 32 * 8));
-    std::memset(h->h_result, 0, 32 * 8);
+    CRT(hipMalloc(&h->d_result, 32 * 8));
+    CRT(hipMemset(h->d_result, 0, 32 * 8));
+    CRT(hipHostMalloc(&h->h_result, 48 * 8));
+    std::memset(h->h_result, 0, 48 * 8);
     h->d_scalars = reinterpret_cast<double *>(h->d_result);
     h->d_counters = h->d_result + 8;
     h->d_fix_over = h->d_result + 12;
@@ -955,6 +996,8 @@ void mcl_destroy(mcl_engine_t *h)
     graph_reset(h);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
+    dfree(h->d_gcdf); dfree(h->d_gtop);
+    dfree(h->d_blockcnt); dfree(h->d_ccdf); dfree(h->d_ctop); dfree(h->d_cidx); dfree(h->d_crec);
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
@@ -1138,8 +1181,8 @@ static int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *
     HIPCHK(h, hipMemcpyAsync(h->d_w, weights, nb, hipMemcpyHostToDevice, h->stream));
     h->N = n;
     if (weight_scale) {
-        std::memcpy(&h->h_result[15], weight_scale, sizeof(double));        // pinned: stays valid until the copy has run
-        HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[15], sizeof(double), hipMemcpyHostToDevice, h->stream));
+        std::memcpy(&h->h_result[kResultStage], weight_scale, sizeof(double));        // pinned: stays valid until the copy has run
+        HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[kResultStage], sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     int rc = weight_stats(h, false, weight_scale ? h->d_scalars : nullptr);
     if (rc) return rc;
@@ -1322,8 +1365,20 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         a.cdf = h->d_cdf; a.n_parents = n; a.q_total = h->q_total;
         a.tile_excl = (h->blocktot_for == h->d_cdf && h->blocktot_n == n) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
         a.leaders = a.tile_excl ? h->d_leaders : nullptr;
-        a.ppack = h->pack_valid[c] ? h->d_pack[c] : nullptr;
-        a.cpack = h->d_pack[nx];
+        // parents: the compact list the last scan left (the particles that carry weight: a few per cent after an update
+        // with many beams) when it exists, else the full CDF and the packed records
+        const bool compact = !keep && h->compact_n > 0;
+        if (compact) {
+            a.ccdf = h->d_ccdf; a.ctop = h->d_ctop; a.n_compact = h->compact_n; a.cidx = h->d_cidx; a.crec = h->d_crec;
+            a.cpack = nullptr;               // the next update most likely draws from a compact list again: no record per child
+        } else {
+            if (!h->pack_valid[c] && n > 65536 && !keep) {       // records first: one fetch per gathered parent instead of three
+                hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_x[c], h->d_y[c], h->d_th[c], n, h->d_pack[c]);
+                h->pack_valid[c] = true;
+            }
+            a.ppack = h->pack_valid[c] ? h->d_pack[c] : nullptr;
+            a.cpack = h->d_pack[nx];
+        }
         a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
         a.idx_out = h->d_idx;
         a.n_children = n; a.child_first = 0; a.n_children_total = n;
@@ -1363,7 +1418,8 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         HIPCHK(h, hipGetLastError());
         h->cur = nx;                       // cpp:689 as a pointer swap
         h->resampled_last = !keep;
-        h->pack_valid[nx] = true;
+        h->pack_valid[nx] = a.cpack != nullptr;
+        h->compact_used = compact;
         h->have_idx = true;
     }
     int rc;
@@ -1377,7 +1433,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         // kernel) ends in the ordinary synchronisation, which reports the error.
         bool seen = false;
         if (h->env_tiny_poll) {
-            const volatile unsigned long long *stamp = h->h_result + 16;
+            const volatile unsigned long long *stamp = h->h_result + kResultStamp;
             const auto give_up = t0 + std::chrono::milliseconds(20);
             for (unsigned spin = 0; !seen; ++spin) {
                 seen = __atomic_load_n(stamp, __ATOMIC_ACQUIRE) == h->result_seq;
@@ -1420,7 +1476,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
                 if (!rc) rc = launch_rays(h, h->d_x[gi], h->d_y[gi], h->d_th[gi], n);
                 if (!rc) rc = weights_and_cdf(h);
                 hipError_t ce = hipSuccess;
-                if (!rc) ce = hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream);
+                if (!rc) ce = hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream);
                 h->capturing = false;
                 const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
                 hipError_t ie = hipErrorUnknown;
@@ -1443,6 +1499,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->pc_ready = false;
         HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->compact_pending = h->d_ccdf != nullptr && !h->env_no_compact && n > mcl::kTinyTailMax;   // the captured scan wrote a list
         unpack_result(h);
         h->carry_pending = false;
         h->have_logw = true;
@@ -1581,6 +1638,14 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4])
 {
     if (!h || !out) return MCL_ERR_INVALID_ARG;
     for (int i = 0; i < 4; ++i) out[i] = h->h_counters[i];
+    return MCL_OK;
+}
+
+int mcl_get_compact_list(const mcl_engine_t *h, int64_t *n_entries, int32_t *used_by_last_update)
+{
+    if (!h || !n_entries || !used_by_last_update) return MCL_ERR_INVALID_ARG;
+    *n_entries = h->compact_n;
+    *used_by_last_update = h->compact_used ? 1 : 0;
     return MCL_OK;
 }
 
@@ -1800,6 +1865,9 @@ struct ParentSource {
     int64_t n_per_rank = 0;
     int self_rank = 0;
     unsigned long long *remote_count = nullptr;
+    const unsigned char *cchunks = nullptr;                         // the shards' compact lists, gathered as chunks
+    int64_t cchunk_entries = 0;
+    const uint64_t *gcdf = nullptr, *gtop = nullptr;                // their merged CDF (k_compact_merge)
     const int32_t *idx_in = nullptr;                                // parents decided by an earlier index-only pass (into `records`)
     int32_t *idx_only_out = nullptr;                                // index-only pass: parents go here, nothing else happens
 };
@@ -1811,8 +1879,8 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
-    const bool have_parents = src.records || src.n_per_rank > 0 || (src.px && src.py && src.pth) || src.idx_only_out;
-    if (!have_parents || (!d_cdf && !src.idx_in) || (!action && !src.idx_only_out) || n_parents <= 0 || n_parents >= MCL_MAX_TOTAL_PARTICLES ||
+    const bool have_parents = src.records || src.n_per_rank > 0 || (src.px && src.py && src.pth) || src.idx_only_out || src.gcdf;
+    if (!have_parents || (!d_cdf && !src.idx_in && !src.gcdf) || (!action && !src.idx_only_out) || n_parents <= 0 || n_parents >= MCL_MAX_TOTAL_PARTICLES ||
         n_children_total >= MCL_MAX_TOTAL_PARTICLES)
         return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments (totals must stay below 2^27)");
     if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
@@ -1832,6 +1900,11 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     a.n_per_rank = src.n_per_rank; a.self_rank = src.self_rank; a.remote_count = src.remote_count;
     a.idx_in = src.idx_in; a.index_only = index_only ? 1 : 0;
     a.cpack = h->d_pack[nx];
+    if (src.gcdf) {
+        a.ccdf = src.gcdf; a.ctop = src.gtop; a.n_compact = n_parents; a.cchunks = src.cchunks;
+        a.ccap = src.cchunk_entries; a.cchunk_bytes = src.cchunk_entries * 44;
+        a.cpack = nullptr;
+    }
     a.tile_excl = (d_cdf && h->blocktot_for == d_cdf && h->blocktot_n == n_parents) ? h->d_blocktot : nullptr;   // spine of the scan that produced d_cdf
     a.leaders = a.tile_excl ? h->d_leaders : nullptr;
     a.cx = h->d_x[nx]; a.cy = h->d_y[nx]; a.cth = h->d_th[nx];
@@ -1860,7 +1933,8 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
         return MCL_OK;
     }
     h->cur = nx;
-    h->pack_valid[nx] = true;
+    h->pack_valid[nx] = a.cpack != nullptr;
+    h->compact_used = src.gcdf != nullptr;
     h->have_idx = true;
     h->have_logw = false;
     HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
@@ -1909,6 +1983,85 @@ int mcl_stage_motion_records(mcl_engine_t *h, const void *d_records, int64_t n_r
     return stage_resample_sync(h, src, nullptr, n_records, 0, child_first, n_children_total, action);
 }
 
+// ---- sharded sets: the shards exchange their compact lists instead of every weight --------------------------------
+int mcl_compact_chunk_bytes(int64_t chunk_entries, int64_t *bytes)
+{
+    if (!bytes || chunk_entries <= 0 || (chunk_entries & 63)) return MCL_ERR_INVALID_ARG;
+    *bytes = chunk_entries * 44;             // [ccdf: 8 | crec: 32 | cidx: 4] per entry, column by column
+    return MCL_OK;
+}
+
+static int export_compact_launch(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries, int dst_device, hipStream_t stream)
+{
+    if (!h || !d_chunk || chunk_entries <= 0 || (chunk_entries & 63)) return MCL_ERR_INVALID_ARG;
+    if (h->compact_n <= 0 || h->compact_n > chunk_entries) return fail(h, MCL_ERR_NOT_READY, "no compact list of that size (mcl_get_compact_list)");
+    unsigned char *c = static_cast<unsigned char *>(d_chunk);
+    const size_t n = (size_t)h->compact_n, cap = (size_t)chunk_entries;
+    const int src = h->cfg.device;
+    HIPCHK(h, hipMemcpyPeerAsync(c, dst_device, h->d_ccdf, src, n * 8, stream));
+    HIPCHK(h, hipMemcpyPeerAsync(c + cap * 8, dst_device, h->d_crec, src, n * 32, stream));
+    HIPCHK(h, hipMemcpyPeerAsync(c + cap * 40, dst_device, h->d_cidx, src, n * 4, stream));
+    return MCL_OK;
+}
+
+int mcl_export_compact(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int rc = export_compact_launch(h, d_chunk, chunk_entries, h->cfg.device, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+// merge of the gathered chunks + staged resample from them, on the engine's stream; no synchronisation
+static int stage_resample_compact_launch(mcl_engine_t *h, const void *d_chunks, int32_t n_shards, int64_t chunk_entries, const int64_t *counts,
+                                         const uint64_t *totals, int64_t n_per_shard, int32_t self_shard, int64_t child_first,
+                                         int64_t n_children_total, const double action[3], unsigned long long *remote_count)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (!d_chunks || !counts || !totals || n_shards <= 0 || n_shards > mcl::kMaxShards || chunk_entries <= 0 || (chunk_entries & 63) || n_per_shard <= 0 ||
+        self_shard < 0 || self_shard >= n_shards)
+        return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample_compact arguments");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    mcl::MergeArgs m{};
+    m.chunks = static_cast<const unsigned char *>(d_chunks); m.chunk_bytes = chunk_entries * 44; m.ccap = chunk_entries; m.n_shards = n_shards;
+    uint64_t off = 0;
+    for (int r = 0; r < n_shards; ++r) {
+        if (counts[r] < 0 || counts[r] > chunk_entries) return fail(h, MCL_ERR_INVALID_ARG, "a list is longer than its chunk");
+        m.count[r] = (uint32_t)counts[r]; m.off[r] = off; m.tot[r] = counts[r] > 0 ? totals[r] : 0ull;
+        off += m.tot[r];
+    }
+    if (off == 0) return fail(h, MCL_ERR_INVALID_ARG, "the lists carry no weight");
+    const size_t total = (size_t)n_shards * (size_t)chunk_entries;
+    if (total >= (size_t)MCL_MAX_TOTAL_PARTICLES) return fail(h, MCL_ERR_INVALID_ARG, "gathered lists exceed 2^27 entries");
+    if (total > h->gcdf_capacity) {
+        dfree(h->d_gcdf); dfree(h->d_gtop);
+        h->gcdf_capacity = 0;
+        HIPCHK(h, hipMalloc(&h->d_gcdf, total * 8));
+        HIPCHK(h, hipMalloc(&h->d_gtop, (total / 64 + 1) * 8));
+        h->gcdf_capacity = total;
+    }
+    m.gcdf = h->d_gcdf; m.gtop = h->d_gtop;
+    hipLaunchKernelGGL(mcl::k_compact_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, m);
+    HIPCHK(h, hipGetLastError());
+    ParentSource src;
+    src.cchunks = m.chunks; src.cchunk_entries = chunk_entries; src.gcdf = h->d_gcdf; src.gtop = h->d_gtop;
+    src.n_per_rank = n_per_shard; src.self_rank = self_shard; src.remote_count = remote_count;
+    return stage_resample_launch(h, src, nullptr, (int64_t)total, off, child_first, n_children_total, action);
+}
+
+int mcl_stage_resample_compact(mcl_engine_t *h, const void *d_chunks, int32_t n_shards, int64_t chunk_entries, const int64_t *counts,
+                               const uint64_t *totals, int64_t n_per_shard, int32_t self_shard, int64_t child_first, int64_t n_children_total,
+                               const double action[3])
+{
+    const int rc = stage_resample_compact_launch(h, d_chunks, n_shards, chunk_entries, counts, totals, n_per_shard, self_shard, child_first,
+                                                 n_children_total, action, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
 static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams, bool force_skip)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
@@ -1933,7 +2086,7 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     h->max_partials_ready = false;
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
     return MCL_OK;
 }
 
@@ -1992,9 +2145,9 @@ static int stage_weights_launch(mcl_engine_t *h, double global_max_logw)
     if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
         return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->h_result[15] = 0;
-    std::memcpy(&h->h_result[15], &global_max_logw, sizeof(double));   // pinned: stays valid until the copy has run
-    HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[15], sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->h_result[kResultStage] = 0;
+    std::memcpy(&h->h_result[kResultStage], &global_max_logw, sizeof(double));   // pinned: stays valid until the copy has run
+    HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[kResultStage], sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = weight_stats(h, true, h->d_scalars);
     if (rc) return rc;
     h->carry_pending = false;
@@ -2002,7 +2155,7 @@ static int stage_weights_launch(mcl_engine_t *h, double global_max_logw)
     rc = scan_weights(h, h->d_q, h->d_cdf, h->N, 0, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, 14 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
     return MCL_OK;
 }
 
@@ -2063,6 +2216,10 @@ struct mcl_group {
     std::vector<mcl_engine *> eng;
     std::vector<uint64_t *> d_qall, d_cdfall;      // per device: all shards' weights and their global CDF
     std::vector<unsigned long long *> d_remote;    // per device: children whose parent was fetched from a peer (last update)
+    std::vector<unsigned char *> d_chunks;         // per device: every shard's compact parent list (grown on demand)
+    std::vector<size_t> chunks_capacity;
+    std::vector<hipEvent_t> ev_ready, ev_children; // per device, see mcl_group_update
+    bool compact_last = false;
     int64_t n_per = 0, n_total = 0;
     uint64_t q_total = 0;
     bool have_q_total = false;
@@ -2104,6 +2261,9 @@ void mcl_group_destroy(mcl_group_t *g)
         if (d < g->d_qall.size() && g->d_qall[d]) (void)hipFree(g->d_qall[d]);
         if (d < g->d_cdfall.size() && g->d_cdfall[d]) (void)hipFree(g->d_cdfall[d]);
         if (d < g->d_remote.size() && g->d_remote[d]) (void)hipFree(g->d_remote[d]);
+        if (d < g->d_chunks.size() && g->d_chunks[d]) (void)hipFree(g->d_chunks[d]);
+        if (d < g->ev_ready.size() && g->ev_ready[d]) (void)hipEventDestroy(g->ev_ready[d]);
+        if (d < g->ev_children.size() && g->ev_children[d]) (void)hipEventDestroy(g->ev_children[d]);
         mcl_destroy(g->eng[d]);
     }
     delete g;
@@ -2129,10 +2289,14 @@ int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_
         g->eng.push_back(e);
     }
     g->d_qall.assign(n_devices, nullptr); g->d_cdfall.assign(n_devices, nullptr); g->d_remote.assign(n_devices, nullptr);
+    g->d_chunks.assign(n_devices, nullptr); g->chunks_capacity.assign(n_devices, 0);
+    g->ev_ready.assign(n_devices, nullptr); g->ev_children.assign(n_devices, nullptr);
     const size_t cap_total = (size_t)cfg->max_particles * n_devices;
     for (int d = 0; d < n_devices; ++d) {
         if (hipSetDevice(devices[d]) != hipSuccess || hipMalloc(&g->d_qall[d], cap_total * 8) != hipSuccess ||
-            hipMalloc(&g->d_cdfall[d], cap_total * 8) != hipSuccess || hipMalloc(&g->d_remote[d], 8) != hipSuccess) {
+            hipMalloc(&g->d_cdfall[d], cap_total * 8) != hipSuccess || hipMalloc(&g->d_remote[d], 8) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_ready[d], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_children[d], hipEventDisableTiming) != hipSuccess) {
             g_create_error = "group buffers: hipMalloc failed";
             mcl_group_destroy(g);
             return MCL_ERR_HIP;
@@ -2250,46 +2414,70 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
     const auto t0 = std::chrono::steady_clock::now();
     const int G = (int)g->eng.size();
     const int64_t n = g->n_per, nt = g->n_total;
-    // phase 1: weights of every shard to every device (peer copies on the destination's stream), exact global CDF,
-    // children drawn from it with the parents read in place
-    for (int d = 0; d < G; ++d) {
-        mcl_engine *e = g->eng[d];
+    // Phases are ordered by EVENTS between the devices' streams, not by host-side synchronisation: ev_ready[s] = shard s's
+    // parent data (records or compact list, weights) may be read by its peers; ev_children[d] = device d has drawn its children
+    // and no longer reads anybody's parent data.  The host waits only where it needs a value (the maxima, the sums).
+    // Exchange: when every shard has a compact parent list (the usual case after an update with many beams) the devices copy
+    // each other's LISTS (44 B per particle that carries weight); otherwise every weight (8 B per particle) and the
+    // selected parents are read where they live.
+    bool compact = g->q_total != 0;
+    int64_t longest = 0;
+    for (int s = 0; s < G; ++s) { compact = compact && g->eng[s]->compact_n > 0; longest = std::max(longest, g->eng[s]->compact_n); }
+    const int64_t centries = (longest + 63) & ~(int64_t)63;
+    for (int s = 0; s < G; ++s) {
+        mcl_engine *e = g->eng[s];
         GHIP(g, hipSetDevice(e->cfg.device));
-        for (int s = 0; s < G; ++s)
-            GHIP(g, hipMemcpyPeerAsync(g->d_qall[d] + (size_t)s * n, e->cfg.device, g->eng[s]->d_q, g->eng[s]->cfg.device, (size_t)n * 8, e->stream));
-        GHIP(g, hipMemsetAsync(g->d_remote[d], 0, 8, e->stream));
-        if (!e->pack_valid[e->cur]) {      // first update after set_particles / init: the records do not exist yet
+        if (!compact && !e->pack_valid[e->cur]) {      // first update after set_particles / init: the records do not exist yet
             hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->d_x[e->cur], e->d_y[e->cur],
                                e->d_th[e->cur], n, e->d_pack[e->cur]);
             e->pack_valid[e->cur] = true;
         }
-    }
-    for (int d = 0; d < G; ++d) {          // the records of every shard exist before any device reads them
-        GHIP(g, hipSetDevice(g->eng[d]->cfg.device));
-        GHIP(g, hipStreamSynchronize(g->eng[d]->stream));
+        GHIP(g, hipEventRecord(g->ev_ready[s], e->stream));
     }
     const double4 *parents[mcl::kMaxShards] = {};      // the launch below flips an engine's current buffer: take the pointers first
     for (int s = 0; s < G; ++s) parents[s] = g->eng[s]->d_pack[g->eng[s]->cur];
+    int64_t counts[mcl::kMaxShards] = {};
+    uint64_t totals[mcl::kMaxShards] = {};
+    for (int s = 0; s < G; ++s) { counts[s] = g->eng[s]->compact_n; totals[s] = g->eng[s]->q_total; }
     for (int d = 0; d < G; ++d) {
         mcl_engine *e = g->eng[d];
         GHIP(g, hipSetDevice(e->cfg.device));
-        if ((size_t)nt / mcl::kScanTile + 2 > e->blocktot_capacity) {
-            graph_reset(e);                // a captured update graph of this engine holds the old pointer
-            dfree(e->d_blocktot);
-            GHIP(g, hipMalloc(&e->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8));
-            e->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;
+        for (int s = 0; s < G; ++s)
+            if (s != d) GHIP(g, hipStreamWaitEvent(e->stream, g->ev_ready[s], 0));
+        GHIP(g, hipMemsetAsync(g->d_remote[d], 0, 8, e->stream));
+        int rc;
+        if (compact) {
+            const size_t need = (size_t)G * (size_t)centries * 44;
+            if (need > g->chunks_capacity[d]) {
+                if (g->d_chunks[d]) { GHIP(g, hipStreamSynchronize(e->stream)); (void)hipFree(g->d_chunks[d]); g->d_chunks[d] = nullptr; }
+                g->chunks_capacity[d] = 0;
+                GHIP(g, hipMalloc(&g->d_chunks[d], need));
+                g->chunks_capacity[d] = need;
+            }
+            for (int s = 0; s < G; ++s) {
+                rc = export_compact_launch(g->eng[s], g->d_chunks[d] + (size_t)s * (size_t)centries * 44, centries, e->cfg.device, e->stream);
+                if (rc) return gfail(g, rc, g->eng[s]->err);
+            }
+            rc = stage_resample_compact_launch(e, g->d_chunks[d], G, centries, counts, totals, n, d, (int64_t)d * n, nt, action, g->d_remote[d]);
+        } else {
+            for (int s = 0; s < G; ++s)
+                GHIP(g, hipMemcpyPeerAsync(g->d_qall[d] + (size_t)s * n, e->cfg.device, g->eng[s]->d_q, g->eng[s]->cfg.device, (size_t)n * 8, e->stream));
+            if ((size_t)nt / mcl::kScanTile + 2 > e->blocktot_capacity) {
+                graph_reset(e);                // a captured update graph of this engine holds the old pointer
+                GHIP(g, hipStreamSynchronize(e->stream));
+                dfree(e->d_blocktot);
+                GHIP(g, hipMalloc(&e->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8));
+                e->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;
+            }
+            rc = scan_weights(e, g->d_qall[d], g->d_cdfall[d], nt, 0, nullptr);
+            if (rc) return gfail(g, rc, e->err);
+            ParentSource src;
+            for (int s = 0; s < G; ++s) src.rank_records[s] = parents[s];
+            src.n_per_rank = n; src.self_rank = d; src.remote_count = g->d_remote[d];
+            rc = stage_resample_launch(e, src, g->d_cdfall[d], nt, g->q_total, (int64_t)d * n, nt, action);
         }
-        int rc = scan_weights(e, g->d_qall[d], g->d_cdfall[d], nt, 0, nullptr);
         if (rc) return gfail(g, rc, e->err);
-        ParentSource src;
-        for (int s = 0; s < G; ++s) src.rank_records[s] = parents[s];
-        src.n_per_rank = n; src.self_rank = d; src.remote_count = g->d_remote[d];
-        rc = stage_resample_launch(e, src, g->d_cdfall[d], nt, g->q_total, (int64_t)d * n, nt, action);
-        if (rc) return gfail(g, rc, e->err);
-    }
-    for (int d = 0; d < G; ++d) {          // children final everywhere: nobody reads the old buffers any more
-        GHIP(g, hipSetDevice(g->eng[d]->cfg.device));
-        GHIP(g, hipStreamSynchronize(g->eng[d]->stream));
+        GHIP(g, hipEventRecord(g->ev_children[d], e->stream));
     }
     // phase 2: rays + likelihood on every device, then the global maximum
     for (int d = 0; d < G; ++d) {
@@ -2302,14 +2490,19 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
         if (rc) return gfail(g, rc, g->eng[d]->err);
         gmax = std::max(gmax, g->eng[d]->h_scalars[0]);
     }
-    // phase 3: weights against the global maximum, sums
+    // phase 3: weights against the global maximum, sums.  The weights (and the compact list) of a shard are rewritten here:
+    // every device must have drawn its children first
     for (int d = 0; d < G; ++d) {
+        GHIP(g, hipSetDevice(g->eng[d]->cfg.device));
+        for (int o = 0; o < G; ++o)
+            if (o != d) GHIP(g, hipStreamWaitEvent(g->eng[d]->stream, g->ev_children[o], 0));
         const int rc = stage_weights_launch(g->eng[d], gmax);
         if (rc) return gfail(g, rc, g->eng[d]->err);
     }
     double gs[5] = {0, 0, 0, 0, 0};
     uint64_t qt = 0;
     unsigned long long remote = 0;
+    uint64_t listed = 0;
     for (int d = 0; d < G; ++d) {
         mcl_engine *e = g->eng[d];
         const int rc = stage_weights_finish(e);
@@ -2319,12 +2512,15 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
         unsigned long long r = 0;
         GHIP(g, hipMemcpy(&r, g->d_remote[d], 8, hipMemcpyDeviceToHost));
         remote += r;
+        if (compact) listed += (uint64_t)counts[d];
     }
     for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
     g->q_total = qt;
     for (int d = 0; d < G; ++d) mcl_stage_finish(g->eng[d], gs);
-    g->bytes_weights = (uint64_t)(G - 1) * (uint64_t)n * 8u;          // received per device
-    g->bytes_parents = (uint64_t)remote * 32u;                         // upper bound: children of remote parents x record size
+    // received per device: the other shards' lists / weights; parents read from peers (dense exchange only)
+    g->bytes_weights = compact ? (listed - (uint64_t)(listed / G)) * 44u : (uint64_t)(G - 1) * (uint64_t)n * 8u;
+    g->bytes_parents = compact ? 0u : (uint64_t)remote * 32u;         // upper bound: children of remote parents x record size
+    g->compact_last = compact;
     for (int k = 0; k < 5; ++k) {
         double m = 0.0;
         for (int d = 0; d < G; ++d) m = std::max(m, g->eng[d]->timings[k]);

@@ -35,50 +35,89 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
     return v;
 }
 
+// Order-preserving list of the particles with a non-zero fixed-point weight ("alive"), produced by the CDF scan itself.
+// After an update with a thousand beams a few per cent of the particles carry all the weight (3.5 % at 4M x 1081 on
+// Spielberg_map): the next update's resampling searches and gathers from this list -- 1 MB of CDF and 5 MB of records,
+// cache-resident -- instead of the 33 MB CDF and the 134 MB of parent records, and a sharded set exchanges the lists
+// instead of every weight.  A particle with q = 0 can never be selected (E6: the first i with
+// C_i * lmul > rhs has q_i > 0), so the draw from the list equals the draw from the full CDF.
+struct CompactOut {
+    uint32_t *block_cnt;        // [tiles]: alive per scan tile -> exclusive prefix (k_scan_spine); null = no list wanted
+    uint64_t *ccdf;             // CDF value at every alive particle (strictly increasing)
+    uint32_t *cidx;             // its index
+    double4 *crec;              // its record (x, y, theta, -)
+    uint64_t *ctop;             // ccdf[64 g + 63] for every complete group of 64 entries: the search's first level
+    const double *x, *y, *th;
+    uint32_t cap;               // room in the arrays above
+    unsigned long long *total;  // alive particles of this scan (may exceed cap: the list is then unusable)
+};
+constexpr int kCompactGroupShift = 6;
+
 __global__ __launch_bounds__(kScanThreads) void k_scan_partials(const uint64_t *__restrict__ q, int64_t n,
-                                                               uint64_t *__restrict__ block_tot)
+                                                               uint64_t *__restrict__ block_tot, uint32_t *__restrict__ block_cnt)
 {
     __shared__ uint64_t sm[kScanThreads / 64];
+    __shared__ uint32_t smc[kScanThreads / 64];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     uint64_t s = 0;
+    uint32_t c = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
-        if (base + k < n) s += q[base + k];
+        if (base + k < n) { const uint64_t v = q[base + k]; s += v; c += v != 0ull; }
     s = wave_sum_u64(s);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) sm[w] = s;
+    if (block_cnt) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    }
+    if (lane == 0) { sm[w] = s; smc[w] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t t = 0;
-        for (int i = 0; i < kScanThreads / 64; ++i) t += sm[i];
+        uint32_t tc = 0;
+        for (int i = 0; i < kScanThreads / 64; ++i) { t += sm[i]; tc += smc[i]; }
         block_tot[blockIdx.x] = t;
+        if (block_cnt) block_cnt[blockIdx.x] = tc;
     }
 }
 
-// exclusive scan of nb block totals in place (single block of 1024 threads), adds `offset`.
+// exclusive scan of nb block totals in place (single block of 1024 threads), adds `offset`; the alive counts likewise.
 __global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *__restrict__ block_tot, int nb, uint64_t offset,
-                                                     uint64_t *__restrict__ grand_total)
+                                                     uint64_t *__restrict__ grand_total, uint32_t *__restrict__ block_cnt,
+                                                     unsigned long long *__restrict__ alive_total)
 {
     __shared__ uint64_t sm[16];
+    __shared__ uint32_t smc[16];
     __shared__ uint64_t carry_s;
+    __shared__ uint32_t carry_c;
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = offset;
+    if (threadIdx.x == 0) { carry_s = offset; carry_c = 0u; }
     __syncthreads();
     for (int base = 0; base < nb; base += 1024) {
         int i = base + threadIdx.x;
         uint64_t v = (i < nb) ? block_tot[i] : 0;
+        uint32_t vc = (block_cnt && i < nb) ? block_cnt[i] : 0u;
         uint64_t inc = wave_incl_scan_u64(v, lane);
-        if (lane == 63) sm[w] = inc;
+        uint32_t incc = vc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incc, o, 64); if (lane >= o) incc += t; }
+        if (lane == 63) { sm[w] = inc; smc[w] = incc; }
         __syncthreads();
         uint64_t woff = 0;
-        for (int k = 0; k < w; ++k) woff += sm[k];
+        uint32_t woffc = 0;
+        for (int k = 0; k < w; ++k) { woff += sm[k]; woffc += smc[k]; }
         uint64_t carry = carry_s;
-        if (i < nb) block_tot[i] = carry + woff + inc - v;
+        uint32_t carryc = carry_c;
+        if (i < nb) {
+            block_tot[i] = carry + woff + inc - v;
+            if (block_cnt) block_cnt[i] = carryc + woffc + incc - vc;
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == 1023) { carry_s = carry + woff + inc; carry_c = carryc + woffc + incc; }
         __syncthreads();
     }
     if (threadIdx.x == 0 && grand_total) *grand_total = carry_s;
+    if (threadIdx.x == 0 && alive_total) *alive_total = (unsigned long long)carry_c;
 }
 
 // `leaders` (optional) receives the last CDF entry of every 16-entry (128-byte) group: a 16x smaller copy the
@@ -86,21 +125,30 @@ __global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *__restrict__ bloc
 constexpr int kLeaderShift = 4;
 __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__restrict__ q, int64_t n,
                                                             const uint64_t *__restrict__ block_off,
-                                                            uint64_t *__restrict__ cdf, uint64_t *__restrict__ leaders)
+                                                            uint64_t *__restrict__ cdf, uint64_t *__restrict__ leaders, CompactOut co)
 {
     __shared__ uint64_t sm[kScanThreads / 64];
+    __shared__ uint32_t smc[kScanThreads / 64];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     uint64_t v[kScanItems];
     uint64_t s = 0;
+    uint32_t alive = 0;                      // bit k: item k has a non-zero weight
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         uint64_t x = (base + k < n) ? q[base + k] : 0;
         s += x;
         v[k] = s;
+        alive |= (x != 0ull ? 1u : 0u) << k;
     }
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t inc = wave_incl_scan_u64(s, lane);
-    if (lane == 63) sm[w] = inc;
+    const uint32_t cnt = (uint32_t)__popc(alive);
+    uint32_t incc = cnt;
+    if (co.block_cnt) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incc, o, 64); if (lane >= o) incc += t; }
+    }
+    if (lane == 63) { sm[w] = inc; smc[w] = incc; }
     __syncthreads();
     uint64_t off = block_off[blockIdx.x] + inc - s;
     for (int k = 0; k < w; ++k) off += sm[k];
@@ -112,6 +160,23 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__r
         const int64_t last = base + kScanItems - 1;
         if ((last & 15) == 15 && last < n) leaders[last >> kLeaderShift] = off + v[kScanItems - 1];
         else if (base < n && n - 1 <= last && ((n - 1) & 15) != 15) leaders[(n - 1) >> kLeaderShift] = off + v[(n - 1) - base];   // ragged last group
+    }
+    if (co.block_cnt && alive) {
+        uint32_t pos = co.block_cnt[blockIdx.x] + incc - cnt;
+        for (int k = 0; k < w; ++k) pos += smc[k];
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k)
+            if ((alive >> k) & 1u) {
+                if (pos < co.cap) {
+                    const int64_t i = base + k;
+                    const uint64_t c = off + v[k];
+                    co.ccdf[pos] = c;
+                    co.cidx[pos] = (uint32_t)i;
+                    co.crec[pos] = make_double4(co.x[i], co.y[i], co.th[i], 0.0);
+                    if ((pos & ((1u << kCompactGroupShift) - 1u)) == (1u << kCompactGroupShift) - 1u) co.ctop[pos >> kCompactGroupShift] = c;
+                }
+                ++pos;
+            }
     }
 }
 
@@ -159,6 +224,17 @@ struct ResampleArgs {
     double ox, oy, res;
     int cdf_lds_entries;
     unsigned long long *clear_counters;   // 4 words zeroed by the first thread, or null
+    // compact parent list (mcl::CompactOut: the particles with a non-zero fixed-point weight, in index order): the search
+    // runs over ccdf / ctop, the parent's index and record come from the list.  Sharded sets gather the shards' lists as
+    // chunks of cchunk_bytes ([ccdf | crec | cidx], ccap entries each; shard r's at cchunks + r * cchunk_bytes) and search
+    // gcdf, the chunks' CDF columns made global (offsets added, padding turned into plateaus) by k_compact_merge.
+    const uint64_t *ccdf;             // n_compact entries, non-decreasing, or null (dense search)
+    const uint64_t *ctop;             // ccdf[64 g + 63], n_compact >> 6 entries
+    int64_t n_compact;
+    const uint32_t *cidx;             // single list: particle index of entry p ...
+    const double4 *crec;              // ... and its record
+    const unsigned char *cchunks;     // gathered lists (cidx / crec null): entry p lives in chunk p / ccap
+    int64_t cchunk_bytes, ccap;
     const float *obs_src;             // this update's ranges (pinned host memory, read once by the first workgroup), or null
     int32_t *obs_idx_out;             // their table rows (obs_index_of), for a ray kernel that reads the static table directly
     int obs_B, obs_P;
@@ -196,6 +272,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     if (m >= a.n_children) return;
     uint64_t g = (uint64_t)(a.child_first + m);
     int64_t idx = m;
+    int64_t cpos = -1;                        // position in the compact parent list, when that is what was searched
     if (a.idx_in) {
         idx = a.idx_in[m];
     } else if (a.do_resample) {
@@ -218,6 +295,25 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 r0 = g * 4294967296ull + a.k0;
                 lmul = (uint64_t)a.n_children_total * 4294967296ull;
             }
+            if (a.ccdf) {
+                // compact list: first group of 64 whose last entry exceeds the threshold (ctop: dense, a few KB), then
+                // inside that group's 512 bytes
+                const int64_t ng = a.n_compact >> kCompactGroupShift;
+                int64_t glo = 0, glen = ng;
+                while (glen > 0) {
+                    int64_t half = glen >> 1, mid = glo + half;
+                    if (!mul_gt(a.ctop[mid], lmul, r0, r1)) { glo = mid + 1; glen = glen - half - 1; }
+                    else glen = half;
+                }
+                int64_t lo = glo << kCompactGroupShift;
+                int64_t len = (lo + (1 << kCompactGroupShift) <= a.n_compact) ? (1 << kCompactGroupShift) : a.n_compact - lo;
+                while (len > 0) {
+                    int64_t half = len >> 1, mid = lo + half;
+                    if (!mul_gt(a.ccdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
+                    else len = half;
+                }
+                cpos = (lo >= a.n_compact) ? a.n_compact - 1 : lo;
+            } else {
             // two-level search: first the tile (its exclusive prefixes are a small, cache-resident array left by the
             // scan), then inside the tile's 16 KB of the CDF
             int64_t lo = 0, len = a.n_parents;
@@ -253,12 +349,34 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 else len = half;
             }
             idx = (lo >= a.n_parents) ? a.n_parents - 1 : lo;
+            }
         }
+    }
+    double x, y, th;
+    bool have_rec = false;
+    if (cpos >= 0) {
+        // index and record of the selected entry of the compact list
+        if (a.cchunks) {
+            const int64_t r = cpos / a.ccap, e = cpos - r * a.ccap;
+            const unsigned char *chunk = a.cchunks + (size_t)r * (size_t)a.cchunk_bytes;
+            const double4 pr = reinterpret_cast<const double4 *>(chunk + (size_t)a.ccap * 8)[e];
+            idx = r * a.n_per_rank + (int64_t)reinterpret_cast<const uint32_t *>(chunk + (size_t)a.ccap * 40)[e];
+            x = pr.x; y = pr.y; th = pr.z;
+            if (a.remote_count) {
+                const unsigned long long rem = __ballot(r != a.self_rank);
+                if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1 && rem) atomicAdd(a.remote_count, (unsigned long long)__popcll(rem));
+            }
+        } else {
+            const double4 pr = a.crec[cpos];
+            idx = (int64_t)a.cidx[cpos];
+            x = pr.x; y = pr.y; th = pr.z;
+        }
+        have_rec = true;
     }
     if (a.idx_out) a.idx_out[m] = (int32_t)idx;
     if (a.index_only) return;
-    double x, y, th;
-    if (a.n_per_rank > 0) {
+    if (have_rec) {
+    } else if (a.n_per_rank > 0) {
         // the parent's record straight from the shard that owns it (this GPU or a peer over xGMI): only selected
         // parents ever cross a link, and a parent many children share is served from this GPU's L2 after the first fetch
         const int r = (int)(idx / a.n_per_rank);
@@ -310,6 +428,29 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
     if (a.cpack) a.cpack[m] = make_double4(x, y, th, 0.0);
     if (a.pc_out) a.pc_out[m] = particle_constants(x, y, th, a.ox, a.oy, a.res);
+}
+
+// The shards' compact lists, gathered as chunks ([ccdf | crec | cidx], ccap entries each), become ONE searchable CDF: chunk r's
+// column plus the fixed-point total of the shards before it, its unused tail turned into a plateau at the shard's end value
+// (a plateau entry is never the first one above a threshold, so it is never selected), and the first search level beside it.
+struct MergeArgs {
+    const unsigned char *chunks;
+    int64_t chunk_bytes, ccap;
+    int n_shards;
+    uint32_t count[kMaxShards];
+    uint64_t off[kMaxShards], tot[kMaxShards];
+    uint64_t *gcdf, *gtop;
+};
+__global__ __launch_bounds__(256) void k_compact_merge(MergeArgs a)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)a.n_shards * a.ccap) return;
+    const int r = (int)(p / a.ccap);
+    const int64_t e = p - (int64_t)r * a.ccap;
+    const uint64_t *col = reinterpret_cast<const uint64_t *>(a.chunks + (size_t)r * (size_t)a.chunk_bytes);
+    const uint64_t v = a.off[r] + (e < (int64_t)a.count[r] ? col[e] : a.tot[r]);
+    a.gcdf[p] = v;
+    if ((p & ((1 << kCompactGroupShift) - 1)) == (1 << kCompactGroupShift) - 1) a.gtop[p >> kCompactGroupShift] = v;
 }
 
 // ---- distinct parents of a shard's children (sharded resampling): a bitmap over the GLOBAL particle indices, its popcount
@@ -2268,9 +2409,9 @@ __global__ __launch_bounds__(1024) void k_tiny_tail(const double *__restrict__ l
             const unsigned long long *blk = reinterpret_cast<const unsigned long long *>(scalars);
             for (int k = 0; k < 8; ++k) host_out[k] = (unsigned long long)__double_as_longlong(scalars[k]);
             for (int k = 8; k < 14; ++k) host_out[k] = blk[k];
-            // the host may be polling word 16 instead of waiting for the stream's completion signal
+            // the host may be polling word 32 (kResultStamp) instead of waiting for the stream's completion signal
             __threadfence_system();
-            __hip_atomic_store(&host_out[16], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_out[32], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

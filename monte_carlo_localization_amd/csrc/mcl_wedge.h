@@ -23,8 +23,12 @@
 
 namespace mcl {
 
-constexpr int kWedges = 16;              // direction bins per turn (a power of two, multiple of 4)
-constexpr int kWedgeShift = 2;           // log2(kWedges / 4): bin -> quadrant
+#ifndef MCL_KWEDGES
+#define MCL_KWEDGES 16                   // (a build with another count is an experiment: include/mcl_hip_engine.h says 16)
+#endif
+constexpr int kWedges = MCL_KWEDGES;     // direction bins per turn (a power of two, multiple of 4)
+constexpr int kWedgeShift = kWedges == 8 ? 1 : kWedges == 16 ? 2 : kWedges == 32 ? 3 : 4;   // log2(kWedges / 4): bin -> quadrant
+static_assert(kWedges == (4 << kWedgeShift), "kWedges must be 8, 16, 32 or 64");
 constexpr int kWedgeR = 255;             // offsets searched per axis: gaps beyond 254 are capped anyway
 
 struct WedgeRow { int16_t xa, xb; };     // reachable offsets ox in row oy: xa..xb (none when xa > xb)

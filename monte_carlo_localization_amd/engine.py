@@ -33,7 +33,8 @@ EXPORTS = [
     "mcl_group_set_beam_angles", "mcl_group_set_particles", "mcl_group_init_particles_pose", "mcl_group_init_global",
     "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
     "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
-    "mcl_set_debug_count_probes", "mcl_set_particles_shard",
+    "mcl_set_debug_count_probes", "mcl_set_particles_shard", "mcl_get_compact_list", "mcl_compact_chunk_bytes", "mcl_export_compact",
+    "mcl_stage_resample_compact",
 ]
 
 
@@ -304,6 +305,12 @@ class Engine:
         return dict(exact_fallback_rays=int(out[0]), off_window_particles=int(out[1]), probes=int(out[2]),
                     level2_rays=int(out[3]))
 
+    def compact_list(self):
+        """(entries of the compact parent list that describes the current weights or -1, whether the last resampling used one)"""
+        n, u = C.c_int64(), C.c_int32()
+        self._chk(self.lib.mcl_get_compact_list(self._h, C.byref(n), C.byref(u)), "mcl_get_compact_list")
+        return n.value, bool(u.value)
+
     def set_debug_count_probes(self, on):
         self._chk(self.lib.mcl_set_debug_count_probes(self._h, C.c_int32(1 if on else 0)), "mcl_set_debug_count_probes")
 
@@ -388,6 +395,27 @@ class Engine:
         a = _c(action, np.float64)
         self._chk(self.lib.mcl_stage_motion_records(self._h, C.c_void_p(d_records), C.c_int64(n_records), C.c_void_p(d_record_of_child),
                                                     C.c_int64(child_first), C.c_int64(n_children_total), _p(a)), "mcl_stage_motion_records")
+
+    @staticmethod
+    def compact_chunk_bytes(chunk_entries) -> int:
+        b = C.c_int64()
+        rc = load_library().mcl_compact_chunk_bytes(C.c_int64(chunk_entries), C.byref(b))
+        if rc != MCL_OK:
+            raise EngineError(f"mcl_compact_chunk_bytes rc={rc}")
+        return b.value
+
+    def export_compact(self, d_chunk, chunk_entries):
+        """This shard's compact parent list -> d_chunk (device memory of compact_chunk_bytes(chunk_entries))."""
+        self._chk(self.lib.mcl_export_compact(self._h, C.c_void_p(d_chunk), C.c_int64(chunk_entries)), "mcl_export_compact")
+
+    def stage_resample_compact(self, d_chunks, n_shards, chunk_entries, counts, totals, n_per_shard, self_shard, child_first, n_children_total, action):
+        a = _c(action, np.float64)
+        c = np.ascontiguousarray(np.asarray(counts, np.int64))
+        t = np.ascontiguousarray(np.asarray(totals, np.uint64))
+        assert c.size == n_shards and t.size == n_shards
+        self._chk(self.lib.mcl_stage_resample_compact(self._h, C.c_void_p(d_chunks), C.c_int32(n_shards), C.c_int64(chunk_entries), _p(c), _p(t),
+                                                      C.c_int64(n_per_shard), C.c_int32(self_shard), C.c_int64(child_first),
+                                                      C.c_int64(n_children_total), _p(a)), "mcl_stage_resample_compact")
 
     def stage_rays(self, obs):
         o = _c(obs, np.float32)

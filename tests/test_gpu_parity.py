@@ -250,6 +250,94 @@ def test_native_philox_motion_noise(orc, engine_mod, sibal1):
     assert abs(nrm.mean()) < 0.05 and abs(nrm.std() - 1.0) < 0.05
 
 
+@pytest.mark.parametrize("shape", ["flat", "peaked"])
+def test_fixed_point_cdf_vs_discrete_distribution_at_262144(orc, engine_mod, sibal1, shape):
+    """The one spec deviation of the resampling step, measured: the engine draws from the EXACT integer CDF
+    of weights quantised to 2^-36 of the maximum, the reference from std::discrete_distribution's floating-point partial
+    sums (cpp:658-663, restated by orc_ref_resample_indices).  Under the same injected uniforms the two disagree only
+    where a draw falls within ~N * 2^-36 (relative) of a CDF step -- the reference's own sequential partial sums carry a
+    rounding error of that order too: expected O(N^2 * 2^-36 / sum(w / w_max)) children per update, i.e. a handful at
+    262 144 particles.  A disagreement picks a neighbour in CDF order (the next particle with weight), never a far one."""
+    n = 262144
+    rng = np.random.default_rng(77)
+    ang = orc.beam_angles(angle_step=54)
+    p = np.vstack([rng.uniform(-2, 2, n), rng.uniform(-1, 1, n), rng.uniform(-np.pi, np.pi, n)])
+    if shape == "flat":
+        w = rng.random(n) + 0.05
+    else:                                   # what an update leaves: a few per cent of the particles carry all the weight
+        w = np.exp(-np.abs(rng.normal(0.0, 40.0, n)))
+    w /= w.sum()
+    u = rng.random(n)
+    e = make_engine(engine_mod, sibal1, ang, n)
+    e.set_particles(p, w)
+    e.update((0.0, 0.0, 0.0), np.full(ang.size, 3.0, np.float32), uniforms=u)
+    got = e.resample_indices()
+    e.close()
+    want = orc.resample_indices(w, u)
+    bad = np.nonzero(got != want)[0]
+    # the engine's own spec is met exactly
+    k53 = np.minimum((u * 9007199254740992.0).astype(np.uint64), np.uint64(9007199254740991))
+    assert np.array_equal(got, orc.eng_resample_indices(orc.eng_quantize_weights(w), 0, k53=k53))
+    assert bad.size <= 16, f"{bad.size} of {n} children differ from std::discrete_distribution"
+    q = orc.eng_quantize_weights(w)
+    for m in bad:                           # a neighbour in CDF order: no particle with fixed-point weight in between
+        lo, hi = sorted((int(got[m]), int(want[m])))
+        assert not q[lo + 1:hi].any()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n", [20000, 300000])
+def test_compact_parent_list_equals_full_cdf(orc, engine_mod, spielberg, spielberg_oracle, monkeypatch, n, mode):
+    """From the second update on the resampling draws from the compact list of the particles that carry weight (a few per
+    cent of the set).  Indices, children and weights equal an engine with the list disabled (MCL_NO_COMPACT=1: full CDF,
+    packed records) bit for bit, and the indices equal the oracle's exact-CDF draw from the oracle's own weights."""
+    ang = orc.beam_angles(angle_step=2)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::2].astype(np.float32).copy()
+    p = tracking_cloud(np.random.default_rng(12), n)
+    w0 = np.full(n, 1.0 / n)
+    eng = {}
+    for tag in ("list", "full"):
+        if tag == "full":
+            monkeypatch.setenv("MCL_NO_COMPACT", "1")
+        eng[tag] = make_engine(engine_mod, spielberg, ang, n, seed=21, resample_mode=mode)
+        eng[tag].set_particles(p, w0)
+    monkeypatch.delenv("MCL_NO_COMPACT")
+    L = orc.eng_log_table(orc.sensor_table(spielberg_oracle.max_range_px))
+    oi = orc.obs_index(obs, spielberg_oracle)
+    q = orc.eng_quantize_weights(w0)
+    prev, times_used = -1, 0
+    for upd in range(4):
+        for e in eng.values():
+            e.update(ACTION, obs)
+        n_list, used = eng["list"].compact_list()
+        assert used == (prev > 0)
+        times_used += used
+        prev = n_list
+        assert eng["full"].compact_list() == (-1, False)
+        idx = eng["list"].resample_indices()
+        assert np.array_equal(idx, eng["full"].resample_indices())
+        assert np.array_equal(idx, orc.eng_resample_indices(q, mode, k53=orc.eng_philox_k53(21, upd, 0, n), k0=orc.eng_philox_k0(21, upd)))
+        parts = eng["list"].get_particles()
+        assert np.array_equal(parts, eng["full"].get_particles())
+        assert np.array_equal(eng["list"].get_weights(), eng["full"].get_weights())
+        logw, _, _ = orc.eng_log_weights(spielberg_oracle, parts, ang, oi, L)
+        assert np.array_equal(eng["list"].log_weights(), logw)
+        _, q, _ = orc.eng_weights_from_log(logw)
+        alive = int(np.count_nonzero(q))
+        assert n_list == (alive if alive <= max(4096, (n // 8 + 63) // 64 * 64) else -1)
+    assert times_used >= 2
+    # a flat weight set (every particle carries weight) has no list: the next update draws from the full CDF again
+    e = eng["list"]
+    e.set_particles(p, w0)
+    assert e.compact_list()[0] == -1
+    e.update(ACTION, obs)
+    assert e.compact_list()[1] is False
+    assert np.array_equal(e.resample_indices(), orc.eng_resample_indices(orc.eng_quantize_weights(w0), mode, k53=orc.eng_philox_k53(21, 4, 0, n),
+                                                                       k0=orc.eng_philox_k0(21, 4)))
+    for e in eng.values():
+        e.close()
+
+
 def test_all_zero_weights_resample_like_reference(orc, engine_mod, sibal1):
     n = 256
     ang = orc.beam_angles(angle_step=120)
