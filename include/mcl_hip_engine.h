@@ -310,9 +310,10 @@ int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int6
  * The reference is ONE process (main, cpp:1019-1025; MCL called from timer_update, cpp:777): a group owns one engine per
  * listed device, shards the particle set contiguously (n_total / n_devices each; cfg->max_particles is PER DEVICE,
  * cfg->device is ignored) and mirrors the single-engine entry points the host patch uses.  Per update a device receives
- * the other shards' fixed-point weights (8 B per particle, peer copies), scans the same exact global CDF, draws its own
- * children and reads each selected parent where it lives (peer pointer over xGMI); maxima and sums are combined on the
- * host.  Results are bit-identical to a single engine holding all particles.  The devices must have peer access to each
+ * the other shards' compact parent lists (44 B per particle that carries weight; mcl_get_compact_list) and draws its own
+ * children from the merged lists -- or, when some shard has no list (first update, flat weights), the other shards'
+ * fixed-point weights (8 B per particle), scans the same exact global CDF and reads each selected parent where it lives (peer
+ * pointer over xGMI); maxima and sums are combined on the host; the phases are ordered by events between the devices' streams.  Results are bit-identical to a single engine holding all particles.  The devices must have peer access to each
  * other; weight_mode LOG and resample_neff_permille 0 only. */
 typedef struct mcl_group mcl_group_t;
 int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_devices, mcl_group_t **out);
@@ -334,9 +335,12 @@ int mcl_group_get_particles(mcl_group_t *g, double *xyz, int64_t n_total);
 int mcl_group_get_weights(mcl_group_t *g, double *weights, int64_t n_total);
 int mcl_group_get_resample_indices(mcl_group_t *g, int32_t *idx, int64_t n_total);   /* global parent indices */
 int mcl_group_get_stage_timings(const mcl_group_t *g, double ms[6]);           /* per stage: the slowest device */
-/* bytes the last update moved between devices: [0] fixed-point weights received PER DEVICE, [1] parent records read from
- * peers by ALL devices (children with a remote parent x 32 B: an upper bound, a shared parent is cached after its first fetch) */
+/* bytes the last update moved between devices: [0] received PER DEVICE for the parent population -- the other shards' compact
+ * lists (44 B per particle that carries weight) or, when some shard had no list, their fixed-point weights (8 B per particle);
+ * [1] parent records read from peers by ALL devices (weights exchange only; children with a remote parent x 32 B: an upper
+ * bound, a shared parent is cached after its first fetch).  mcl_group_exchanged_lists: 1 when the last update exchanged lists. */
 int mcl_group_exchange_bytes(const mcl_group_t *g, uint64_t out[2]);
+int32_t mcl_group_exchanged_lists(const mcl_group_t *g);
 
 #ifdef __cplusplus
 }

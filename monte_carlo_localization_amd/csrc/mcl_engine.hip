@@ -142,6 +142,7 @@ struct mcl_engine {
     int fix_segments = 0;
     uint8_t *d_far = nullptr;           // cap * 4 flags
     uint32_t *d_far_list = nullptr;     // k_rays_sweep: slots with a flagged quadrant (cap entries, allocated on first use)
+    uint32_t *d_far_sorted = nullptr, *d_far_cnt = nullptr;   // the same in ascending order (k_far_*), per-2048-slot counts
     // cell sort for k_rays_cell
     double4 *d_pcs = nullptr;           // cap: pc in sorted order
     double *d_ths = nullptr;            // cap: heading in sorted order
@@ -482,7 +483,7 @@ void unpack_result(mcl_engine *h)
     // length of the compact list the scan of this update's weights wrote (word 16); unusable when it outgrew its arrays
     if (h->compact_pending) {
         const unsigned long long na = h->h_result[16];
-        h->compact_n = (na > 0 && na <= (unsigned long long)h->compact_cap) ? (int64_t)na : -1;
+        h->compact_n = na <= (unsigned long long)h->compact_cap ? (int64_t)na : -1;       // 0: a valid, empty list (no weight here)
         h->compact_pending = false;
     }
 }
@@ -528,6 +529,23 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip)
     const int64_t cell_min = h->env_cell_min > 0 ? h->env_cell_min : 65536;
     if (windows_ok && n >= cell_min && n * (int64_t)h->B >= (8 << 20)) return sweep_ok ? 5 : 4;
     return 2;
+}
+
+// The windowed pass over what k_rays_sweep's windows did not fit (k_rays_skip<.., FAR>): ordered list of the flagged slots,
+// then persistent workgroups with the 568-cell nibble window.  Every kernel stands down on the device when the launch flagged
+// fewer than kFarWindowedMin slots (the tracking regime: none), and k_rays_far stands down when this pass runs.
+int launch_far_windowed(mcl_engine *h, const mcl::RayArgs &a, int64_t n, bool count)
+{
+    const unsigned nb = (unsigned)((n + mcl::kFarTile - 1) / mcl::kFarTile);
+    const uint32_t *flags32 = reinterpret_cast<const uint32_t *>(h->d_far);
+    hipLaunchKernelGGL(mcl::k_far_count, dim3(nb), dim3(256), 0, h->stream, flags32, n, a.far_count, h->d_far_cnt);
+    hipLaunchKernelGGL(mcl::k_far_spine, dim3(1), dim3(1024), 0, h->stream, h->d_far_cnt, (int)nb, a.far_count);
+    hipLaunchKernelGGL(mcl::k_far_scatter, dim3(nb), dim3(256), 0, h->stream, flags32, n, a.far_count, h->d_far_cnt, h->d_far_sorted);
+    const size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
+    if (count) hipLaunchKernelGGL((mcl::k_rays_skip<1, true, true>), dim3(h->num_cu), dim3(mcl::kRayThreads), lds, h->stream, a);
+    else hipLaunchKernelGGL((mcl::k_rays_skip<1, false, true>), dim3(h->num_cu), dim3(mcl::kRayThreads), lds, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
 }
 
 int launch_rays(mcl_engine *h, const double *x, const double *y, const double *th, int64_t n, bool force_skip = false, bool direct_table = false)
@@ -687,7 +705,12 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             if (rc_plan) return rc_plan;
             a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.items = h->d_items; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.slot_space = 1;
-            if (!h->d_far_list) HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
+            if (!h->d_far_list) {
+                HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
+                HIPCHK(h, hipMalloc(&h->d_far_sorted, (size_t)h->cap * sizeof(uint32_t)));
+                HIPCHK(h, hipMalloc(&h->d_far_cnt, ((size_t)h->cap / mcl::kFarTile + 2) * sizeof(uint32_t)));
+            }
+            a.far_sorted = h->d_far_sorted; a.far_windowed = 1;
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
         size_t qlds = sweep ? (size_t)mcl::kSwSide * mcl::kSwSide : (size_t)h->qside * h->qside;
@@ -704,6 +727,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+            if (sweep) { const int rcw = launch_far_windowed(h, a, n, true); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
@@ -712,6 +736,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+            if (sweep) { const int rcw = launch_far_windowed(h, a, n, false); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<false>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
@@ -965,6 +990,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipDeviceSynchronize());        // the memsets above ran on the null stream; everything later uses h->stream
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -998,7 +1025,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
     dfree(h->d_gcdf); dfree(h->d_gtop);
     dfree(h->d_blockcnt); dfree(h->d_ccdf); dfree(h->d_ctop); dfree(h->d_cidx); dfree(h->d_crec);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);
@@ -1994,7 +2021,8 @@ int mcl_compact_chunk_bytes(int64_t chunk_entries, int64_t *bytes)
 static int export_compact_launch(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries, int dst_device, hipStream_t stream)
 {
     if (!h || !d_chunk || chunk_entries <= 0 || (chunk_entries & 63)) return MCL_ERR_INVALID_ARG;
-    if (h->compact_n <= 0 || h->compact_n > chunk_entries) return fail(h, MCL_ERR_NOT_READY, "no compact list of that size (mcl_get_compact_list)");
+    if (h->compact_n < 0 || h->compact_n > chunk_entries) return fail(h, MCL_ERR_NOT_READY, "no compact list of that size (mcl_get_compact_list)");
+    if (h->compact_n == 0) return MCL_OK;
     unsigned char *c = static_cast<unsigned char *>(d_chunk);
     const size_t n = (size_t)h->compact_n, cap = (size_t)chunk_entries;
     const int src = h->cfg.device;
@@ -2422,8 +2450,8 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
     // selected parents are read where they live.
     bool compact = g->q_total != 0;
     int64_t longest = 0;
-    for (int s = 0; s < G; ++s) { compact = compact && g->eng[s]->compact_n > 0; longest = std::max(longest, g->eng[s]->compact_n); }
-    const int64_t centries = (longest + 63) & ~(int64_t)63;
+    for (int s = 0; s < G; ++s) { compact = compact && g->eng[s]->compact_n >= 0; longest = std::max(longest, g->eng[s]->compact_n); }
+    const int64_t centries = std::max<int64_t>(64, (longest + 63) & ~(int64_t)63);
     for (int s = 0; s < G; ++s) {
         mcl_engine *e = g->eng[s];
         GHIP(g, hipSetDevice(e->cfg.device));
@@ -2588,5 +2616,7 @@ int mcl_group_exchange_bytes(const mcl_group_t *g, uint64_t out[2])
     out[0] = g->bytes_weights; out[1] = g->bytes_parents;
     return MCL_OK;
 }
+
+int32_t mcl_group_exchanged_lists(const mcl_group_t *g) { return g && g->compact_last ? 1 : 0; }
 
 }  // extern "C"

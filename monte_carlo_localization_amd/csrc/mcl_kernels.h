@@ -636,6 +636,9 @@ struct RayArgs {
     const double4 *unit_sums;      // k_rays_sweep: per unit of kSwUnit sorted particles (sum px, sum py, count, -), k_slice_means
     uint32_t *far_list;            // k_rays_sweep -> k_rays_far: slots with at least one flagged quadrant (appended once each), or null
     unsigned long long *far_count; // entries in far_list
+    const uint32_t *far_sorted;    // k_rays_skip<.., FAR>: the flagged slots in ascending (= spatial) order, k_far_scatter
+    const unsigned long long *far_min;   // the windowed far pass runs when *far_count >= *far_min ... (k_rays_far: when below)
+    int far_windowed;              // k_rays_far: 1 = a windowed far pass was launched beside it (stand down when it runs)
     int slot_space;                // 1: fix-list entries, far flags and `logw` are indexed by sorted slot (k_rays_sweep), and the
                                    // per-particle constants of k_rays_fix / k_rays_far come from pcs / ths; perm gives the particle
     double *logw;                  // out
@@ -860,17 +863,29 @@ __device__ __forceinline__ int trace_fp64(const RayArgs &a, const unsigned char 
 }
 
 // R = rays per lane per pass (independent dependency chains that hide the LDS round trip).
-template <int R, bool COUNT>
+// FAR: the windowed pass over the (particle, quadrant) pairs k_rays_sweep could not fit into its 256-cell windows -- the
+// uniform cloud of a global re-localisation, where 1024 consecutive sorted particles cover more cells than a window leaves
+// room for.  The flagged slots arrive in ascending (= tile-sorted) order; persistent workgroups take slices of kFarSlice
+// of them, centre this kernel's 568-cell nibble window on each slice (a 32 x 32-cell tile or two fit its play at any
+// supported range) and trace only the beams of the flagged quadrants; the sums are added to the slot's accumulator.
+constexpr int kFarSlice = 256;
+constexpr unsigned long long kFarWindowedMin = 2048;     // fewer flagged slots than this: k_rays_far (no window loads)
+template <int R, bool COUNT, bool FAR = false>
 __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
-    const int64_t p_begin = (int64_t)blockIdx.x * per;
-    const int64_t p_end = (p_begin + per < a.n) ? p_begin + per : a.n;
-
     unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0, cnt_l2 = 0;
+    const int64_t n_items = FAR ? (int64_t)min((unsigned long long)a.n, *a.far_count) : a.n;
+    if (FAR && (unsigned long long)n_items < kFarWindowedMin) return;
+    const uint32_t *flags32 = reinterpret_cast<const uint32_t *>(a.far_flags);
+    for (int64_t slice = blockIdx.x; FAR ? slice * kFarSlice < n_items : slice == (int64_t)blockIdx.x; slice += gridDim.x) {
+    if (FAR && slice != (int64_t)blockIdx.x) __syncthreads();          // every wave is done with the previous slice's window
+    const int64_t per = FAR ? kFarSlice : (a.n + gridDim.x - 1) / gridDim.x;
+    const int64_t p_begin = (FAR ? slice : (int64_t)blockIdx.x) * per;
+    const int64_t p_end = (p_begin + per < n_items) ? p_begin + per : n_items;
+
     const int TW = a.tw_cells;
     const int strideB = TW >> 1;
     const int wpr = TW >> 3;                 // 32-bit words (8 cells) per window row
@@ -878,26 +893,28 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     // (a small update is one particle per wave: these two round trips would otherwise follow the fill)
     const int64_t i_first = p_begin + wave;
     double4 pci_first = make_double4(0.0, 0.0, 0.0, 0.0);
-    if (i_first < p_end) pci_first = a.pc[i_first];
+    if (!FAR && i_first < p_end) pci_first = a.pc[i_first];
     const double2 cs_first = a.beam_cs[lane];          // beam_cs is padded to a multiple of 64 * R entries
     const int tw = a.P + 1;
     int wx0, wy0;
     {
         // ---- window placement: centred on the mean padded-pixel position of this slice ----
         double *red = reinterpret_cast<double *>(lds_raw);   // scratch, overwritten by the window below
-        double sx = 0.0, sy = 0.0;
+        double sx = 0.0, sy = 0.0, sc = 0.0;
         for (int64_t i = p_begin + threadIdx.x; i < p_end; i += kRayThreads) {
-            double4 c = a.pc[i];
+            double4 c = FAR ? a.pcs[a.far_sorted[i]] : a.pc[i];
             double gx = c.z, gy = c.w;
-            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; }
+            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; sc += 1.0; }
         }
-        sx = wave_sum(sx); sy = wave_sum(sy);
-        if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
+        sx = wave_sum(sx); sy = wave_sum(sy); sc = wave_sum(sc);
+        if (lane == 0) { red[3 * wave] = sx; red[3 * wave + 1] = sy; red[3 * wave + 2] = sc; }
         __syncthreads();
-        double mx = 0.0, my = 0.0;
-        for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
-        int64_t cntp = p_end - p_begin;
-        if (cntp > 0) { mx /= (double)cntp; my /= (double)cntp; }
+        double mx = 0.0, my = 0.0, mc = 0.0;
+        for (int k = 0; k < kRayWaves; ++k) { mx += red[3 * k]; my += red[3 * k + 1]; mc += red[3 * k + 2]; }
+        // the mean over the slice (FAR: over its finite positions; the plain kernel keeps dividing by the slice length,
+        // which is what its results -- not their values, the off-window counter -- were recorded with)
+        const double cntp = FAR ? mc : (double)(p_end - p_begin);
+        if (cntp > 0.0) { mx /= cntp; my /= cntp; }
         wx0 = (((int)floor(mx) + 1 - TW / 2)) & ~7;      // padded coordinate = global + 1
         wy0 = (int)floor(my) + 1 - TW / 2;
         __syncthreads();
@@ -932,8 +949,14 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     uint32_t strideB_v = (uint32_t)strideB, gbias_v = kG1 << (32 - kFx);
     asm volatile("" : "+v"(strideB_v), "+v"(gbias_v));   // keep both in VGPRs across the loop
 
-    for (int64_t i = p_begin + wave; i < p_end; i += kRayWaves) {
-        const double4 pci = (i == i_first) ? pci_first : a.pc[i];
+    for (int64_t ii = p_begin + wave; ii < p_end; ii += kRayWaves) {
+        // FAR: list entry ii is a sorted slot; its constants, heading and flags live in slot space, its particle index is perm[slot]
+        const int64_t slot = FAR ? (int64_t)a.far_sorted[ii] : ii;
+        const int64_t i = FAR ? (int64_t)a.perm[slot] : ii;
+        const double4 pci = FAR ? a.pcs[slot] : ((ii == i_first) ? pci_first : a.pc[ii]);
+        const uint32_t farfl = FAR ? flags32[slot] : 0u;
+        const double hth = FAR ? a.ths[slot] : 0.0;
+        const bool hth_ok = hth == hth && fabs(hth) < 1e6;
         double acc = 0.0;
         const double cth = pci.x, sth = pci.y;
         const double gpx = pci.z;                     // global pixel coordinate of the particle
@@ -948,7 +971,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
         const double p0x = inwin ? (wpx + kMagic) : ((gpx + 1.0 + 262144.0) + kMagic);
         const double p0y = inwin ? (wpy + kMagic) : ((gpy + 1.0 + 262144.0) + kMagic);
         const int base = inwin ? kCellBase : (kCellBase + 262144);
-        if (!inwin && lane == 0) ++cnt_off;
+        if ((FAR || !inwin) && lane == 0) ++cnt_off;      // FAR: every pair here is one k_rays_sweep's windows did not fit
         // the particle's own cell gives a first skip shared by all its beams
         uint32_t amb0 = 0;
         int s0 = 1;
@@ -976,6 +999,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
             for (int grp = 0; grp < ngroups; ++grp) {
                 int NUx[R], NUy[R], rem[R], n[R];
                 uint32_t Pex[R], Pey[R], g[R];
+                bool want[R];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     int j = (grp * R + k) * 64 + lane;        // beam_cs is padded: no clamp needed
@@ -986,6 +1010,13 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                     Pex[k] = mad_i24(-a.P, NUx[k], P0x);
                     Pey[k] = mad_i24(-a.P, NUy[k], P0y);
                     rem[k] = (j < a.B) ? rem_start : 0;       // a padding slot probes its end sample once
+                    if (FAR) {
+                        // only the beams of a flagged quadrant (the others were traced by k_rays_sweep); the quadrant of a
+                        // beam is derived as everywhere else (beam_turns), a garbage heading has all its beams in quadrant 0
+                        const int qj = (j < a.B) ? (hth_ok ? (beam_turns(hth, a.beam_angle[j]) & 3) : 0) : 0;
+                        want[k] = j < a.B && ((farfl >> (8 * qj)) & 0xFFu) != 0u;
+                        if (!want[k]) rem[k] = 0;
+                    }
                     g[k] = g0;
                     n[k] = 0;
                 }
@@ -1035,7 +1066,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     int j = (grp * R + k) * 64 + lane;
-                    if (j < a.B) {
+                    if (j < a.B && (!FAR || want[k])) {
                         // R == 1: rem was decremented once more after an overshoot; only the stop case reads it
                         int r = (n[k] == 0) ? a.P - rem[k] - 1 : a.P;
                         if (COUNT) ++cnt_probe;
@@ -1062,7 +1093,12 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
         } else {
             for (int j0 = 0; j0 < a.B; j0 += 64) {
                 int j = j0 + lane;
-                if (j < a.B) {
+                bool mine = j < a.B;
+                if (FAR && mine) {
+                    const int qj = hth_ok ? (beam_turns(hth, a.beam_angle[j]) & 3) : 0;
+                    mine = ((farfl >> (8 * qj)) & 0xFFu) != 0u;
+                }
+                if (mine) {
                     int r = a.P;
                     unsigned np = 0;
                     uint32_t amb = amb0;
@@ -1083,8 +1119,12 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
             }
         }
         acc = wave_sum(acc);          // exact: fp32 table entries, |sum| < 2^13
-        if (lane == 0) a.logw[i] = acc;
+        if (lane == 0) {
+            if (FAR) atomicAdd(&a.logw[slot], acc);      // beside what k_rays_sweep / k_rays_fix leave for this slot
+            else a.logw[i] = acc;
+        }
     }
+    }   // slices
     if (a.counters) {
         cnt_exact = wave_sum_u64(cnt_exact);
         cnt_off = wave_sum_u64(cnt_off);
@@ -2110,6 +2150,71 @@ __global__ void k_fix_overflow(const unsigned long long *__restrict__ counts, in
     if (threadIdx.x == 0) *over = s;
 }
 
+// The flagged slots in ascending order (k_rays_sweep appends them in arrival order): count per 2048 slots, exclusive scan of the
+// counts by one workgroup, scatter.  All three stand down below kFarWindowedMin flagged slots (k_rays_far handles those).
+constexpr int kFarTile = 2048;
+__global__ __launch_bounds__(256) void k_far_count(const uint32_t *__restrict__ flags32, int64_t n, const unsigned long long *__restrict__ far_count,
+                                                  uint32_t *__restrict__ cnt)
+{
+    if (*far_count < kFarWindowedMin) return;
+    __shared__ uint32_t ws[4];
+    const int64_t base = (int64_t)blockIdx.x * kFarTile + (int64_t)threadIdx.x * 8;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c += (base + k < n && flags32[base + k] != 0u) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void k_far_spine(uint32_t *__restrict__ cnt, int nb, const unsigned long long *__restrict__ far_count)
+{
+    if (*far_count < kFarWindowedMin) return;
+    __shared__ uint32_t ws[16];
+    __shared__ uint32_t carry_sh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_sh = 0u;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int i = b0 + (int)threadIdx.x;
+        const uint32_t v = i < nb ? cnt[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        uint32_t at = carry_sh + inc - v;
+        for (int k = 0; k < wv; ++k) at += ws[k];
+        if (i < nb) cnt[i] = at;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = at + v;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_far_scatter(const uint32_t *__restrict__ flags32, int64_t n, const unsigned long long *__restrict__ far_count,
+                                                    const uint32_t *__restrict__ cnt_excl, uint32_t *__restrict__ out)
+{
+    if (*far_count < kFarWindowedMin) return;
+    __shared__ uint32_t ws[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kFarTile + (int64_t)threadIdx.x * 8;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m |= ((base + k < n && flags32[base + k] != 0u) ? 1u : 0u) << k;
+    const uint32_t c = (uint32_t)__popc(m);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    uint32_t at = cnt_excl[blockIdx.x] + inc - c;
+    for (int k = 0; k < wv; ++k) at += ws[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if ((m >> k) & 1u) out[at++] = (uint32_t)(base + k);
+}
+
 // (particle, quadrant) pairs outside their quadrant window: the global-field path, one wave per particle.
 template <bool COUNT>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
@@ -2119,6 +2224,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
     const int64_t p_end = a.n;
     unsigned long long cnt_exact = 0, cnt_off = 0, cnt_probe = 0;
     const uint32_t *flags32 = reinterpret_cast<const uint32_t *>(a.far_flags);
+    if (a.far_windowed && a.far_count && *a.far_count >= kFarWindowedMin) return;     // k_rays_skip<.., FAR> takes this launch
     // each wave scans 64 particles' flags with one coalesced load and visits only the flagged ones.  The 64-particle
     // chunks are dealt round-robin over ALL waves of the grid: in sorted-slot order (k_rays_sweep) the flagged particles
     // sit in a few long runs, which a contiguous range per workgroup would hand to a few workgroups

@@ -2,26 +2,32 @@
 torch.distributed (backend "nccl" == RCCL over xGMI) for the exchange steps of an update.
 
 The reference has no distributed code.  The update couples particles only through
-  (1) resampling  — children of rank g are drawn from the GLOBAL weighted set.  Only the fixed-point weights are
-                    gathered (all-gather, 8 B per particle: every rank scans the same exact integer CDF); each rank then
-                    asks the engine which parents its children selected (`stage_resample_indices`), requests the DISTINCT
-                    ones from their owners (two all-to-alls: 4-byte local indices out, 32-byte records back) and hands the
-                    compact record table to `stage_motion_records`.  With the peaked weights of a converged filter a few
-                    thousand parents serve millions of children, so almost nothing crosses a link; the worst case
-                    (uniform weights) moves what the former wholesale all-gather of the records always moved;
+  (1) resampling  — children of rank g are drawn from the GLOBAL weighted set.
+                    LIST exchange (the usual case): after an update with many beams only a few per cent of the particles
+                    keep a non-zero fixed-point weight, and a particle without weight is never selected (E6).  The scan of
+                    every shard's weights leaves a compact list of the ones that carry weight (index, CDF value, record:
+                    44 B each); ONE all-gather of those lists gives every rank the whole parent population -- no weight
+                    gather, no pass over n_total elements, no index / request / reply round trips.  The list lengths and
+                    weight totals of all ranks ride in the sums all-reduce of the previous update, so every rank sizes the
+                    gather identically without a collective of its own.
+                    DENSE exchange (some shard has no list: the first update after initialisation, flat weights): the
+                    fixed-point weights are gathered (all-gather, 8 B per particle: every rank scans the same exact integer
+                    CDF); each rank asks the engine which parents its children selected (`stage_resample_indices`), requests
+                    the DISTINCT ones from their owners (all-to-alls: local indices out, 32-byte records back) and hands the
+                    record table to `stage_motion_records`;
   (2) max log-weight — all-reduce(MAX) of one double;
-  (3) normalisation / pose — all-reduce(SUM) of five doubles (+ the two halves of the local
-                    fixed-point weight total, so that the next update knows the global total
-                    without reading it back from the device).
+  (3) normalisation / pose — all-reduce(SUM) of five doubles, plus three slots per rank that only that rank fills: the
+                    length of its compact list and the two halves of its fixed-point weight total (exact in doubles), so
+                    that the next update knows every shard's list and the global total.
 Everything else (motion, ray cast, likelihood) is local to a shard.  Because the CDF is an exact
 integer scan and the log-weights are exact fp64 sums, resample indices and weights are bit-identical
 for any number of ranks.  (Several GPUs driven by ONE process do the same through `mcl_group_*` in the
 library itself, with peer copies and peer pointers instead of collectives.)
 
-`shard` is anything with the staging interface of engine.Engine (export_state / scan_weights /
-stage_resample_indices / stage_distinct_parents / export_records_at / stage_motion_records / stage_rays / scalars /
-stage_weights / stage_finish); tests drive this class on CPU tensors over gloo with an oracle-backed stand-in that lives
-under tests/.
+`shard` is anything with the staging interface of engine.Engine (compact_list / export_compact / stage_resample_compact /
+export_state / scan_weights / stage_resample_indices / stage_distinct_parents / export_records_at / stage_motion_records /
+stage_rays / scalars / stage_weights / stage_finish); tests drive this class on CPU tensors over gloo with an oracle-backed
+stand-in that lives under tests/.
 """
 from __future__ import annotations
 
@@ -59,7 +65,16 @@ class ShardedFilter:
         self.uniq_buf = torch.empty(n, dtype=i64, device=device)        # distinct parents of the local children (ascending)
         self.slot_buf = torch.empty(n, dtype=i32, device=device)        # every child's position among them
         self.pose = np.zeros(3)
-        self.exchange_bytes = dict(weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
+        self.exchange_bytes = dict(kind="none", weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0,
+                                   list_bytes_received=0)
+        # list exchange: every rank's list length (-1: none) and fixed-point total, known from the previous update's sums
+        self.counts = None
+        self.totals = None
+        self.list_cap = max(4096, ((n // 8 + 63) // 64) * 64)             # the engine's own bound on a list (max_particles / 8)
+        self.chunk_local = None                                           # grown on demand: one chunk / world chunks, uint8
+        self.chunk_all = None
+        self.pending_list = None                                          # (async all-gather of the lists, entries per chunk)
+        self.use_lists = os.environ.get("MCL_DIST_NO_LISTS") != "1" and hasattr(shard, "export_compact")
 
     def _sync(self):
         if self.device.type == "cuda":
@@ -67,11 +82,33 @@ class ShardedFilter:
 
     def reset(self):
         """Call after the shard's particle state was replaced from outside (set_particles / init_*)."""
-        if self.pending_q is not None:
-            self.pending_q.wait()
-            self._sync()
+        for pend in (self.pending_q, self.pending_list[0] if self.pending_list else None):
+            if pend is not None:
+                pend.wait()
+                self._sync()
         self.pending_q = None
+        self.pending_list = None
         self.q_total = None
+        self.counts = self.totals = None
+
+    # ---- list exchange
+    def _lists_usable(self):
+        return (self.use_lists and self.counts is not None and bool((self.counts >= 0).all()) and int(self.counts.max()) <= self.list_cap
+                and int(self.totals.sum()) > 0)
+
+    def _start_list_gather(self, async_op):
+        """all-gather of the shards' compact lists as chunks of `entries` entries (the same on every rank: the longest list
+        rounded up to 64); returns (work handle or None, entries)."""
+        entries = max(64, (int(self.counts.max()) + 63) // 64 * 64)
+        nbytes = 44 * entries
+        if self.chunk_local is None or self.chunk_local.numel() < nbytes:
+            self.chunk_local = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.chunk_all = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+        if int(self.counts[self.rank]) > 0:
+            self.shard.export_compact(self.chunk_local.data_ptr(), entries)
+        self._sync()
+        work = dist.all_gather_into_tensor(self.chunk_all[:nbytes * self.world], self.chunk_local[:nbytes], group=self.group, async_op=async_op)
+        return (work if async_op else None), entries
 
     def _distinct(self):
         """self.parent (global indices) -> (distinct parents ascending = grouped by owner, position of every child's parent
@@ -117,9 +154,23 @@ class ShardedFilter:
         self.exchange_bytes.update(requests_sent=8 * remote, records_received=32 * remote, distinct_remote_parents=remote)
         return table, inv
 
-    def update(self, action, obs):
+    def _resample_from_lists(self, action):
+        if self.pending_list is not None:
+            work, entries = self.pending_list                             # issued at the end of the previous update
+            self.pending_list = None
+            if work is not None:
+                work.wait()
+        else:
+            _, entries = self._start_list_gather(False)
+        self._sync()
+        listed = int(self.counts.sum())
+        self.exchange_bytes.update(kind="lists", list_bytes_received=44 * (listed - int(self.counts[self.rank])), weights_received=0,
+                                   requests_sent=0, records_received=0, distinct_remote_parents=0)
+        self.shard.stage_resample_compact(self.chunk_all.data_ptr(), self.world, entries, self.counts, self.totals, self.n, self.rank,
+                                          self.rank * self.n, self.n_total, action)
+
+    def _resample_dense(self, action):
         s = self.shard
-        # (1) exchange for resampling: weights everywhere, then only the selected parents
         if self.pending_q is None:
             s.export_state(0, 0, 0, self.loc_q.data_ptr())
             dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
@@ -127,37 +178,66 @@ class ShardedFilter:
             self.pending_q.wait()                                        # issued at the end of the previous update
             self.pending_q = None
         self._sync()
-        self.exchange_bytes["weights_received"] = 8 * self.n * (self.world - 1)
+        self.exchange_bytes.update(kind="dense", weights_received=8 * self.n * (self.world - 1), list_bytes_received=0)
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
         s.stage_resample_indices(self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, self.parent.data_ptr())
         table, slot = self._fetch_parents()
         self._sync()
         s.stage_motion_records(table.data_ptr(), int(table.shape[0]), slot.data_ptr(), self.rank * self.n, self.n_total, action)
+
+    def update(self, action, obs):
+        s = self.shard
+        # (1) exchange for resampling + the children
+        if self._lists_usable():
+            self._resample_from_lists(action)
+        else:
+            if self.pending_list is not None and self.pending_list[0] is not None:
+                self.pending_list[0].wait()
+            self.pending_list = None
+            self._resample_dense(action)
         s.stage_rays(obs)
         # (2) global max log-weight
         read = getattr(s, "host_scalars", s.scalars)                      # the stage calls already read SCALARS back
         mx = torch.tensor([read()[0]], dtype=torch.float64, device=self.device)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         s.stage_weights(float(mx.item()))
-        if self.overlap:
-            # this update's fixed-point weights are final: start gathering them for the next update now, beside the
-            # sums all-reduce and the host work between updates
-            s.export_state(0, 0, 0, self.loc_q.data_ptr())
-            self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
-        # (3) global sums: sum w, sum wx, sum wy, sum w sin, sum w cos
+        # (3) global sums: sum w, sum wx, sum wy, sum w sin, sum w cos; per rank (filled by that rank only): list length + 1
+        # (0: no list) and the two halves of its fixed-point weight total
         sc = read()
         ql = int(np.float64(sc[2]).view(np.uint64))                      # this shard's fixed-point weight total
-        sums = torch.tensor([sc[1], sc[3], sc[4], sc[5], sc[6], float(ql & 0xFFFFFFFF), float(ql >> 32)],
-                            dtype=torch.float64, device=self.device)
+        n_list = s.compact_list()[0] if self.use_lists else -1
+        vec = np.zeros(5 + 3 * self.world)
+        vec[:5] = (sc[1], sc[3], sc[4], sc[5], sc[6])
+        vec[5 + 3 * self.rank: 8 + 3 * self.rank] = (float(n_list + 1), float(ql & 0xFFFFFFFF), float(ql >> 32))
+        sums = torch.from_numpy(vec).to(self.device)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         gs = sums.cpu().numpy()
-        self.q_total = (int(gs[5]) + (int(gs[6]) << 32)) & 0xFFFFFFFFFFFFFFFF     # exact: both halves stay below 2^53
+        per = gs[5:].reshape(self.world, 3)
+        self.counts = per[:, 0].astype(np.int64) - 1
+        self.totals = np.array([(int(a) + (int(b) << 32)) & 0xFFFFFFFFFFFFFFFF for a, b in per[:, 1:]], dtype=np.uint64)   # exact: halves < 2^32
+        self.q_total = int(sum(int(t) for t in self.totals)) & 0xFFFFFFFFFFFFFFFF
         gs = gs[:5]
         s.stage_finish(gs)
+        if self.overlap:
+            # this update's weights are final: start the exchange of the next update now, beside the host work between updates
+            if self._lists_usable():
+                self.pending_list = self._start_list_gather(True)
+            else:
+                s.export_state(0, 0, 0, self.loc_q.data_ptr())
+                self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
         k = 1.0 / gs[0] if gs[0] > 0 else 1.0
         self.pose = np.array([gs[1] * k, gs[2] * k, np.arctan2(gs[3] * k, gs[4] * k)])
         return self.pose
+
+    def set_particles(self, xyz_colmajor, weights):
+        """Host-supplied particles for this shard (any non-negative weights): every shard quantises its weights against the
+        maximum of the WHOLE set, found with one all-reduce."""
+        w = np.ascontiguousarray(weights, np.float64)
+        mx = torch.tensor([float(w.max())], dtype=torch.float64, device=self.device)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        self.shard.set_particles_shard(xyz_colmajor, w, float(mx.item()))
+        self.reset()
 
     def expected_pose(self):
         return self.pose

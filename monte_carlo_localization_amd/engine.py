@@ -34,7 +34,7 @@ EXPORTS = [
     "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
     "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
     "mcl_set_debug_count_probes", "mcl_set_particles_shard", "mcl_get_compact_list", "mcl_compact_chunk_bytes", "mcl_export_compact",
-    "mcl_stage_resample_compact",
+    "mcl_stage_resample_compact", "mcl_group_exchanged_lists",
 ]
 
 
@@ -61,6 +61,18 @@ def load_library():
     """Loads libmcl_hip_engine.so (built by __graft_entry__.build()); raises if absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm wheels bundle their own copies of the ROCm runtime under the same sonames as /opt/rocm's
+        # (libamdhip64.so.7, libhsa-runtime64.so.1).  A process that uses both must load torch's first: if this library pulls
+        # in /opt/rocm's copies before `import torch`, torch ends up on a runtime it was not built with and reports
+        # "No HIP GPUs are available".  So when torch is installed and not imported yet, import it here (dist.py and
+        # bench.py need it anyway); without torch the library simply uses /opt/rocm's runtime.
+        import importlib.util
+        import sys
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise EngineError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
@@ -536,4 +548,5 @@ class Group:
     def exchange_bytes(self):
         out = np.zeros(2, np.uint64)
         self._chk(self.lib.mcl_group_exchange_bytes(self._h, _p(out)), "mcl_group_exchange_bytes")
-        return dict(weights_received_per_device=int(out[0]), parent_records_from_peers=int(out[1]))
+        return dict(weights_received_per_device=int(out[0]), parent_records_from_peers=int(out[1]),
+                    lists=bool(self.lib.mcl_group_exchanged_lists(self._h)))

@@ -71,3 +71,13 @@ def tracking_cloud(rng, n, pose=(0.0, 0.0, 0.0), sig=(0.5, 0.5, 0.4)):
     th = pose[2] + rng.normal(0, sig[2], n)
     p[2] = (th + np.pi) % (2 * np.pi) - np.pi
     return p
+
+
+def block_digests(a, block=1 << 20):
+    """crc32 of every `block` entries along the last axis (rows of a 2-D array separately): arrays of tens of millions of
+    entries are compared through these instead of being written out.  Shards that are a whole number of blocks long
+    concatenate to the digests of the unsharded array."""
+    import zlib
+    a = np.ascontiguousarray(a)
+    rows = a.reshape(-1, a.shape[-1])
+    return np.array([[zlib.crc32(r[i:i + block].tobytes()) for i in range(0, r.size, block)] for r in rows], dtype=np.uint32)

@@ -20,13 +20,21 @@ def main():
     from monte_carlo_localization_amd.dist import ShardedFilter
     from oracle import oracle as orc
     m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
-    ang = orc.beam_angles(angle_step=30)
-    obs = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"][::30].copy()
+    bstep = int(os.environ.get("MCL_TEST_BEAM_STEP", "30"))
+    ang = orc.beam_angles(angle_step=bstep)
+    obs = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"][::bstep].copy()
     rng = np.random.default_rng(123)
     ntot = n_local * world
-    p = np.stack([rng.normal(0, 0.5, ntot), rng.normal(0, 0.5, ntot), rng.normal(0, 0.4, ntot)])
+    device_init = os.environ.get("MCL_TEST_DEVICE_INIT") == "1"        # the engine's own initialiser (Philox keyed by the global index)
+    digest = os.environ.get("MCL_TEST_DIGEST") == "1"                  # checksums per 2^20 particles instead of the arrays
+    p = None if device_init else np.stack([rng.normal(0, 0.5, ntot), rng.normal(0, 0.5, ntot), rng.normal(0, 0.4, ntot)])
     mine = slice(rank * n_local, (rank + 1) * n_local)
     w = np.full(n_local, 1.0 / ntot)
+    skewed = os.environ.get("MCL_TEST_SKEWED_WEIGHTS") == "1"          # host-supplied weights that differ between the shards
+    if skewed:
+        wall = rng.random(ntot) * np.where(np.arange(ntot) < ntot // 2, 1e-3, 1.0)
+        wall /= wall.sum()
+        w = wall[mine]
     if backend_kind == "oracle":
         from oracle_shard import OracleShard
         om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
@@ -38,13 +46,19 @@ def main():
         shard = engine.Engine(max_particles=n_local, device=0, seed=2024, resample_mode=mode)
         shard.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
         shard.set_beam_angles(ang)
-        shard.set_particles(p[:, mine], w)
+        if device_init:
+            shard.init_particles_pose((0.0, 0.0, 0.0), n_local, rank * n_local, ntot)
+        else:
+            shard.set_particles(p[:, mine], w)
         device = torch.device("cuda", 0)
     overlap = len(sys.argv) > 6 and sys.argv[6] == "overlap"
     sf = ShardedFilter(shard, n_local, device, overlap=overlap)
-    poses = []
+    if skewed:
+        sf.set_particles(p[:, mine], w)                 # every shard quantises against the maximum of the whole set
+    poses, kinds = [], []
     for _ in range(steps):
         poses.append(sf.update((0.05, 0.0, 0.01), obs))
+        kinds.append(sf.exchange_bytes["kind"])
     if backend_kind == "oracle":
         parts, q, idx = shard.p, shard.q, shard.idx
     else:
@@ -52,7 +66,12 @@ def main():
         qt = torch.empty(n_local, dtype=torch.int64, device=device)
         shard.export_state(0, 0, 0, qt.data_ptr())
         q = qt.cpu().numpy().view(np.uint64)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses))
+    if digest:
+        from conftest import block_digests
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=block_digests(parts), q=block_digests(q), idx=block_digests(idx),
+                 poses=np.array(poses), kinds=np.array(kinds))
+    else:
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds))
     dist.barrier()
     dist.destroy_process_group()
 

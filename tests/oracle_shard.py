@@ -111,6 +111,54 @@ class OracleShard:
         self.p = orc.motion_model(parents, action, nrm)
         self.upd += 1
 
+    # ---- compact parent lists (mcl_get_compact_list / mcl_export_compact / mcl_stage_resample_compact)
+    def compact_list(self):
+        alive = np.nonzero(self.q)[0]
+        cap = max(4096, (self.n // 8 + 63) // 64 * 64)
+        return (int(alive.size) if alive.size <= cap else -1), False
+
+    def export_compact(self, d_chunk, chunk_entries):
+        alive = np.nonzero(self.q)[0]
+        k = alive.size
+        assert k <= chunk_entries and chunk_entries % 64 == 0
+        cdf = np.cumsum(self.q, dtype=np.uint64)
+        _view(d_chunk, chunk_entries, ctypes.c_uint64, np.uint64)[:k] = cdf[alive]
+        rec = _view(d_chunk + 8 * chunk_entries, 4 * chunk_entries, ctypes.c_double, np.float64).reshape(chunk_entries, 4)
+        rec[:k, 0], rec[:k, 1], rec[:k, 2], rec[:k, 3] = self.p[0, alive], self.p[1, alive], self.p[2, alive], 0.0
+        _view(d_chunk + 40 * chunk_entries, chunk_entries, ctypes.c_uint32, np.uint32)[:k] = alive.astype(np.uint32)
+
+    def stage_resample_compact(self, d_chunks, n_shards, chunk_entries, counts, totals, n_per_shard, self_shard, child_first, n_children_total, action):
+        """The scalar statement of the list exchange: the lists are the whole weighted population -- rebuild the sparse global
+        weight vector from them and draw exactly as from the dense one."""
+        q = np.zeros(n_shards * n_per_shard, np.uint64)
+        rec = np.zeros((n_shards * n_per_shard, 3))
+        for r in range(n_shards):
+            k = int(counts[r])
+            if k == 0:
+                continue
+            base = d_chunks + 44 * chunk_entries * r
+            cdf = _view(base, chunk_entries, ctypes.c_uint64, np.uint64)[:k]
+            assert int(cdf[-1]) == int(totals[r])
+            idx = _view(base + 40 * chunk_entries, chunk_entries, ctypes.c_uint32, np.uint32)[:k].astype(np.int64) + r * n_per_shard
+            q[idx] = np.diff(cdf, prepend=np.uint64(0)).astype(np.uint64)
+            rec[idx] = _view(base + 8 * chunk_entries, 4 * chunk_entries, ctypes.c_double, np.float64).reshape(chunk_entries, 4)[:k, :3]
+        n = self.n
+        if self.mode == 0:
+            idx = orc.eng_resample_indices(q, 0, n_children=n, k53=orc.eng_philox_k53(self.seed, self.upd, child_first, n))
+        else:
+            idx = orc.eng_resample_indices(q, 1, n_children=n_children_total, k0=orc.eng_philox_k0(self.seed, self.upd))[child_first:child_first + n]
+        self.idx = idx
+        assert (q[idx] > 0).all()
+        nrm = orc.eng_philox_normals(self.seed, self.upd, child_first, n)
+        self.p = orc.motion_model(np.ascontiguousarray(rec[idx].T), action, nrm)
+        self.upd += 1
+
+    def set_particles_shard(self, p, w, max_weight):
+        self.p = np.array(p, np.float64)
+        self.n = self.p.shape[1]
+        self.w = np.array(w, np.float64)
+        self.q = np.floor(np.where(self.w > 0, self.w / max_weight, 0.0) * 2.0 ** 36).astype(np.uint64)
+
     def stage_rays(self, obs):
         oi = orc.obs_index(np.asarray(obs, np.float32), self.om)
         self.logw, _, _ = orc.eng_log_weights(self.om, self.p, self.angles, oi, self.L, use_omp=False)

@@ -22,12 +22,12 @@ def free_port():
     return p
 
 
-def run_world(kind, out_dir, world, n_local, steps, mode, overlap=False):
+def run_world(kind, out_dir, world, n_local, steps, mode, overlap=False, **extra_env):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), kind, str(out_dir),
                                        str(n_local), str(steps), str(mode), "overlap" if overlap else "sync"], env=env))
     for p in procs:
@@ -51,6 +51,31 @@ def test_two_ranks_equal_one_rank_gloo_cpu(tmp_path, mode, overlap):
     two = run_world("oracle", d2, 2, 96, 3, mode, overlap)
     one = run_world("oracle", d1, 1, 192, 3, mode)
     check_equal(two, one, 96)
+    # the first update has no lists yet (uniform start, nothing reduced), the later ones exchange lists
+    assert list(two[0]["kinds"]) == ["dense", "lists", "lists"]
+
+
+def test_two_ranks_dense_exchange_only_gloo_cpu(tmp_path):
+    """The dense exchange (weights gathered, distinct parents fetched) on every update: what runs when some shard has no
+    compact list."""
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir(); d1.mkdir()
+    two = run_world("oracle", d2, 2, 96, 3, 0, False, MCL_DIST_NO_LISTS="1")
+    one = run_world("oracle", d1, 1, 192, 3, 0)
+    check_equal(two, one, 96)
+    assert list(two[0]["kinds"]) == ["dense"] * 3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_two_ranks_host_weights_that_differ_between_shards_gloo_cpu(tmp_path, mode):
+    """ShardedFilter.set_particles: every shard scales its fixed-point weights by the maximum of the WHOLE set, so a set whose
+    mass sits in the second shard resamples exactly like the unsharded one."""
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir(); d1.mkdir()
+    two = run_world("oracle", d2, 2, 96, 1, mode, False, MCL_TEST_SKEWED_WEIGHTS="1")
+    one = run_world("oracle", d1, 1, 192, 1, mode, False, MCL_TEST_SKEWED_WEIGHTS="1")
+    check_equal(two, one, 96)
+    assert (np.concatenate([z["idx"] for z in two]) >= 96).mean() > 0.9      # the parents come from the heavy shard
 
 
 @pytest.mark.gpu
@@ -61,6 +86,17 @@ def test_two_ranks_equal_one_rank_hip_engine(tmp_path, mode, overlap):
     two = run_world("engine", d2, 2, 4096, 4, mode, overlap)
     one = run_world("engine", d1, 1, 8192, 4, mode)
     check_equal(two, one, 4096)
+    assert list(two[0]["kinds"]) == ["dense", "lists", "lists", "lists"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_dense_exchange_and_skewed_weights_hip_engine(tmp_path):
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir(); d1.mkdir()
+    two = run_world("engine", d2, 2, 4096, 3, 0, False, MCL_DIST_NO_LISTS="1", MCL_TEST_SKEWED_WEIGHTS="1")
+    one = run_world("engine", d1, 1, 8192, 3, 0, False, MCL_TEST_SKEWED_WEIGHTS="1")
+    check_equal(two, one, 4096)
+    assert list(two[0]["kinds"]) == ["dense"] * 3
 
 
 @pytest.mark.gpu

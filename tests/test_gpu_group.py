@@ -42,7 +42,31 @@ def test_group_equals_one_engine(orc, engine_mod, spielberg, shards, mode):
         np.testing.assert_allclose(grp.get_weights(), one.get_weights(), rtol=1e-13, atol=0, err_msg=f"update {k}")
         np.testing.assert_allclose(grp.expected_pose(), one.expected_pose(), rtol=0, atol=1e-12)
     xb = grp.exchange_bytes()
-    assert xb["weights_received_per_device"] == (shards - 1) * (n // shards) * 8
+    # after the first update the shards exchange their compact lists (the particles that carry weight, 44 B each) ...
+    assert xb["lists"] and xb["parent_records_from_peers"] == 0
+    assert 0 < xb["weights_received_per_device"] <= (shards - 1) * (n // shards) * 44
+    grp.close(); one.close()
+
+
+def test_group_weights_exchange_when_a_shard_has_no_list(orc, engine_mod, spielberg, monkeypatch):
+    """MCL_NO_COMPACT=1: no engine makes a list, so every update gathers the weights and reads the selected parents where they
+    live -- the exchange of a first update, kept alive over several."""
+    monkeypatch.setenv("MCL_NO_COMPACT", "1")
+    ang = orc.beam_angles(angle_step=18)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].astype(np.float32).copy()
+    n = 8192
+    one = make_engine(engine_mod, spielberg, ang, n, seed=3)
+    grp = make_group(engine_mod, spielberg, ang, n // 2, 2, seed=3)
+    monkeypatch.delenv("MCL_NO_COMPACT")
+    one.init_particles_pose((0.0, 0.0, 0.0), n)
+    grp.init_particles_pose((0.0, 0.0, 0.0), n)
+    for k in range(3):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        assert np.array_equal(grp.resample_indices(), one.resample_indices()), f"update {k}"
+        assert np.array_equal(grp.get_particles(), one.get_particles()), f"update {k}"
+    xb = grp.exchange_bytes()
+    assert not xb["lists"] and xb["weights_received_per_device"] == (n // 2) * 8
     # only children whose parent lives in another shard fetch a record across: never more than all children
     assert 0 < xb["parent_records_from_peers"] <= n * 32
     grp.close(); one.close()

@@ -253,3 +253,37 @@ def test_beam_count_multiple_of_256(orc, engine_mod, spielberg, spielberg_oracle
         got, _ = sweep_logw(engine_mod, spielberg, ang, p, obs)
     pick = np.random.default_rng(5).choice(n, 8192, replace=False)
     assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs))
+
+
+@pytest.mark.parametrize("keep_steps", [0, 1])
+def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, spielberg, spielberg_oracle, keep_steps):
+    """The uniform cloud of a global re-localisation (cpp:401-446): 1024 consecutive sorted particles cover far more cells
+    than a 256-cell window leaves room for, so most (particle, quadrant) pairs are flagged and go to the windowed far pass
+    (k_rays_skip<.., FAR> over the ordered list of flagged slots: 568-cell nibble windows, only the flagged quadrants'
+    beams).  Flagged and unflagged quadrants of one particle must add up to the oracle's sum, bit for bit."""
+    from monte_carlo_localization_amd import synth
+    ang = orc.beam_angles(angle_step=4)
+    obs = scan1081()[::4].copy()
+    n = 200000
+    p = synth.global_cloud(np.random.default_rng(5), spielberg, n)
+    p[:, :7] = np.array([[np.nan, 1e12, 0.0, -3.0, 5.0, 0.5, 0.0], [0.0, 0.0, np.inf, 2.0, -1.0, 0.5, 0.0],
+                         [0.1, 0.2, 0.3, np.nan, np.inf, 1e9, 0.0]])          # garbage rows ride along in the list
+    e = make_engine(engine_mod, spielberg, ang, n, ray_kernel=engine_mod.RAYS_SWEEP, keep_ray_steps=keep_steps)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(obs)
+    got, c = e.log_weights(), e.counters()
+    assert c["off_window_particles"] > 2048                  # kFarWindowedMin: the windowed pass took the list
+    pick = np.concatenate([np.arange(16), np.random.default_rng(6).choice(n, 6000, replace=False)])
+    T = orc.sensor_table(spielberg_oracle.max_range_px)
+    want, steps, _ = orc.eng_log_weights(spielberg_oracle, np.ascontiguousarray(p[:, pick]), ang, orc.obs_index(obs, spielberg_oracle),
+                                         orc.eng_log_table(T), want_steps=True)
+    assert np.array_equal(got[pick], want)
+    if keep_steps:
+        assert np.array_equal(e.ray_steps()[pick], steps)
+    e.close()
+    # a handful of stragglers beside a tight cloud: below the threshold, k_rays_far keeps them
+    q = tracking_cloud(np.random.default_rng(7), 70000, sig=(0.2, 0.2, 0.4))
+    q[0, :500] += 40.0
+    got2, c2 = sweep_logw(engine_mod, spielberg, ang, q, obs)
+    assert 0 < c2["off_window_particles"] < 2048
+    assert np.array_equal(got2[:2000], oracle_logw(orc, spielberg_oracle, q[:, :2000], ang, obs))
