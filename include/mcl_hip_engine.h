@@ -73,7 +73,10 @@ typedef enum {
     MCL_RAYS_SWEEP = 5            /* CELL with work items planned on the device (runs of units x wedge groups, partial
                                      sums kept by the owning lane instead of 16 atomics per particle), 256-cell
                                      mirrored windows addressed by one v_perm_b32 and the probe / per-ray code
-                                     built around gfx950's 2-cycle and 4-cycle VALU classes; ranges up to 243 px */
+                                     built around gfx950's 2-cycle and 4-cycle VALU classes; ranges up to 243 px.
+                                     (Longer ranges -- MAX_RANGE_PX up to 2047 -- run on MCL_RAYS_SKIP / MCL_RAYS_MARCH: the LDS
+                                     window of SKIP holds a particle's reach up to 281 px, beyond that its global-field path
+                                     traces every ray; same results, AUTO chooses.) */
 } mcl_ray_kernel;
 
 /* Upper bound (exclusive) on max_particles and on the particle total of a sharded set: weights are quantised to 2^-36 and
@@ -183,7 +186,8 @@ int mcl_get_stage_timings(const mcl_engine_t *h, double ms[6]);
 
 /* ---- parity / diagnostics ------------------------------------------------------------------ */
 int mcl_get_resample_indices(mcl_engine_t *h, int32_t *idx, int64_t n);      /* parents of last update */
-int mcl_get_ray_steps(mcl_engine_t *h, uint8_t *steps, size_t n);            /* N*B, needs keep_ray_steps */
+int mcl_get_ray_steps(mcl_engine_t *h, uint8_t *steps, size_t n);            /* N*B, needs keep_ray_steps; MAX_RANGE_PX <= 255 */
+int mcl_get_ray_steps16(mcl_engine_t *h, uint16_t *steps, size_t n);         /* the same for any range (cpp:195 has no bound) */
 int mcl_get_log_weights(mcl_engine_t *h, double *logw, int64_t n);           /* un-normalised log w   */
 /* counters of the last update: [0] rays resolved by the literal-march fallback (level 3),
  * [1] particles that did not fit the LDS window (global-memory path), [2] grid probes examined
@@ -193,7 +197,7 @@ int mcl_get_counters(mcl_engine_t *h, uint64_t out[4]);
  * particles whose weight is not zero -- after an update with many beams a few per cent of the set -- and the next
  * resampling searches and gathers from that list instead of the full CDF and record arrays (same draw: a particle with a
  * zero fixed-point weight is never selected).  n_entries: length of the list that describes the current weights, -1 when
- * there is none (more than max_particles / 8 particles carry weight, or a small update); used_by_last_update: whether the
+ * there is none (more than max_particles / 4 particles carry weight, or a small update); used_by_last_update: whether the
  * last mcl_update / staged resampling drew from a list.  MCL_NO_COMPACT=1 in the environment at mcl_create disables it. */
 int mcl_get_compact_list(const mcl_engine_t *h, int64_t *n_entries, int32_t *used_by_last_update);
 /* switches cfg.debug_count_probes on an existing engine (the next update tallies counters[2]; bench.py's untimed probe count) */

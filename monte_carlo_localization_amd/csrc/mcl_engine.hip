@@ -76,11 +76,14 @@ struct mcl_engine {
     double *d_partial = nullptr;        // k_rays_sweep: [kWedges / sweep_g][cap] partial log-weights in sorted-slot order
     size_t partial_capacity = 0;
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
-    int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), rebuilt when (n, workgroups, G) change
+    int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), planned on the device every update
+    int2 *d_centres = nullptr;          // window centre of every run of units (k_sweep_plan)
     size_t items_capacity = 0;
     int *d_nitems = nullptr;            // number of work items (written by k_sweep_plan)
     int64_t plan_n = 0;
-    double4 *d_unit_sums = nullptr;     // per unit of 1024 sorted particles: (sum px, sum py, count, -)
+    double4 *d_unit_sums = nullptr;     // per unit of the sorted order: (sum px, sum py, count, -), bounding box
+    uint32_t *d_unit_begin = nullptr;   // first slot of every unit + one (k_unit_table)
+    int *d_nunits = nullptr;            // number of units of this update's sorted order
     size_t unit_sums_capacity = 0;
     // environment knobs, read once at mcl_create (0 / negative = default)
     int64_t env_cell_min = 0, env_cell_slice = 0;
@@ -111,7 +114,7 @@ struct mcl_engine {
     uint64_t *d_ccdf = nullptr, *d_ctop = nullptr;
     uint32_t *d_cidx = nullptr;
     double4 *d_crec = nullptr;
-    int64_t compact_cap = 0;            // room in the list (cap / 8, at least 4096)
+    int64_t compact_cap = 0;            // room in the list (cap / 4, at least 4096)
     int64_t compact_n = -1;             // entries of the list that describes d_cdf / the current particles; -1: none
     bool compact_pending = false;       // the last scan wrote a list; its length arrives with the next result read-back
     bool compact_used = false;          // the last resampling drew from a compact list
@@ -490,20 +493,24 @@ void unpack_result(mcl_engine *h)
 
 // Work items of k_rays_sweep: made on the device from this update's unit statistics (k_sweep_plan, mcl_rays_sweep.h);
 // the host only sizes the list (every unit on its own, once per wedge group, is the longest it can get).
+// upper bound on the units of n sorted particles: the plain grid plus one cut per map tile (mcl::k_unit_table)
+int64_t max_sweep_units(int64_t n) { return (n + mcl::kSwUnit - 1) / mcl::kSwUnit + mcl::kSortMaxTiles + 2; }
+
 int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
 {
     const int ngroups = mcl::kWedges / g;
-    const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
-    const size_t need = (size_t)M * ngroups;
+    const size_t need = (size_t)max_sweep_units(n) * ngroups;
     if (need > h->items_capacity) {
-        dfree(h->d_items);
+        dfree(h->d_items); dfree(h->d_centres);
+        h->items_capacity = 0;
         HIPCHK(h, hipMalloc(&h->d_items, need * sizeof(int4)));
+        HIPCHK(h, hipMalloc(&h->d_centres, (size_t)max_sweep_units(n) * sizeof(int2)));
         h->items_capacity = need;
     }
     if (!h->d_nitems) HIPCHK(h, hipMalloc(&h->d_nitems, sizeof(int)));
     const int play = mcl::kSwSide - (h->P + 2) - 3;                     // cells a window leaves for the particles of an item
-    hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), 0, h->stream, h->d_unit_sums, (int)M, ngroups, nwg, (double)(play / 2 - 1),
-                       h->d_items, h->d_nitems);
+    hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), 0, h->stream, h->d_unit_sums, h->d_nunits, ngroups, nwg, (double)(play / 2 - 1),
+                       h->d_items, h->d_centres, h->d_nitems);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -562,7 +569,20 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         a.beam_inv_inc = span > 0.0 ? (double)(h->B - 1) / span : 0.0;
     }
     a.logw = h->d_logw;
-    a.steps = h->cfg.keep_ray_steps ? h->d_steps : nullptr;
+    if (h->cfg.keep_ray_steps) {
+        // one byte per step index up to 255 px of range, two beyond (allocated here: both the map and the beam set size it)
+        const size_t need = (size_t)h->cap * h->B * (h->P > 255 ? 2 : 1);
+        if (need > h->steps_capacity) {
+            if (h->capturing) return fail(h, MCL_ERR_HIP, "step buffer missing during capture (internal)");
+            graph_reset(h);
+            dfree(h->d_steps);
+            h->steps_capacity = 0;
+            HIPCHK(h, hipMalloc(&h->d_steps, need));
+            h->steps_capacity = need;
+        }
+        if (h->P > 255) a.steps16 = reinterpret_cast<uint16_t *>(h->d_steps);
+        else a.steps = h->d_steps;
+    }
     a.grid = h->d_grid; a.W = h->W; a.H = h->H;
     a.res = h->res; a.ox = h->ox; a.oy = h->oy;
     if (direct_table) { a.Ldirect = h->d_L; a.obs_idx = h->d_obs_idx; }       // small updates: no per-update table (do_update)
@@ -650,8 +670,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over; clr.exact_count = h->d_result + 14;
             if (sweep) clr.far_count = h->d_result + 15;
             if (cell) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
-            hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
-                               h->res, h->d_pc, h->d_angle, h->B, cell ? (short4 *)nullptr : h->d_qr, clr);
+            if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
+                clr.logw_acc = nullptr; clr.far_flags = nullptr;
+                hipLaunchKernelGGL(mcl::k_prep_small, dim3(1), dim3(256), 0, h->stream, clr);
+            } else {
+                hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
+                                   h->res, h->d_pc, h->d_angle, h->B, cell ? (short4 *)nullptr : h->d_qr, clr);
+            }
         }
         if (cell) {
             // order the particles by (tile, cell, heading): bounding box -> bucket histogram (the atomic's return value
@@ -673,14 +698,25 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
             hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_skey, h->d_srank,
                                h->d_hist, h->d_pcs, h->d_ths, h->d_perm);
+            if (sweep) {
+                // units of the sorted order (cut at tile borders when the set is ordered by whole tiles), from the bucket
+                // offsets the scatter has just used -- before they are cleared
+                const size_t mu = (size_t)max_sweep_units(n);
+                if (mu > h->unit_sums_capacity) {
+                    dfree(h->d_unit_sums); dfree(h->d_unit_begin);
+                    h->unit_sums_capacity = 0;
+                    HIPCHK(h, hipMalloc(&h->d_unit_sums, mu * 2 * sizeof(double4)));
+                    HIPCHK(h, hipMalloc(&h->d_unit_begin, (mu + 1) * sizeof(uint32_t)));
+                    h->unit_sums_capacity = mu;
+                }
+                if (!h->d_nunits) HIPCHK(h, hipMalloc(&h->d_nunits, sizeof(int)));
+                hipLaunchKernelGGL(mcl::k_unit_table, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, n, h->d_hist, h->d_histpart, h->d_tile_used,
+                                   h->d_unit_begin, h->d_nunits, (int)mu);
+            }
             hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
             if (sweep) {
-                if ((size_t)nsl > h->unit_sums_capacity) {
-                    dfree(h->d_unit_sums);
-                    HIPCHK(h, hipMalloc(&h->d_unit_sums, (size_t)nsl * 2 * sizeof(double4)));
-                    h->unit_sums_capacity = nsl;
-                }
-                hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)nsl), dim3(256), 0, h->stream, h->d_pcs, n, h->d_unit_sums);
+                hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)max_sweep_units(n)), dim3(256), 0, h->stream, h->d_pcs, h->d_unit_begin, h->d_nunits,
+                                   h->d_unit_sums);
             } else {
                 if ((size_t)nsl > h->slice_mean_capacity) {
                     dfree(h->d_slice_mean);
@@ -704,7 +740,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
             if (rc_plan) return rc_plan;
             a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
-            a.items = h->d_items; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.slot_space = 1;
+            a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
                 HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
                 HIPCHK(h, hipMalloc(&h->d_far_sorted, (size_t)h->cap * sizeof(uint32_t)));
@@ -823,8 +859,8 @@ int sensor_and_weights(mcl_engine *h, const double *d_global_max)
     if (h->cfg.weight_mode == MCL_WEIGHT_PRODUCT) {
         if (!h->cfg.keep_ray_steps) return fail(h, MCL_ERR_UNSUPPORTED, "weight_mode PRODUCT needs keep_ray_steps");
         int64_t n = h->N;
-        hipLaunchKernelGGL(mcl::k_product_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_steps,
-                           h->d_obs_idx, n, h->B, h->d_table, h->P + 1, 1.0 / h->cfg.squash_factor, h->d_w);
+        hipLaunchKernelGGL(mcl::k_product_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->P > 255 ? (const uint8_t *)nullptr : h->d_steps,
+                           h->P > 255 ? reinterpret_cast<const uint16_t *>(h->d_steps) : (const uint16_t *)nullptr, h->d_obs_idx, n, h->B, h->d_table, h->P + 1, 1.0 / h->cfg.squash_factor, h->d_w);
         HIPCHK(h, hipGetLastError());
         return weight_stats(h, false, nullptr);
     }
@@ -951,7 +987,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     h->blocktot_capacity = (size_t)h->cap / mcl::kScanTile + 2;
     CRT(hipMalloc(&h->d_blocktot, h->blocktot_capacity * 8));
     CRT(hipMalloc(&h->d_blockcnt, h->blocktot_capacity * 4));
-    h->compact_cap = std::max<int64_t>(4096, ((h->cap / 8 + 63) / 64) * 64);
+    h->compact_cap = std::max<int64_t>(4096, ((h->cap / 4 + 63) / 64) * 64);
     CRT(hipMalloc(&h->d_ccdf, (size_t)h->compact_cap * 8));
     CRT(hipMalloc(&h->d_ctop, ((size_t)h->compact_cap / 64 + 1) * 8));
     CRT(hipMalloc(&h->d_cidx, (size_t)h->compact_cap * 4));
@@ -1028,7 +1064,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1046,7 +1082,9 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const double res = (double)resolution;                    // cpp:191
     const int P = (int)(h->cfg.max_range_m / res);            // cpp:195
-    if (P < 1 || P > 255) return fail(h, MCL_ERR_UNSUPPORTED, "MAX_RANGE_PX must be in [1,255] (step indices are bytes)");
+    // cpp:195 has no bound; the engine's tables are (P + 1)^2 doubles and its step indices 16 bits.  Up to 243 px the windowed
+    // kernels apply, up to 281 px k_rays_skip's LDS window, beyond that k_rays_skip's global-field path (same results)
+    if (P < 1 || P > 2047) return fail(h, MCL_ERR_UNSUPPORTED, "MAX_RANGE_PX must be in [1, 2047]");
     h->W = (int)width; h->H = (int)height; h->P = P;
     h->res = res; h->ox = origin_x; h->oy = origin_y;
     h->Wp = h->W + 1; h->Hp = h->H + 1; h->Wps = (h->Wp + 7) & ~7;
@@ -1179,14 +1217,6 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     HIPCHK(h, hipMemcpy(h->d_angle, angles, (size_t)n_beams * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)ncs * sizeof(double2), hipMemcpyHostToDevice));
     h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd); h->ltd_ready = false;
-    if (h->cfg.keep_ray_steps) {
-        size_t need = (size_t)h->cap * n_beams;
-        if (need > h->steps_capacity) {
-            dfree(h->d_steps);
-            HIPCHK(h, hipMalloc(&h->d_steps, need));
-            h->steps_capacity = need;
-        }
-    }
     h->B = n_beams;
     return MCL_OK;
 }
@@ -1434,10 +1464,15 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
             stage_observation(h, obs, obs_stride);
             a.obs_src = h->h_obs; a.obs_idx_out = h->d_obs_idx; a.obs_B = h->B; a.obs_P = h->P; a.res = h->res;
         }
-        if (choose_ray_mode(h, n, false) == 2) {
-            // k_rays_skip follows: its per-particle constants come out of this kernel (one launch less per small update)
-            a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
-            h->pc_ready = true;
+        {
+            // the ray stage's per-particle constants come out of this kernel (k_rays_skip: one launch less per small update;
+            // k_rays_cell / k_rays_sweep: also the per-particle scratch their stage wants zeroed, a pass over the children less)
+            const int rmode = choose_ray_mode(h, n, false);
+            if (rmode == 2 || rmode >= 4) {
+                a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
+                if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
+                h->pc_ready = true;
+            }
         }
         size_t cdf_lds = 0;
         if (!a.tile_excl && a.do_resample && n <= mcl::kTinyTailMax) { a.cdf_lds_entries = (int)n; cdf_lds = (size_t)n * sizeof(uint64_t); }
@@ -1642,11 +1677,31 @@ int mcl_get_ray_steps(mcl_engine_t *h, uint8_t *steps, size_t n)
 {
     if (!h || !steps) return MCL_ERR_INVALID_ARG;
     if (!h->cfg.keep_ray_steps) return fail(h, MCL_ERR_UNSUPPORTED, "engine created without keep_ray_steps");
+    if (h->P > 255) return fail(h, MCL_ERR_UNSUPPORTED, "MAX_RANGE_PX > 255: step indices do not fit bytes, use mcl_get_ray_steps16");
     if (!h->have_steps) return MCL_ERR_NOT_READY;
     if (n != (size_t)h->N * h->B) return MCL_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(steps, h->d_steps, n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+}
+
+int mcl_get_ray_steps16(mcl_engine_t *h, uint16_t *steps, size_t n)
+{
+    if (!h || !steps) return MCL_ERR_INVALID_ARG;
+    if (!h->cfg.keep_ray_steps) return fail(h, MCL_ERR_UNSUPPORTED, "engine created without keep_ray_steps");
+    if (!h->have_steps) return MCL_ERR_NOT_READY;
+    if (n != (size_t)h->N * h->B) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->P > 255) {
+        HIPCHK(h, hipMemcpyAsync(steps, h->d_steps, n * 2, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        std::vector<uint8_t> b(n);
+        HIPCHK(h, hipMemcpyAsync(b.data(), h->d_steps, n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (size_t k = 0; k < n; ++k) steps[k] = b[k];
+    }
     return MCL_OK;
 }
 

@@ -221,6 +221,8 @@ struct ResampleArgs {
     // small updates (one launch less each): the per-particle constants k_particle_prep would compute, the CDF staged in
     // LDS (cdf_lds_entries = n_parents when the launch has n_parents * 8 bytes of dynamic LDS, else 0), counters to zero
     double4 *pc_out;                  // (cos, sin, pixel x, pixel y) per child, or null
+    double *clr_logw_acc;             // with pc_out, for the windowed ray kernels: the per-particle scratch k_particle_prep
+    uint32_t *clr_far_flags;          //   would zero (the launch then needs k_prep_small only), or null
     double ox, oy, res;
     int cdf_lds_entries;
     unsigned long long *clear_counters;   // 4 words zeroed by the first thread, or null
@@ -428,6 +430,8 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
     if (a.cpack) a.cpack[m] = make_double4(x, y, th, 0.0);
     if (a.pc_out) a.pc_out[m] = particle_constants(x, y, th, a.ox, a.oy, a.res);
+    if (a.clr_logw_acc) a.clr_logw_acc[m] = 0.0;
+    if (a.clr_far_flags) a.clr_far_flags[m] = 0u;
 }
 
 // The shards' compact lists, gathered as chunks ([ccdf | crec | cidx], ccap entries each), become ONE searchable CDF: chunk r's
@@ -630,10 +634,12 @@ struct RayArgs {
     int ltd_cols;
     double *part;                  // k_rays_sweep: [kWedges / sweep_g][n] partial log-weights in sorted-slot order
     int sweep_g;                   // k_rays_sweep: wedges per work item
-    const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, -), big first (guided schedule)
+    const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, run), big first (guided schedule)
+    const int2 *centres;           // k_rays_sweep: window centre (padded cell) of every run, k_sweep_plan
     int nitems;
     const int *nitems_ptr;          // k_rays_sweep: number of work items, written by k_sweep_plan
-    const double4 *unit_sums;      // k_rays_sweep: per unit of kSwUnit sorted particles (sum px, sum py, count, -), k_slice_means
+    const double4 *unit_sums;      // k_rays_sweep: per unit of the sorted order (sum px, sum py, count, -) and its bounding box, k_unit_sums
+    const uint32_t *unit_begin;    // k_rays_sweep: first slot of every unit, one entry past the last (k_unit_table)
     uint32_t *far_list;            // k_rays_sweep -> k_rays_far: slots with at least one flagged quadrant (appended once each), or null
     unsigned long long *far_count; // entries in far_list
     const uint32_t *far_sorted;    // k_rays_skip<.., FAR>: the flagged slots in ascending (= spatial) order, k_far_scatter
@@ -643,6 +649,7 @@ struct RayArgs {
                                    // per-particle constants of k_rays_fix / k_rays_far come from pcs / ths; perm gives the particle
     double *logw;                  // out
     uint8_t *steps;                // out N*B or null
+    uint16_t *steps16;             // the same as 16-bit entries, for maps whose range exceeds 255 px (k_rays_march / k_rays_skip)
     // map
     const int8_t *grid; int W, H;
     double res, ox, oy;
@@ -673,6 +680,13 @@ __device__ __forceinline__ int march_exact(const RayArgs &a, double x, double y,
         if (a.grid[(size_t)gy * a.W + gx] > 50) return step;
     }
     return a.P;
+}
+
+// step index of ray (i, j) to whichever output the launch has
+__device__ __forceinline__ void store_step(const RayArgs &a, int64_t i, int j, int r)
+{
+    if (a.steps16) a.steps16[(size_t)i * a.B + j] = (uint16_t)r;
+    else if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
 }
 
 constexpr int kRayThreads = 1024;
@@ -745,6 +759,18 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     if (qr) qr[i] = quadrant_ranges_of(t, t == t && fabs(t) < 1e6, beam_angle, B);
 }
 
+// the few words of k_particle_prep's clearing that are not per particle: what is left to do when the resampling kernel has
+// already written the constants and zeroed the per-particle scratch
+__global__ __launch_bounds__(256) void k_prep_small(PrepClear clr)
+{
+    const int i = threadIdx.x;
+    if (clr.fix_count) for (int k = i; k < clr.fix_words; k += 256) clr.fix_count[k] = 0ull;
+    if (clr.fix_over && i < 2) clr.fix_over[i] = 0ull;
+    if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
+    if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
+    if (clr.bbox && i < 6) clr.bbox[i] = i < 2 ? 0x7fffffff : (i < 4 ? (int)0x80000000 : 0);
+}
+
 // D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
 __device__ __forceinline__ uint32_t mad_i24(int a, int b, uint32_t c)
 {
@@ -793,7 +819,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_march(RayArgs a)
             if (j < a.B) {
                 int r = march_exact(a, x, y, th + (double)a.beam_angle[j]);   // cpp:533
                 acc += (double)a.Lt[(size_t)r * a.bpad + j];
-                if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                store_step(a, i, j, r);
                 if (COUNT) cnt_probe += (r < a.P) ? (r + 1) : a.P;
             }
         }
@@ -898,23 +924,33 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     const int tw = a.P + 1;
     int wx0, wy0;
     {
-        // ---- window placement: centred on the mean padded-pixel position of this slice ----
+        // ---- window placement: centred on the mean padded-pixel position of this slice (FAR: on the centre of its bounding
+        //      box -- a slice that straddles two neighbouring tiles, 64 x 32 cells, then fits the play as a whole) ----
         double *red = reinterpret_cast<double *>(lds_raw);   // scratch, overwritten by the window below
-        double sx = 0.0, sy = 0.0, sc = 0.0;
+        double sx = 0.0, sy = 0.0, bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
         for (int64_t i = p_begin + threadIdx.x; i < p_end; i += kRayThreads) {
             double4 c = FAR ? a.pcs[a.far_sorted[i]] : a.pc[i];
             double gx = c.z, gy = c.w;
-            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) { sx += gx; sy += gy; sc += 1.0; }
+            if (gx == gx && gy == gy && fabs(gx) < 1e9 && fabs(gy) < 1e9) {
+                sx += gx; sy += gy;
+                if (FAR) { bx0 = fmin(bx0, gx); bx1 = fmax(bx1, gx); by0 = fmin(by0, gy); by1 = fmax(by1, gy); }
+            }
         }
-        sx = wave_sum(sx); sy = wave_sum(sy); sc = wave_sum(sc);
-        if (lane == 0) { red[3 * wave] = sx; red[3 * wave + 1] = sy; red[3 * wave + 2] = sc; }
-        __syncthreads();
-        double mx = 0.0, my = 0.0, mc = 0.0;
-        for (int k = 0; k < kRayWaves; ++k) { mx += red[3 * k]; my += red[3 * k + 1]; mc += red[3 * k + 2]; }
-        // the mean over the slice (FAR: over its finite positions; the plain kernel keeps dividing by the slice length,
-        // which is what its results -- not their values, the off-window counter -- were recorded with)
-        const double cntp = FAR ? mc : (double)(p_end - p_begin);
-        if (cntp > 0.0) { mx /= cntp; my /= cntp; }
+        double mx = 0.0, my = 0.0;
+        if (FAR) {
+            bx0 = -wave_max(-bx0); bx1 = wave_max(bx1); by0 = -wave_max(-by0); by1 = wave_max(by1);
+            if (lane == 0) { red[4 * wave] = bx0; red[4 * wave + 1] = bx1; red[4 * wave + 2] = by0; red[4 * wave + 3] = by1; }
+            __syncthreads();
+            for (int k = 0; k < kRayWaves; ++k) { bx0 = fmin(bx0, red[4 * k]); bx1 = fmax(bx1, red[4 * k + 1]); by0 = fmin(by0, red[4 * k + 2]); by1 = fmax(by1, red[4 * k + 3]); }
+            if (bx1 >= bx0) { mx = 0.5 * (bx0 + bx1); my = 0.5 * (by0 + by1); }
+        } else {
+            sx = wave_sum(sx); sy = wave_sum(sy);
+            if (lane == 0) { red[2 * wave] = sx; red[2 * wave + 1] = sy; }
+            __syncthreads();
+            for (int k = 0; k < kRayWaves; ++k) { mx += red[2 * k]; my += red[2 * k + 1]; }
+            int64_t cntp = p_end - p_begin;
+            if (cntp > 0) { mx /= (double)cntp; my /= (double)cntp; }
+        }
         wx0 = (((int)floor(mx) + 1 - TW / 2)) & ~7;      // padded coordinate = global + 1
         wy0 = (int)floor(my) + 1 - TW / 2;
         __syncthreads();
@@ -946,7 +982,9 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     const int ngroups = (a.B + 64 * R - 1) / (64 * R);
     // the level-1 loop addresses the window with raw LDS offsets: the dynamic segment must start at 0
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != 0u) __builtin_trap();
-    uint32_t strideB_v = (uint32_t)strideB, gbias_v = kG1 << (32 - kFx);
+    // level-1 error bound: (1 + s) / 2 units for s <= P samples (+ 4 of slack); kG1 covers the byte ranges
+    const uint32_t g1 = (uint32_t)a.P > 255u ? (uint32_t)(a.P + 2) / 2u + 4u : kG1;
+    uint32_t strideB_v = (uint32_t)strideB, gbias_v = g1 << (32 - kFx);
     asm volatile("" : "+v"(strideB_v), "+v"(gbias_v));   // keep both in VGPRs across the loop
 
     for (int64_t ii = p_begin + wave; ii < p_end; ii += kRayWaves) {
@@ -1070,7 +1108,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                         // R == 1: rem was decremented once more after an overshoot; only the stop case reads it
                         int r = (n[k] == 0) ? a.P - rem[k] - 1 : a.P;
                         if (COUNT) ++cnt_probe;
-                        if (g[k] < ((2u * kG1) << (32 - kFx)) || a.force_exact) {
+                        if (g[k] < ((2u * g1) << (32 - kFx)) || a.force_exact) {
                             // ---- level 2 (and 3): rare, everything recomputed from scratch ----
                             double2 cs = a.beam_cs[j];
                             double ux = cth * cs.x - sth * cs.y;
@@ -1086,7 +1124,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                             }
                         }
                         acc += a.Ldirect ? (double)a.Ldirect[(size_t)a.obs_idx[j] * tw + r] : (double)a.Lt[(size_t)r * a.bpad + j];
-                        if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                        store_step(a, i, j, r);
                     }
                 }
             }
@@ -1113,7 +1151,7 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
                         ++cnt_exact;
                     }
                     acc += a.Ldirect ? (double)a.Ldirect[(size_t)a.obs_idx[j] * tw + r] : (double)a.Lt[(size_t)r * a.bpad + j];
-                    if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                    store_step(a, i, j, r);
                     if (COUNT) cnt_probe += np;
                 }
             }
@@ -1510,18 +1548,28 @@ __global__ __launch_bounds__(1024) void k_tile_compact(int *__restrict__ bbox, i
 }
 
 constexpr int kSortMaxSub = MCL_SORT_MAX_SUB;        // sub-cell bits per axis a dense set may get (0: none)
-__device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const int *__restrict__ tilemap, int ntx_abs, int cx, int cy, double th,
-                                         int64_t n, double fx = 0.0, double fy = 0.0)
+// How the key bits are split for this update's set: a pure function of the bounding box / occupied-tile count and n, so that
+// every particle -- and k_unit_table, which needs to know where a tile's keys start -- derives the same layout.
+//   key = ((((tile << inner | iy) << inner | ix) << ss | sy) << ss | sx) << tb | heading bin
+struct SortLayout {
+    int cs, tb, inner, ss;
+    uint32_t ntx;
+    int tx0, ty0;
+    bool compact;
+    uint64_t ntiles;
+    __device__ __forceinline__ int tile_shift() const { return 2 * inner + 2 * ss + tb; }
+};
+__device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, int64_t n)
 {
-    cx = cx < bbox[0] ? bbox[0] : (cx > bbox[2] ? bbox[2] : cx);
-    cy = cy < bbox[1] ? bbox[1] : (cy > bbox[3] ? bbox[3] : cy);
-    const int tx0 = bbox[0] >> 5, ty0 = bbox[1] >> 5;
-    const uint32_t ntx = (uint32_t)((bbox[2] >> 5) - tx0 + 1), nty = (uint32_t)((bbox[3] >> 5) - ty0 + 1);
-    const bool compact = bbox[5] != 0;
-    const uint64_t ntiles = compact ? (uint64_t)bbox[4] + 1u : (uint64_t)ntx * nty;       // + 1: the overflow tile
+    SortLayout L;
+    L.tx0 = bbox[0] >> 5; L.ty0 = bbox[1] >> 5;
+    L.ntx = (uint32_t)((bbox[2] >> 5) - L.tx0 + 1);
+    const uint32_t nty = (uint32_t)((bbox[3] >> 5) - L.ty0 + 1);
+    L.compact = bbox[5] != 0;
+    L.ntiles = L.compact ? (uint64_t)bbox[4] + 1u : (uint64_t)L.ntx * nty;       // + 1: the overflow tile
     // cells the set can be taken to live on: its bounding box, or its occupied tiles if that is less
     double cells_est = (double)(bbox[2] - bbox[0] + 1) * (double)(bbox[3] - bbox[1] + 1);
-    if (compact && (double)bbox[4] * 1024.0 < cells_est) cells_est = (double)bbox[4] * 1024.0;
+    if (L.compact && (double)bbox[4] * 1024.0 < cells_est) cells_est = (double)bbox[4] * 1024.0;
     // Heading first: the lanes of a wave must agree on which wedge their beams are in, so six heading bits (5.6 degrees)
     // are kept while the in-tile resolution is coarsened to make room (a particle set spread over a large bounding box
     // -- several far-apart clusters -- otherwise spends the whole key space on empty cells: 80 % slower ray stage);
@@ -1533,15 +1581,11 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const
     // compactness of a unit is what the windows and the probe loop live on (coarser buckets cost 4-30 %).
     int cs = 0, tb = 6;
     if (cells_est > 0.0 && (double)n < 8.0 * cells_est) cs = 5;
-    while (cs < 5 && ((ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) ++cs;
-    while (tb > 0 && ((ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) --tb;
+    while (cs < 5 && ((L.ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) ++cs;
+    while (tb > 0 && ((L.ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) --tb;
     const int inner = 5 - cs;                             // log2 of the bucket grid inside one tile
-    uint64_t ncell = ntiles << (2 * inner);
+    const uint64_t ncell = L.ntiles << (2 * inner);
     while (tb < 8 && (ncell << (tb + 1)) <= kSortKeySpace) ++tb;
-    uint32_t tile = (uint32_t)((cy >> 5) - ty0) * ntx + (uint32_t)((cx >> 5) - tx0);
-    if (compact) tile = (uint32_t)tilemap[(cy >> 5) * ntx_abs + (cx >> 5)];
-    const uint32_t ix = (uint32_t)(cx & 31) >> cs, iy = (uint32_t)(cy & 31) >> cs;
-    uint64_t key = ((((uint64_t)tile << inner) | iy) << inner) | ix;
     // Bits left over once the cells have their full resolution and the heading its eight bits go to the position inside
     // the cell (half cells, then quarter cells): a collapsed set is thousands of particles per cell, and rays that start
     // within half a cell of each other keep company longer (levine stand-in: ray kernel -10 %, Spielberg -3 %).
@@ -1552,6 +1596,21 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const
         double per_bucket = cells_est > 0.0 ? (double)n / cells_est / 32.0 : 0.0;
         while (ss < kSortMaxSub && (ncell << (tb + 2 * (ss + 1))) <= kSortKeySpace && per_bucket >= 4.0 * 8.0) { ++ss; per_bucket *= 0.25; }
     }
+    L.cs = cs; L.tb = tb; L.inner = inner; L.ss = ss;
+    return L;
+}
+
+__device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const int *__restrict__ tilemap, int ntx_abs, int cx, int cy, double th,
+                                         int64_t n, double fx = 0.0, double fy = 0.0)
+{
+    cx = cx < bbox[0] ? bbox[0] : (cx > bbox[2] ? bbox[2] : cx);
+    cy = cy < bbox[1] ? bbox[1] : (cy > bbox[3] ? bbox[3] : cy);
+    const SortLayout L = sort_layout(bbox, n);
+    const int cs = L.cs, tb = L.tb, inner = L.inner, ss = L.ss;
+    uint32_t tile = (uint32_t)((cy >> 5) - L.ty0) * L.ntx + (uint32_t)((cx >> 5) - L.tx0);
+    if (L.compact) tile = (uint32_t)tilemap[(cy >> 5) * ntx_abs + (cx >> 5)];
+    const uint32_t ix = (uint32_t)(cx & 31) >> cs, iy = (uint32_t)(cy & 31) >> cs;
+    uint64_t key = ((((uint64_t)tile << inner) | iy) << inner) | ix;
     if (ss > 0) {
         const uint32_t sx = (fx >= 0.0 && fx < 1.0) ? (uint32_t)(fx * (double)(1 << ss)) : 0u;
         const uint32_t sy = (fy >= 0.0 && fy < 1.0) ? (uint32_t)(fy * (double)(1 << ss)) : 0u;
@@ -2319,14 +2378,14 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
 
 // product-as-reference weights (cpp:566-578) from materialised steps: one thread per particle,
 // sequential double product in beam order, then pow(.,inv_squash).
-__global__ void k_product_weights(const uint8_t *__restrict__ steps, const int32_t *__restrict__ obs_idx, int64_t n, int B,
+__global__ void k_product_weights(const uint8_t *__restrict__ steps, const uint16_t *__restrict__ steps16, const int32_t *__restrict__ obs_idx, int64_t n, int B,
                                   const double *__restrict__ table /* col-major (P+1)^2 */, int tw, double inv_squash,
                                   double *__restrict__ w_out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double w = 1.0;
-    for (int j = 0; j < B; ++j) w *= table[(size_t)steps[(size_t)i * B + j] * tw + obs_idx[j]];
+    for (int j = 0; j < B; ++j) w *= table[(size_t)(steps16 ? (int)steps16[(size_t)i * B + j] : (int)steps[(size_t)i * B + j]) * tw + obs_idx[j]];
     w_out[i] = pow(w, inv_squash);
 }
 

@@ -54,14 +54,74 @@ __global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restri
     Ltd[(size_t)r * cols + j] = v;
 }
 
-// Per unit of kSwUnit sorted particles, over its finite positions: out[2u] = (sum of pixel x, sum of pixel y, count, -) and
-// out[2u + 1] = (min x, max x, min y, max y).  A work item centres its windows on the mean over its units; k_sweep_plan
+// Units of the sorted order: at most kSwUnit consecutive slots each, ub[u] = first slot of unit u, ub[M] = n, *m_out = M.
+// A set ordered by whole map tiles (SortLayout: one group of heading buckets per 32 x 32-cell tile -- the sparse cloud of a
+// global re-localisation) is cut at the tile borders as well: the particles of a unit then lie within ONE tile, which the
+// play of a window covers at ranges up to 256 - 35 - 5 = 216 px, where a unit that straddles two tiles (64 x 32 cells or
+// worse) loses its minority side to the far pass.  Any other set gets the plain grid of kSwUnit slots.
+// hist: the bucket offsets k_hist_final left (copy of XCD 0 = the first slot of a bucket), part: the exclusive prefix of the
+// histogram tiles' totals (the offset of every bucket of a tile nobody fell into).  One workgroup.
+__global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbox, int64_t n, const uint32_t *__restrict__ hist,
+                                                    const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_used,
+                                                    uint32_t *__restrict__ ub, int *__restrict__ m_out, int max_units)
+{
+    __shared__ uint32_t ws[16];
+    __shared__ uint32_t carry_sh;
+    const SortLayout L = sort_layout(bbox, n);
+    const int shift = L.tile_shift();
+    const bool tilecut = L.compact && shift <= 12 && (int64_t)L.ntiles <= (int64_t)kSortMaxTiles + 1 && (L.ntiles << shift) <= kSortKeySpace;
+    const int64_t Mgrid = (n + kSwUnit - 1) / kSwUnit;
+    if (!tilecut) {
+        for (int64_t u = threadIdx.x; u <= Mgrid; u += 1024) ub[u] = (uint32_t)(u * kSwUnit < n ? u * kSwUnit : n);
+        if (threadIdx.x == 0) m_out[0] = (int)Mgrid;
+        return;
+    }
+    static_assert(kHistTile == 4096, "a map tile's buckets (at most 2^12) lie inside one histogram tile");
+    const int ntl = (int)L.ntiles;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_sh = 0u;
+    __syncthreads();
+    auto start_of = [&](int t) -> uint32_t {
+        if (t >= ntl) return (uint32_t)n;
+        const uint32_t key0 = (uint32_t)t << shift;
+        return tile_used[key0 >> 12] ? hist[key0] : part[key0 >> 12];
+    };
+    for (int t0 = 0; t0 < ntl; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        uint32_t s0 = 0, cnt = 0;
+        if (t < ntl) { s0 = start_of(t); const uint32_t s1 = start_of(t + 1); cnt = s1 > s0 ? s1 - s0 : 0u; }
+        const uint32_t nu = (cnt + kSwUnit - 1) / kSwUnit;
+        uint32_t inc = nu;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        uint32_t at = carry_sh + inc - nu;
+        for (int k = 0; k < wv; ++k) at += ws[k];
+        for (uint32_t j = 0; j < nu; ++j)
+            if (at + j < (uint32_t)max_units) ub[at + j] = s0 + j * kSwUnit;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = at + nu;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int M = (int)carry_sh;
+        if (M > max_units) M = max_units;                  // cannot happen: max_units = ceil(n / kSwUnit) + tiles (never write out of bounds)
+        ub[M] = (uint32_t)n;
+        m_out[0] = M;
+    }
+}
+
+// Per unit of the sorted order, over its finite positions: out[2u] = (sum of pixel x, sum of pixel y, count, -) and
+// out[2u + 1] = (min x, max x, min y, max y).  A work item centres its windows on the bounding box of its units; k_sweep_plan
 // joins neighbouring units into one item while their particles still fit one window.
-__global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ pcs, int64_t n, double4 *__restrict__ out)
+__global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ pcs, const uint32_t *__restrict__ ub, const int *__restrict__ m_ptr,
+                                                  double4 *__restrict__ out)
 {
     __shared__ double sm[4][7];
-    const int64_t p_begin = (int64_t)blockIdx.x * kSwUnit;
-    const int64_t p_end = (p_begin + kSwUnit < n) ? p_begin + kSwUnit : n;
+    if ((int)blockIdx.x >= m_ptr[0]) return;
+    const int64_t p_begin = (int64_t)ub[blockIdx.x];
+    const int64_t p_end = (int64_t)ub[blockIdx.x + 1];
     double sx = 0.0, sy = 0.0, cnt = 0.0, x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
     for (int64_t s = p_begin + threadIdx.x; s < p_end; s += blockDim.x) {
         const double4 c = pcs[s];
@@ -87,14 +147,15 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
 // the run length the guided schedule wants there (long runs while plenty of work is left -- fewer window loads and fewer
 // workgroup barriers per particle --, single units for the last third, so that the persistent workgroups finish within
 // one small item of each other) is halved until the particles of every run fit one window (`half_play` cells either side of
-// the run's mean position, both axes; a sparse cloud or a long range thus gets shorter runs instead of off-window
+// the centre of the run's bounding box, both axes; a sparse cloud or a long range thus gets shorter runs instead of off-window
 // particles).  Every run is listed once per wedge group.  One workgroup; items come out in unit order.
 constexpr int kSwRunMax = 8;
-__global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, int M, int ngroups, int nwg, double half_play,
-                                                    int4 *__restrict__ items, int *__restrict__ nitems_out)
+__global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, const int *__restrict__ m_ptr, int ngroups, int nwg, double half_play,
+                                                    int4 *__restrict__ items, int2 *__restrict__ centres, int *__restrict__ nitems_out)
 {
     __shared__ int wave_tot[16];
     __shared__ int carry_sh;
+    const int M = m_ptr[0];                   // units of this update's sorted order (k_unit_table)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
@@ -118,16 +179,14 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
                     const int avail = (u0 + k + cc <= M) ? cc : M - (u0 + k);
                     bool fits = true;
                     if (cc > 1) {
-                        double sx = 0.0, sy = 0.0, cnt = 0.0, x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+                        // the windows of a run are centred on the bounding box of its particles: they fit when the box is
+                        // narrower than the play on both axes
+                        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
                         for (int j = 0; j < avail; ++j) {
-                            const double4 s4 = unit_stats[2 * (size_t)(u0 + k + j)], bb = unit_stats[2 * (size_t)(u0 + k + j) + 1];
-                            sx += s4.x; sy += s4.y; cnt += s4.z;
+                            const double4 bb = unit_stats[2 * (size_t)(u0 + k + j) + 1];
                             x0 = fmin(x0, bb.x); x1 = fmax(x1, bb.y); y0 = fmin(y0, bb.z); y1 = fmax(y1, bb.w);
                         }
-                        if (cnt > 0.0) {
-                            const double mx = sx / cnt, my = sy / cnt;
-                            fits = (x1 - mx) < half_play && (mx - x0) < half_play && (y1 - my) < half_play && (my - y0) < half_play;
-                        }
+                        if (x1 >= x0) fits = 0.5 * (x1 - x0) < half_play && 0.5 * (y1 - y0) < half_play;
                     }
                     if (fits || cc == 1) { len[k] = avail; ++nruns; k += cc; }
                     else cc >>= 1;                      // try the first half; the second half is tried at the same (halved) length
@@ -146,7 +205,15 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
 #pragma unroll
             for (int k = 0; k < kSwRunMax; ++k)
                 if (len[k] > 0) {
-                    for (int g = 0; g < ngroups; ++g) items[(size_t)at * ngroups + g] = make_int4(u0 + k, len[k], (g + u0 + k) % ngroups, 0);
+                    // the windows of the run are centred on the bounding box of its particles (cell of the centre + 1: padded)
+                    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+                    for (int j = 0; j < len[k]; ++j) {
+                        const double4 bb = unit_stats[2 * (size_t)(u0 + k + j) + 1];
+                        x0 = fmin(x0, bb.x); x1 = fmax(x1, bb.y); y0 = fmin(y0, bb.z); y1 = fmax(y1, bb.w);
+                    }
+                    const double mx = x1 >= x0 ? 0.5 * (x0 + x1) : 0.0, my = x1 >= x0 ? 0.5 * (y0 + y1) : 0.0;
+                    centres[at] = make_int2((int)floor(mx) + 1, (int)floor(my) + 1);
+                    for (int g = 0; g < ngroups; ++g) items[(size_t)at * ngroups + g] = make_int4(u0 + k, len[k], (g + u0 + k) % ngroups, at);
                     ++at;
                 }
         }
@@ -270,16 +337,12 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // persistent workgroups finish within one small item of each other
     const int4 it = a.items[item];                                   // wave-uniform: scalar loads
     const int grp = it.z;
-    const int64_t p_begin = (int64_t)it.x * kSwUnit;
-    const int64_t p_end = (p_begin + (int64_t)it.y * kSwUnit < a.n) ? p_begin + (int64_t)it.y * kSwUnit : a.n;
+    // units are runs of the sorted order (k_unit_table); slots stay below 2^27: 32-bit slot arithmetic (registers are scarce here)
+    const uint32_t p_begin = a.unit_begin[it.x];
+    const uint32_t p_end = a.unit_begin[it.x + it.y];
     if (p_begin >= p_end) continue;
     double *part = a.part + (size_t)grp * (size_t)a.n;
-    double2 mm = make_double2(0.0, 0.0);
-    {
-        double sx = 0.0, sy = 0.0, cnt = 0.0;
-        for (int u = 0; u < it.y; ++u) { const double4 us = a.unit_sums[2 * (size_t)(it.x + u)]; sx += us.x; sy += us.y; cnt += us.z; }
-        if (cnt > 0.0) mm = make_double2(sx / cnt, sy / cnt);
-    }
+    const int2 ctr = a.centres[it.w];                                  // window centre of the run (k_sweep_plan): padded cell
     for (int gw = 0; gw < G; ++gw) {
     const int kbin = grp * G + gw;
     const int q = kbin >> kWedgeShift;
@@ -288,10 +351,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const int mlo = 3;
     int wx0, wy0;
     {
-        const double mx = mm.x, my = mm.y;
         const int E = S - (a.P + 2) - mlo;
         const int back = E / 2 + mlo;
-        int cxm = (int)floor(mx) + 1, cym = (int)floor(my) + 1;
+        const int cxm = ctr.x, cym = ctr.y;
         wx0 = sxp ? cxm - back : cxm + back - S;
         wy0 = syp ? cym - back : cym + back - S;
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
@@ -320,14 +382,11 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         __syncthreads();
     }
 
-    for (int64_t s0g = p_begin + (int64_t)wave * 64; s0g < p_end; s0g += (int64_t)kRayWaves * 64) {
-        const int64_t slot = s0g + lane;
+    for (uint32_t s0g = p_begin + (uint32_t)wave * 64u; s0g < p_end; s0g += (uint32_t)kRayWaves * 64u) {
+        const uint32_t slot = s0g + (uint32_t)lane;
         const bool have = slot < p_end;
-        const int64_t sl = have ? slot : p_end - 1;
+        const uint32_t sl = have ? slot : p_end - 1u;
         const double4 pci = a.pcs[sl];
-        // running sum of this group's earlier wedges (the same lane wrote it): requested now, needed after the walk
-        double prev = 0.0;
-        if (gw > 0 && have) prev = part[slot];
         // beams of this particle in wedge kbin: [ja, jb) and, for scans wider than a turn minus one wedge, [ja2, B)
         int ja = 0, jb = 0, ja2 = a.B;
         {
@@ -505,7 +564,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             }
             if (ambcnt > 2u) acc_fast = 0.0;
         }
-        if (have) part[slot] = prev + (acc_fast + acc);
+        // the running sum of this group's earlier wedges (the same lane wrote it)
+        if (have) part[slot] = (gw > 0 ? part[slot] : 0.0) + (acc_fast + acc);
     }
     }   // wedges of the group
     }   // work items

@@ -70,7 +70,7 @@ class ShardedFilter:
         # list exchange: every rank's list length (-1: none) and fixed-point total, known from the previous update's sums
         self.counts = None
         self.totals = None
-        self.list_cap = max(4096, ((n // 8 + 63) // 64) * 64)             # the engine's own bound on a list (max_particles / 8)
+        self.list_cap = max(4096, ((n // 4 + 63) // 64) * 64)             # the engine's own bound on a list (max_particles / 4)
         self.chunk_local = None                                           # grown on demand: one chunk / world chunks, uint8
         self.chunk_all = None
         self.pending_list = None                                          # (async all-gather of the lists, entries per chunk)

@@ -34,7 +34,7 @@ EXPORTS = [
     "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
     "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
     "mcl_set_debug_count_probes", "mcl_set_particles_shard", "mcl_get_compact_list", "mcl_compact_chunk_bytes", "mcl_export_compact",
-    "mcl_stage_resample_compact", "mcl_group_exchanged_lists",
+    "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16",
 ]
 
 
@@ -302,8 +302,13 @@ class Engine:
         return out
 
     def ray_steps(self):
-        out = np.empty(self.n * self.n_beams, np.uint8)
-        self._chk(self.lib.mcl_get_ray_steps(self._h, _p(out), C.c_size_t(out.size)), "mcl_get_ray_steps")
+        """Step index of every ray of the last update (needs keep_ray_steps): uint8 up to 255 px of range, uint16 beyond."""
+        if self.max_range_px > 255:
+            out = np.empty(self.n * self.n_beams, np.uint16)
+            self._chk(self.lib.mcl_get_ray_steps16(self._h, _p(out), C.c_size_t(out.size)), "mcl_get_ray_steps16")
+        else:
+            out = np.empty(self.n * self.n_beams, np.uint8)
+            self._chk(self.lib.mcl_get_ray_steps(self._h, _p(out), C.c_size_t(out.size)), "mcl_get_ray_steps")
         return out.reshape(self.n, self.n_beams)
 
     def log_weights(self):

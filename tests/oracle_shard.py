@@ -114,7 +114,7 @@ class OracleShard:
     # ---- compact parent lists (mcl_get_compact_list / mcl_export_compact / mcl_stage_resample_compact)
     def compact_list(self):
         alive = np.nonzero(self.q)[0]
-        cap = max(4096, (self.n // 8 + 63) // 64 * 64)
+        cap = max(4096, (self.n // 4 + 63) // 64 * 64)
         return (int(alive.size) if alive.size <= cap else -1), False
 
     def export_compact(self, d_chunk, chunk_entries):

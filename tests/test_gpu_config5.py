@@ -1,5 +1,5 @@
 """BASELINE.json configs[4] at its TOTAL: 33 554 432 particles on Spielberg_map, sharded -- here 2 x 16 777 216 on the one test
-GPU (61 beams keep an update at tens of milliseconds; the particle-count-dependent code -- the global CDF of 2^25 entries,
+GPU (361 beams keep an update at tens of milliseconds; the particle-count-dependent code -- the global CDF of 2^25 entries,
 global int32 parents, the bitmap over the global indices, the list exchange -- is what this size is for).  Both hosts of the
 sharded engine: one process per shard over torch.distributed (gloo here, RCCL in bench.py) and mcl_group_* in one process.
 Everything is compared with ONE engine holding all 33 554 432 particles, bit for bit, through checksums of 2^20-particle
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ACTION = (0.05, 0.0, 0.01)
 N_TOTAL = 33_554_432
 STEPS = 3
-BEAM_STEP = 18
+BEAM_STEP = 3                     # 361 beams: peaked enough for the list exchange (a list holds up to a quarter of the set)
 SEED = 2024                       # tests/dist_worker.py's seed
 
 

@@ -324,7 +324,7 @@ def test_compact_parent_list_equals_full_cdf(orc, engine_mod, spielberg, spielbe
         assert np.array_equal(eng["list"].log_weights(), logw)
         _, q, _ = orc.eng_weights_from_log(logw)
         alive = int(np.count_nonzero(q))
-        assert n_list == (alive if alive <= max(4096, (n // 8 + 63) // 64 * 64) else -1)
+        assert n_list == (alive if alive <= max(4096, (n // 4 + 63) // 64 * 64) else -1)
     assert times_used >= 2
     # a flat weight set (every particle carries weight) has no list: the next update draws from the full CDF again
     e = eng["list"]

@@ -273,7 +273,9 @@ def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, spielberg, sp
     e.sensor_update(obs)
     got, c = e.log_weights(), e.counters()
     assert c["off_window_particles"] > 2048                  # kFarWindowedMin: the windowed pass took the list
-    pick = np.concatenate([np.arange(16), np.random.default_rng(6).choice(n, 6000, replace=False)])
+    # (rows 0-4 are not finite: the reference's int cast of them is undefined behaviour, no common answer to compare with;
+    #  row 5's huge-but-finite heading is marched literally, like the oracle does)
+    pick = np.concatenate([np.arange(5, 16), 16 + np.random.default_rng(6).choice(n - 16, 6000, replace=False)])
     T = orc.sensor_table(spielberg_oracle.max_range_px)
     want, steps, _ = orc.eng_log_weights(spielberg_oracle, np.ascontiguousarray(p[:, pick]), ang, orc.obs_index(obs, spielberg_oracle),
                                          orc.eng_log_table(T), want_steps=True)
@@ -287,3 +289,55 @@ def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, spielberg, sp
     got2, c2 = sweep_logw(engine_mod, spielberg, ang, q, obs)
     assert 0 < c2["off_window_particles"] < 2048
     assert np.array_equal(got2[:2000], oracle_logw(orc, spielberg_oracle, q[:, :2000], ang, obs))
+
+
+def test_2p5_cm_cells_range_of_479_px(orc, engine_mod, sibal1):
+    """cpp:195 puts no bound on MAX_RANGE_PX = int(max_range / resolution): a 0.025 m map at 12 m is 479 px (the float32
+    resolution is a hair above 0.025).  The step
+    indices then need 16 bits and no LDS window holds a particle's reach, so AUTO runs k_rays_skip's global-field path
+    (and MARCH the literal march): ray steps, log-weights and the children of a full update equal the oracle's."""
+    grid = np.kron(sibal1.data, np.ones((2, 2), np.int8)).astype(np.int8)          # the same rooms at half the cell size
+    res = 0.025
+    om = orc.OracleMap(grid, res, sibal1.origin_x, sibal1.origin_y)
+    P = om.max_range_px
+    assert P == 479
+    ang = orc.beam_angles(angle_step=12)
+    rng = np.random.default_rng(41)
+    n = 3000
+    p = np.stack([rng.uniform(-7.0, 9.0, n), rng.uniform(-2.0, 6.0, n), rng.uniform(-np.pi, np.pi, n)])
+    obs = (rng.uniform(0.3, 13.0, ang.size)).astype(np.float32)
+    T = orc.sensor_table(om.max_range_px)
+    L = orc.eng_log_table(T)
+    want_logw, _, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L)
+    _, want_steps = orc.cast_many(om, np.repeat(p[0], ang.size), np.repeat(p[1], ang.size),
+                                  (p[2][:, None] + ang.astype(np.float64)[None, :]).ravel())
+    for rk in (engine_mod.RAYS_AUTO, engine_mod.RAYS_MARCH):
+        e = engine_mod.Engine(max_particles=n, seed=9, keep_ray_steps=1, ray_kernel=rk)
+        e.set_map(grid, res, sibal1.origin_x, sibal1.origin_y)
+        assert e.max_range_px == P
+        e.set_beam_angles(ang)
+        e.set_particles(p, np.full(n, 1.0 / n))
+        e.sensor_update(obs)
+        assert e.ray_kernel_name() == ("k_rays_skip" if rk == engine_mod.RAYS_AUTO else "k_rays_march")
+        steps = e.ray_steps()
+        assert steps.dtype == np.uint16 and steps.max() == P
+        assert np.array_equal(steps.astype(np.int32).ravel(), np.asarray(want_steps, np.int32).ravel())
+        assert np.array_equal(e.log_weights(), want_logw)
+        # a full update through mcl_update: resampling from these weights, motion, rays again
+        _, q, _ = orc.eng_weights_from_log(want_logw)
+        e.update((0.05, 0.0, 0.01), obs)
+        idx = e.resample_indices()
+        assert np.array_equal(idx, orc.eng_resample_indices(q, 0, k53=orc.eng_philox_k53(9, 0, 0, n)))
+        parts = e.get_particles()
+        np.testing.assert_allclose(parts, orc.motion_model(p[:, idx], (0.05, 0.0, 0.01), orc.eng_philox_normals(9, 0, 0, n)), rtol=1e-13, atol=1e-13)
+        logw2, _, _ = orc.eng_log_weights(om, parts, ang, orc.obs_index(obs, om), L)
+        assert np.array_equal(e.log_weights(), logw2)
+        e.close()
+    # the windowed kernels cannot take this map: asking for one is refused
+    e = engine_mod.Engine(max_particles=n, ray_kernel=engine_mod.RAYS_SWEEP)
+    e.set_map(grid, res, sibal1.origin_x, sibal1.origin_y)
+    e.set_beam_angles(ang)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    with pytest.raises(engine_mod.EngineError):
+        e.sensor_update(obs)
+    e.close()
