@@ -16,8 +16,8 @@ Rank 0 prints ONE JSON line.
 `roofline` names the bound that applies to the dominant kernel (k_rays_sweep): VALU issue.  Its inputs are the
 kernel's VALU instruction count (rocprofv3 PMC), the cycles one wave64 instruction of ITS instruction mix occupies a
 SIMD (tools/ubench/valu_rates.hip, measured on the box), the clock the kernel held (GRBM_GUI_ACTIVE) -- all read from
-profiles/r02_roofline_inputs.json, which tools/roofline_inputs.py writes from the committed rocprofv3 / ubench
-outputs -- and the kernel duration measured live with HIP events on the engine's stream.  `roofline.algorithmic`
+profiles/rNN_roofline_inputs.json (the latest round's), which tools/roofline_inputs.py writes from the committed rocprofv3 /
+ubench outputs -- and the kernel duration measured live with HIP events on the engine's stream.  `roofline.algorithmic`
 keeps SURVEY.md §8(d)'s figure (per ray S-bar one-byte grid probes as the reference reads them, cpp:642, + one 4-byte
 table entry, cpp:576; per particle 32 B) priced against the HBM peak: it exceeds 1 because the kernel examines a
 tenth of those samples (same results) and is NOT a bound.
@@ -39,7 +39,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_PER_GPU = 4 * 1024 * 1024
 ACTION = (0.05, 0.0, 0.01)
 TRUE_POSE = (0.0, 0.0, 0.0)
-ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")
+
+
+def _latest_roofline_inputs():
+    """profiles/rNN_roofline_inputs.json of the latest round that committed one (tools/profile_round.sh writes it)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_roofline_inputs.json")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")
+
+
+ROOFLINE_INPUTS = _latest_roofline_inputs()
 
 
 def host_cpu():
@@ -112,6 +121,14 @@ MAX_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md chip table: max clock 2400 
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 
 
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True):
     """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time.
 
@@ -151,7 +168,9 @@ def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True):
                                "at_measured_mix_rate": {"cycles_per_inst": inp["cycles_per_valu_inst"], "clock_ghz": inp["clock_ghz"],
                                                         "floor_ms": mix_floor_ms, "kernel_ms_while_profiled": inp["kernel_ms_while_profiled"],
                                                         "frac": mix_floor_ms / inp["kernel_ms_while_profiled"]},
-                               "source": "profiles/r02_roofline_inputs.json"},
+                               "source": os.path.relpath(ROOFLINE_INPUTS, ROOT), "source_sha256_16": _sha16(ROOFLINE_INPUTS),
+                               "note": "insts_per_launch and probe_trips_per_launch are PROFILE CONSTANTS (rocprofv3 PMC passes of this "
+                                       "workload, committed under profiles/); only kernel_ms is measured by this run"},
                       "traffic": inp.get("hbm_bytes_per_launch"),
                       "traffic_source": inp.get("hbm_bytes_source")})
     else:

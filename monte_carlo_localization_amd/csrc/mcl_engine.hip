@@ -550,6 +550,7 @@ int launch_far_windowed(mcl_engine *h, const mcl::RayArgs &a, int64_t n, bool co
     hipLaunchKernelGGL(mcl::k_far_scatter, dim3(nb), dim3(256), 0, h->stream, flags32, n, a.far_count, h->d_far_cnt, h->d_far_sorted);
     const size_t lds = (size_t)h->tw_cells * h->tw_cells / 2;
     if (count) hipLaunchKernelGGL((mcl::k_rays_skip<1, true, true>), dim3(h->num_cu), dim3(mcl::kRayThreads), lds, h->stream, a);
+    // (one ray per lane: two / four in flight measured 52 / 67 ms against 46 on the uniform levine cloud)
     else hipLaunchKernelGGL((mcl::k_rays_skip<1, false, true>), dim3(h->num_cu), dim3(mcl::kRayThreads), lds, h->stream, a);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;

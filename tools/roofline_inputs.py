@@ -46,6 +46,31 @@ for line in open(ub):
     if "k_rays_sweep whole beam" in line and "W=8" in line:
         cpi = float(re.search(r"([0-9.]+) \(wall x clock\)", line).group(1))
 assert cpi, "ubench row not found"
+
+
+def trip_mix_from_disassembly():
+    """The probe trip of the beam walk as the shipped library contains it: opcode sequence of the loop body between the two
+    `s_cbranch_execz` of MCL_SW_WALK, classified by the issue classes of profiles/*_op_rates.txt.  bench.py's VALU bound
+    assumes 5 four-cycle + 2 two-cycle VALU instructions per trip; this records what the binary really has."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "monte_carlo_localization_amd", "libmcl_hip_engine.so")
+    if not os.path.exists(lib):
+        return None
+    txt = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_meta.py"), lib, "--disasm", "k_rays_sweepILb0"],
+                         capture_output=True, text=True).stdout
+    ops = [re.sub(r"_e(32|64)$", "", l.split()[0]) for l in txt.splitlines() if l.startswith("\t")]
+    two = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_mov_b32", "v_lshrrev_b32", "v_ashrrev_i32"}
+    want = ["v_mad_u32_u24", "v_mad_u32_u24", "v_perm_b32", "ds_read_i8", "v_and_b32", "v_and_b32", "v_min3_u32", "s_waitcnt", "v_sub_co_u32", "s_andn2_b64"]
+    hits = [i for i in range(len(ops) - len(want)) if ops[i:i + len(want)] == want]
+    if not hits:
+        return {"verified": False}
+    valu = [o for o in want if o.startswith("v_")]
+    return {"verified": True, "occurrences": len(hits), "valu_per_trip": len(valu), "two_cycle": sum(o in two for o in valu),
+            "four_cycle": sum(o not in two for o in valu), "sequence": want}
+
+
 out = {
     "kernel": KERNEL, "particles": int(n), "beams": int(B),
     "valu_insts_per_launch": insts, "lds_insts_per_launch": lds, "cycles_per_valu_inst": cpi, "simds": 1024, "clock_ghz": round(clock_ghz, 4),
@@ -54,6 +79,7 @@ out = {
     "hbm_bytes_source": f"profiles/{tag}_pmc_*.csv: 2 x FETCH_SIZE + WRITE_SIZE (KB) of {KERNEL}, steady-state launches; "
                         "8-byte accesses are outside the guide's calibration (16 B per lane), so this is an upper estimate",
     "fetch_kb": fetch_kb, "write_kb": write_kb,
+    "probe_trip_in_binary": trip_mix_from_disassembly(),
     "sources": {"SQ_INSTS_VALU": f"profiles/{tag}_pmc_sq.csv", "GRBM_GUI_ACTIVE": f"profiles/{tag}_pmc_sq2.csv",
                 "FETCH_SIZE": f"profiles/{tag}_pmc_fetch.csv", "WRITE_SIZE": f"profiles/{tag}_pmc_write.csv",
                 "cycles_per_valu_inst": f"profiles/{tag}_valu_rates.txt, row 'k_rays_sweep whole beam', W=8, wall x clock"},
