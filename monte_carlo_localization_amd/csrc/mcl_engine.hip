@@ -161,6 +161,7 @@ struct mcl_engine {
     int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell, 5 sweep
     unsigned long long result_seq = 0;  // stamps the result block a small update writes to pinned memory (h_result[kResultStamp])
     int env_tiny_poll = 1;
+    bool far_fresh = true;              // no ray stage has seen the current particle set yet (set / initialised since the last one)
     bool pc_ready = false;              // d_pc already holds the constants of the current particles (written by k_resample_motion)
     int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
     unsigned long long *d_result = nullptr;   // [0..7] scalars, [8..11] counters, [12..13] overflow flag + work counter: one D2H copy
@@ -747,7 +748,12 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                 HIPCHK(h, hipMalloc(&h->d_far_sorted, (size_t)h->cap * sizeof(uint32_t)));
                 HIPCHK(h, hipMalloc(&h->d_far_cnt, ((size_t)h->cap / mcl::kFarTile + 2) * sizeof(uint32_t)));
             }
-            a.far_sorted = h->d_far_sorted; a.far_windowed = 1;
+            // the windowed far pass (four launches that stand down on the device when little is flagged) is only launched when
+            // there is reason to expect work for it: the previous ray stage flagged a fair number of slots, or the particle set
+            // is fresh (set / initialised since).  A misjudgement costs time, never results: without it k_rays_far takes all.
+            a.far_sorted = h->d_far_sorted;
+            a.far_windowed = (h->far_fresh || h->h_result[15] >= mcl::kFarWindowedMin / 2) ? 1 : 0;
+            h->far_fresh = false;
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
         size_t qlds = sweep ? (size_t)mcl::kSwSide * mcl::kSwSide : (size_t)h->qside * h->qside;
@@ -764,7 +770,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
-            if (sweep) { const int rcw = launch_far_windowed(h, a, n, true); if (rcw) return rcw; }
+            if (sweep && a.far_windowed) { const int rcw = launch_far_windowed(h, a, n, true); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
@@ -773,7 +779,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
-            if (sweep) { const int rcw = launch_far_windowed(h, a, n, false); if (rcw) return rcw; }
+            if (sweep && a.far_windowed) { const int rcw = launch_far_windowed(h, a, n, false); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<false>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
@@ -1249,6 +1255,7 @@ static int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *
     rc = fetch_scalars(h);
     if (rc) return rc;
     h->have_particles = true;
+    h->far_fresh = true;
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     return MCL_OK;
@@ -1277,6 +1284,7 @@ static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
     rc = fetch_scalars(h);
     if (rc) return rc;
     h->have_particles = true;
+    h->far_fresh = true;
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     h->init_idx++;

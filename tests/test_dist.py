@@ -55,6 +55,16 @@ def test_two_ranks_equal_one_rank_gloo_cpu(tmp_path, mode, overlap):
     assert list(two[0]["kinds"]) == ["dense", "lists", "lists"]
 
 
+def test_four_ranks_equal_one_rank_gloo_cpu(tmp_path):
+    """Four shards: the merged list CDF carries three non-trivial offsets, the sums all-reduce twelve per-rank slots."""
+    d4, d1 = tmp_path / "w4", tmp_path / "w1"
+    d4.mkdir(); d1.mkdir()
+    four = run_world("oracle", d4, 4, 48, 3, 0, True)
+    one = run_world("oracle", d1, 1, 192, 3, 0)
+    check_equal(four, one, 48)
+    assert list(four[3]["kinds"]) == ["dense", "lists", "lists"]
+
+
 def test_two_ranks_dense_exchange_only_gloo_cpu(tmp_path):
     """The dense exchange (weights gathered, distinct parents fetched) on every update: what runs when some shard has no
     compact list."""

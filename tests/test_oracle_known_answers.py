@@ -1,7 +1,8 @@
-"""Pins the reference-faithful half of the CPU oracle (oracle/mcl_oracle.c orc_ref_*, refdraws.cpp)
-to outputs of the REFERENCE ITSELF: the known answers recorded in SURVEY.md Appendix B, produced by
-running the reference's own src/particle_filter.cpp during the survey.  The reference ships no tests or
-golden vectors (CMakeLists.txt:126-133), so these literals are the only reference-side pin there is."""
+"""Regression net for the reference-faithful half of the CPU oracle (oracle/mcl_oracle.c orc_ref_*, refdraws.cpp): the
+known answers recorded in SURVEY.md Appendix B, which the survey produced by running the reference's own
+src/particle_filter.cpp against stub headers.  The reference ships no tests or golden vectors (CMakeLists.txt:126-133)
+and a stand-in build is not an admissible pin, so the oracle's status stays PARITY UNPINNED (oracle/mcl_oracle.c header,
+DESIGN.md §7); these literals are the only reference-derived numbers there are, and the oracle reproduces every one."""
 import numpy as np
 import pytest
 

@@ -15,11 +15,11 @@ mkdir -p "$OUT" "$PROF"
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rates.hip -o tools/ubench/valu_rates
 ./tools/ubench/valu_rates > "$PROF/${TAG}_valu_rates.txt"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o t -- python3 "$R/bench.py" --steps 10 --no-cpu-baseline > "$R/$OUT/prof.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/pmc_write" -o w -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$R/$OUT/pmc_sq" -o s -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_sq.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$R/$OUT/pmc_sq2" -o s2 -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline > "$R/$OUT/pmc_sq2.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o t -- python3 "$R/bench.py" --steps 10 --no-cpu-baseline --no-parity-check > "$R/$OUT/prof.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/pmc_write" -o w -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$R/$OUT/pmc_sq" -o s -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_sq.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$R/$OUT/pmc_sq2" -o s2 -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_sq2.log" 2>&1
 cd "$R"
 # keep only the rows of the ray-stage kernels in the committed PMC files (the full CSVs are tens of MB)
 for p in fetch:f write:w sq:s sq2:s2; do
