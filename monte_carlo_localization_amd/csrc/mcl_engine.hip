@@ -760,7 +760,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();
-        if (dbgpath && !sweep) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
+        if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
         // k_rays_far is bound by global-memory latency: 4 workgroups per CU worth of blocks (2 resident at a time)
         dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU

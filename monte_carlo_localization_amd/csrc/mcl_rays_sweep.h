@@ -167,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         int nruns = 0;
         if (b < nblocks) {
             long long want = ((long long)(M - u0) * ngroups) / (3ll * (nwg > 0 ? nwg : 1));
-            int c = 1;
+            int c = 1;                            // (a floor of 2 or 4 units per run costs 0.5 / 2.5 %: the tail of the launch)
             while (c * 2 <= kSwRunMax && c * 2 <= want) c *= 2;
 #pragma unroll
             for (int k = 0; k < kSwRunMax; ++k) len[k] = 0;
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int item_sh;
     __shared__ unsigned int fixn_sh;                           // entries this workgroup appended to ITS segment of the fix-up list
+    __shared__ unsigned int chunk_sh;                          // next 64-slot chunk of the current (run, wedge) pass
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long cnt_probe = 0;
     const int G = a.sweep_g;                                   // wedges per work item (divides kWedges)
     const int nitems = a.nitems_ptr ? a.nitems_ptr[0] : a.nitems;       // the plan is made on the device (k_sweep_plan)
@@ -327,12 +327,16 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // the segment belongs to this workgroup alone: the append counter lives in LDS and entries are plain stores (the list
     // is read by k_rays_fix, a later kernel); the count goes to memory once, at the end
     unsigned long long *const fix_seg = a.fix_list + (size_t)blockIdx.x * a.fix_cap;
+    unsigned long long dbg_t0 = 0, dbg_wait = 0, dbg_bar = 0;               // MCL_DEBUG_WG: start / end stamps (100 MHz) and items of this workgroup
+    unsigned int dbg_items = 0;
+    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) item_sh = (int)atomicAdd(a.work_counter, 1ull);
     __syncthreads();
     const int item = item_sh;
     if (item >= nitems) break;
+    ++dbg_items;
     // (first unit, units, wedge group): the host lists big items first and single units last (guided schedule), so the
     // persistent workgroups finish within one small item of each other
     const int4 it = a.items[item];                                   // wave-uniform: scalar loads
@@ -359,7 +363,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
         const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
         constexpr int wpr = S >> 3, nwords = wpr * S;
+        unsigned long long dbg_w0 = 0;
+        if (a.dbg) dbg_w0 = __builtin_amdgcn_s_memrealtime();
         if (gw > 0) __syncthreads();                                       // every wave is done with the previous window
+        if (a.dbg) { const unsigned long long tq = __builtin_amdgcn_s_memrealtime(); dbg_bar += tq - dbg_w0; }
         for (int wi = threadIdx.x; wi < nwords; wi += kRayThreads) {
             const int row = wi / wpr, cw = wi - row * wpr;
             // LDS cell (row, col) = grid cell (wy0 + row, wx0 + col), mirrored in the axes along which the wedge's rays
@@ -379,10 +386,20 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             }
             win[wi] = sxp ? b8 : __builtin_bswap64(b8);
         }
+        if (threadIdx.x == 0) chunk_sh = 0u;
         __syncthreads();
+        if (a.dbg) dbg_wait += __builtin_amdgcn_s_memrealtime() - dbg_w0;
     }
 
-    for (uint32_t s0g = p_begin + (uint32_t)wave * 64u; s0g < p_end; s0g += (uint32_t)kRayWaves * 64u) {
+    // The waves take 64-slot chunks of the run from a counter instead of a fixed stride: a wave whose particles had short rays
+    // takes another chunk while the slow ones finish, so the barrier before the next window waits for the slowest CHUNK, not
+    // for the slowest of sixteen fixed shares (the window phase, barrier waits included, was 9 % of a workgroup's time)
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&chunk_sh, 1u);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+        const uint32_t s0g = p_begin + chunk * 64u;
+        if (s0g >= p_end) break;
         const uint32_t slot = s0g + (uint32_t)lane;
         const bool have = slot < p_end;
         const uint32_t sl = have ? slot : p_end - 1u;
@@ -570,6 +587,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     }   // wedges of the group
     }   // work items
     __syncthreads();
+    if (a.dbg && threadIdx.x == 0) {
+        unsigned long long *d = a.dbg + (size_t)blockIdx.x * 4;
+        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = dbg_items | (dbg_bar << 32); d[3] = dbg_wait;
+    }
     if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = fixn_sh;      // may exceed fix_cap: k_fix_overflow reports it
     if (COUNT && a.counters) {
         cnt_probe = wave_sum_u64(cnt_probe);
