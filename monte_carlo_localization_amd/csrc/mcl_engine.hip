@@ -73,8 +73,6 @@ struct mcl_engine {
     int ltd_cols = 0;
     bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
-    double *d_partial = nullptr;        // k_rays_sweep: [kWedges / sweep_g][cap] partial log-weights in sorted-slot order
-    size_t partial_capacity = 0;
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
     int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), planned on the device every update
     int2 *d_centres = nullptr;          // window centre of every run of units (k_sweep_plan)
@@ -637,8 +635,10 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             // particles, where the finer items balance better than the sixteen partial-sum arrays cost (262 144 x 1081:
             // 0.58 / 0.80 -> 0.53 / 0.77, 1M: 1.72 / 2.13 -> 1.63 / 2.07; at 4M G = 1 and 2 are level).
             const int64_t M = (n + mcl::kSwUnit - 1) / mcl::kSwUnit;
-            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : (M <= 2048 ? 1 : 2);
-            if (sweep_g > mcl::kWedges || (mcl::kWedges % sweep_g) != 0) sweep_g = 2;
+            // Round 3: with the per-wedge sums added atomically (no partial-sum array per group) G = 1 wins at every size
+            // (4M x 1081, ms per update G = 1 / 2 / 4: 6.80 / 6.91 / 7.08; levine stand-in 7.89 / 8.00 / 8.24)
+            sweep_g = h->env_sweep_g > 0 ? h->env_sweep_g : 1;
+            if (sweep_g > mcl::kWedges || (mcl::kWedges % sweep_g) != 0) sweep_g = 1;
             nsl = (int)M;
         }
         const int items_per_slice = sweep ? mcl::kWedges / sweep_g : (cell ? mcl::kWedges : 4);
@@ -731,17 +731,11 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             a.distw = h->d_distw; a.distw_stride = (size_t)h->Hp * h->Wps;
         }
         if (sweep) {
-            const size_t need = (size_t)(mcl::kWedges / sweep_g) * (size_t)n;
-            if (need > h->partial_capacity) {
-                dfree(h->d_partial);
-                HIPCHK(h, hipMalloc(&h->d_partial, need * sizeof(double)));
-                h->partial_capacity = need;
-            }
             if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not allocated (internal)");
             if (!h->ltd_ready) build_ltd(h);          // a caller whose table decision was made for another particle count
             const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
             if (rc_plan) return rc_plan;
-            a.part = h->d_partial; a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
+            a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
                 HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
@@ -786,9 +780,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         }
         hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         if (sweep) {
-            // partial sums (sorted order) + what the far / fix / exact kernels added -> d_logw, and the per-workgroup maxima
-            hipLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, h->d_partial, mcl::kWedges / sweep_g, n,
-                               h->d_perm, h->d_logw_acc, h->d_logw, h->d_part);
+            // the slot accumulators (k_rays_sweep's per-wedge sums + what the far / fix / exact kernels added) -> d_logw in particle
+            // order, and the per-workgroup maxima
+            hipLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, n, h->d_perm, h->d_logw_acc, h->d_logw, h->d_part);
             h->max_partials_ready = true;
         } else {
             hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
@@ -1071,7 +1065,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_partial); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);

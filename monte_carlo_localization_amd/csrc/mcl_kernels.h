@@ -632,7 +632,6 @@ struct RayArgs {
     const float *Ltr;              // the same with the rows reversed (row P - d)
     const double *Ltd;             // k_rays_sweep: fp64 table indexed by samples left + kSwUnder (mcl_rays_sweep.h), ltd_cols columns
     int ltd_cols;
-    double *part;                  // k_rays_sweep: [kWedges / sweep_g][n] partial log-weights in sorted-slot order
     int sweep_g;                   // k_rays_sweep: wedges per work item
     const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, run), big first (guided schedule)
     const int2 *centres;           // k_rays_sweep: window centre (padded cell) of every run, k_sweep_plan

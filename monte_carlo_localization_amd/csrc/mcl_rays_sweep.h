@@ -16,9 +16,9 @@
 //       - the beam walk of the slots every live lane of the wave has is ONE asm block with its own vmcnt counting,
 //         induction variables advanced by per-lane increments (0 for a lane without rays) and undecided rays parked in
 //         two registers until the pass is over.
-//   * A work item is (run of units, group of G wedges), planned on the device per update (k_sweep_plan): the workgroup
-//     keeps the running sum of a particle in part[group][slot] (sorted order, plain loads and stores by the one lane
-//     that owns the slot), so the 16 fp64 atomics per particle of k_rays_cell are gone.
+//   * A work item is (run of units, group of G wedges; G = 1 by default), planned on the device per update (k_sweep_plan).  The sum of
+//     a particle's rays in a wedge goes to its slot's accumulator with one fp64 atomic -- sixty-four lanes on 512 contiguous
+//     bytes of the sorted order, unlike k_rays_cell's atomics scattered by particle index.
 #pragma once
 
 namespace mcl {
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
 // one small item of each other) is halved until the particles of every run fit one window (`half_play` cells either side of
 // the centre of the run's bounding box, both axes; a sparse cloud or a long range thus gets shorter runs instead of off-window
 // particles).  Every run is listed once per wedge group.  One workgroup; items come out in unit order.
-constexpr int kSwRunMax = 8;
+#ifndef MCL_SW_RUNMAX
+#define MCL_SW_RUNMAX 16
+#endif
+constexpr int kSwRunMax = MCL_SW_RUNMAX;
 __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, const int *__restrict__ m_ptr, int ngroups, int nwg, double half_play,
                                                     int4 *__restrict__ items, int2 *__restrict__ centres, int *__restrict__ nitems_out)
 {
@@ -345,7 +348,6 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const uint32_t p_begin = a.unit_begin[it.x];
     const uint32_t p_end = a.unit_begin[it.x + it.y];
     if (p_begin >= p_end) continue;
-    double *part = a.part + (size_t)grp * (size_t)a.n;
     const int2 ctr = a.centres[it.w];                                  // window centre of the run (k_sweep_plan): padded cell
     for (int gw = 0; gw < G; ++gw) {
     const int kbin = grp * G + gw;
@@ -581,8 +583,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             }
             if (ambcnt > 2u) acc_fast = 0.0;
         }
-        // the running sum of this group's earlier wedges (the same lane wrote it)
-        if (have) part[slot] = (gw > 0 ? part[slot] : 0.0) + (acc_fast + acc);
+        // the sum of this particle's rays in this wedge joins the slot's accumulator: one fp64 atomic per (slot, wedge), a wave's
+        // sixty-four on 512 contiguous bytes; exact and order-independent (E4).  Round 2 kept one partial-sum array per wedge
+        // group instead, read-modify-written by the owning lane and summed by k_combine_logw: 0.09 ms more per update.
+        if (have) atomicAdd(&a.logw[slot], acc_fast + acc);
     }
     }   // wedges of the group
     }   // work items
@@ -598,18 +602,17 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     }
 }
 
-// log-weight of every particle = the partial sums of its wedge groups + what k_rays_far / k_rays_fix / k_rays_exact added
-// for it (fp64 atomics of earlier kernels: plain loads see them, profiles/r02_coherence.txt), all in sorted-slot order and
-// read coalesced; one scattered 8-byte store per particle puts the sum where the rest of the update expects it.  Also the
-// per-workgroup maximum for the normalisation (replaces k_reduce_max; k_final_max reduces `maxpart`).
-__global__ __launch_bounds__(256) void k_combine_logw(const double *__restrict__ part, int ngroups, int64_t n, const uint32_t *__restrict__ perm,
-                                                     const double *__restrict__ acc, double *__restrict__ logw, double *__restrict__ maxpart)
+// log-weight of every particle = its slot's accumulator (k_rays_sweep's per-wedge sums and what k_rays_far / k_rays_skip<FAR> /
+// k_rays_fix / k_rays_exact added: fp64 atomics of earlier kernels, which plain loads see, profiles/r02_coherence.txt), read
+// coalesced in sorted-slot order; one scattered 8-byte store per particle puts it where the rest of the update expects it.
+// Also the per-workgroup maximum for the normalisation (k_final_max reduces `maxpart`).
+__global__ __launch_bounds__(256) void k_combine_logw(int64_t n, const uint32_t *__restrict__ perm, const double *__restrict__ acc,
+                                                     double *__restrict__ logw, double *__restrict__ maxpart)
 {
     __shared__ double sm[4];
     double m = -INFINITY;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
-        double v = acc[s];
-        for (int g = 0; g < ngroups; ++g) v += part[(size_t)g * (size_t)n + s];
+        const double v = acc[s];
         logw[perm[s]] = v;
         m = fmax(m, v);
     }

@@ -116,8 +116,8 @@ def test_cluster_near_map_corner_and_nonfinite(orc, engine_mod, sibal1, sibal1_o
 
 @pytest.mark.parametrize("g", [1, 2, 4, 8, 16])
 def test_every_wedge_group_size_gives_the_same_sums(orc, engine_mod, spielberg, spielberg_oracle, g, monkeypatch):
-    """MCL_SWEEP_G (read at mcl_create) sets how many wedges a work item walks, i.e. how many partial-sum arrays the
-    update keeps and how the running sums are carried: the log-weights must not depend on it."""
+    """MCL_SWEEP_G (read at mcl_create) sets how many wedges a work item walks before it takes the next run of units (one by
+    default; every wedge's sum joins the slot accumulator atomically): the log-weights must not depend on it."""
     monkeypatch.setenv("MCL_SWEEP_G", str(g))
     ang = orc.beam_angles(angle_step=3)
     n = 70000                                                    # 69 units: runs of several units and single ones
