@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
 // one small item of each other) is halved until the particles of every run fit one window (`half_play` cells either side of
 // the centre of the run's bounding box, both axes; a sparse cloud or a long range thus gets shorter runs instead of off-window
 // particles).  Every run is listed once per wedge group.  One workgroup; items come out in unit order.
+#ifndef MCL_SW_GUIDE
+#define MCL_SW_GUIDE 3
+#endif
 #ifndef MCL_SW_RUNMAX
 #define MCL_SW_RUNMAX 16
 #endif
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         int len[kSwRunMax];                       // len[k] = units of the run that starts at u0 + k (0: inside another run)
         int nruns = 0;
         if (b < nblocks) {
-            long long want = ((long long)(M - u0) * ngroups) / (3ll * (nwg > 0 ? nwg : 1));
+            long long want = ((long long)(M - u0) * ngroups) / ((long long)MCL_SW_GUIDE * (nwg > 0 ? nwg : 1));
             int c = 1;                            // (a floor of 2 or 4 units per run costs 0.5 / 2.5 %: the tail of the launch)
             while (c * 2 <= kSwRunMax && c * 2 <= want) c *= 2;
 #pragma unroll
