@@ -75,7 +75,7 @@ struct mcl_engine {
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
     int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), planned on the device every update
-    int2 *d_centres = nullptr;          // window centre of every run of units (k_sweep_plan)
+    int4 *d_centres = nullptr;          // per run of units: window centre, first unit, units (k_sweep_plan)
     size_t items_capacity = 0;
     int *d_nitems = nullptr;            // number of work items (written by k_sweep_plan)
     int64_t plan_n = 0;
@@ -503,12 +503,12 @@ int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
         dfree(h->d_items); dfree(h->d_centres);
         h->items_capacity = 0;
         HIPCHK(h, hipMalloc(&h->d_items, need * sizeof(int4)));
-        HIPCHK(h, hipMalloc(&h->d_centres, (size_t)max_sweep_units(n) * sizeof(int2)));
+        HIPCHK(h, hipMalloc(&h->d_centres, (size_t)max_sweep_units(n) * sizeof(int4)));
         h->items_capacity = need;
     }
     if (!h->d_nitems) HIPCHK(h, hipMalloc(&h->d_nitems, sizeof(int)));
     const int play = mcl::kSwSide - (h->P + 2) - 3;                     // cells a window leaves for the particles of an item
-    hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), 0, h->stream, h->d_unit_sums, h->d_nunits, ngroups, nwg, (double)(play / 2 - 1),
+    hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), mcl::kPlanLds, h->stream, h->d_unit_sums, h->d_nunits, ngroups, nwg, (double)(play / 2 - 1),
                        h->d_items, h->d_centres, h->d_nitems);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
@@ -1037,6 +1037,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_tiny_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_sweep_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     {   // k_rays_sweep addresses its window from the raw LDS offset kQLdsBase: its static LDS must end exactly there.  A

@@ -634,7 +634,7 @@ struct RayArgs {
     int ltd_cols;
     int sweep_g;                   // k_rays_sweep: wedges per work item
     const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, run), big first (guided schedule)
-    const int2 *centres;           // k_rays_sweep: window centre (padded cell) of every run, k_sweep_plan
+    const int4 *centres;           // k_rays_sweep: per run of units (window centre as a padded cell x, y; first unit; units), k_sweep_plan
     int nitems;
     const int *nitems_ptr;          // k_rays_sweep: number of work items, written by k_sweep_plan
     const double4 *unit_sums;      // k_rays_sweep: per unit of the sorted order (sum px, sum py, count, -) and its bounding box, k_unit_sums

@@ -156,76 +156,109 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
 #define MCL_SW_RUNMAX 16
 #endif
 constexpr int kSwRunMax = MCL_SW_RUNMAX;
+static_assert(kSwRunMax == 16, "k_sweep_plan's bounding-box pyramid has four levels above the units");
+constexpr int kPlanBlocks = 256;                 // blocks of kSwRunMax units planned per pass of the workgroup
+constexpr int kPlanLds = (kPlanBlocks * kSwRunMax * 15 / 16) * (int)sizeof(float4);     // levels 1..4 of one pass: 61 440 bytes
 __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, const int *__restrict__ m_ptr, int ngroups, int nwg, double half_play,
-                                                    int4 *__restrict__ items, int2 *__restrict__ centres, int *__restrict__ nitems_out)
+                                                    int4 *__restrict__ items, int4 *runs, int *__restrict__ nitems_out)
 {
-    __shared__ int wave_tot[16];
+    // Bounding boxes of the aligned runs of 2, 4, 8 and 16 units as a pyramid in LDS (floats: the plan is a heuristic, the ray
+    // kernel tests every particle against its window exactly), built by all threads; then one thread per block of 16 units
+    // halves its candidate runs until they fit, one pyramid node per test.
+    extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
+    float4 *pyr = reinterpret_cast<float4 *>(plan_lds);          // level l (1..4) of this pass at pyr + lvl_off[l]
+    __shared__ int wave_tot[4];
     __shared__ int carry_sh;
     const int M = m_ptr[0];                   // units of this update's sorted order (k_unit_table)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int U = kPlanBlocks * kSwRunMax;                   // units per pass
+    constexpr int off1 = 0, off2 = U / 2, off3 = off2 + U / 4, off4 = off3 + U / 8;
+    const float hp = (float)half_play;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
     const int nblocks = (M + kSwRunMax - 1) / kSwRunMax;
-    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+    auto unit_box = [&](int u) -> float4 {                       // (x0, x1, y0, y1); empty: x1 < x0
+        if (u >= M) return make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+        const double4 bb = unit_stats[2 * (size_t)u + 1];
+        return make_float4((float)bb.x, (float)bb.y, (float)bb.z, (float)bb.w);
+    };
+    auto join = [](float4 p, float4 q) { return make_float4(fminf(p.x, q.x), fmaxf(p.y, q.y), fminf(p.z, q.z), fmaxf(p.w, q.w)); };
+    for (int b0 = 0; b0 < nblocks; b0 += kPlanBlocks) {
+        const int ubase = b0 * kSwRunMax;
+        for (int k = threadIdx.x; k < U / 2; k += 1024) pyr[off1 + k] = join(unit_box(ubase + 2 * k), unit_box(ubase + 2 * k + 1));
+        __syncthreads();
+        for (int k = threadIdx.x; k < U / 4; k += 1024) pyr[off2 + k] = join(pyr[off1 + 2 * k], pyr[off1 + 2 * k + 1]);
+        __syncthreads();
+        for (int k = threadIdx.x; k < U / 8; k += 1024) pyr[off3 + k] = join(pyr[off2 + 2 * k], pyr[off2 + 2 * k + 1]);
+        __syncthreads();
+        for (int k = threadIdx.x; k < U / 16; k += 1024) pyr[off4 + k] = join(pyr[off3 + 2 * k], pyr[off3 + 2 * k + 1]);
+        __syncthreads();
+        // box of the aligned run of cc units (a power of two) that starts at unit index r of this pass
+        auto run_box = [&](int r, int cc) -> float4 {
+            return cc == 1 ? unit_box(ubase + r) : cc == 2 ? pyr[off1 + (r >> 1)] : cc == 4 ? pyr[off2 + (r >> 2)] : cc == 8 ? pyr[off3 + (r >> 3)] : pyr[off4 + (r >> 4)];
+        };
         const int b = b0 + (int)threadIdx.x;
-        const int u0 = b * kSwRunMax;
-        int len[kSwRunMax];                       // len[k] = units of the run that starts at u0 + k (0: inside another run)
+        const int u0 = b * kSwRunMax, r0 = (int)threadIdx.x * kSwRunMax;
+        const bool mine = (int)threadIdx.x < kPlanBlocks && b < nblocks;
+        unsigned int starts = 0u;                 // bit k: a run starts at unit k of the block (it ends where the next one starts)
         int nruns = 0;
-        if (b < nblocks) {
+        if (mine) {
             long long want = ((long long)(M - u0) * ngroups) / ((long long)MCL_SW_GUIDE * (nwg > 0 ? nwg : 1));
             int c = 1;                            // (a floor of 2 or 4 units per run costs 0.5 / 2.5 %: the tail of the launch)
             while (c * 2 <= kSwRunMax && c * 2 <= want) c *= 2;
-#pragma unroll
-            for (int k = 0; k < kSwRunMax; ++k) len[k] = 0;
             // runs of c units, each halved until it fits
             for (int k0 = 0; k0 < kSwRunMax && u0 + k0 < M; k0 += c) {
                 int cc = c;
                 int k = k0;
                 while (k < k0 + c && u0 + k < M) {
-                    const int avail = (u0 + k + cc <= M) ? cc : M - (u0 + k);
                     bool fits = true;
                     if (cc > 1) {
                         // the windows of a run are centred on the bounding box of its particles: they fit when the box is
                         // narrower than the play on both axes
-                        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-                        for (int j = 0; j < avail; ++j) {
-                            const double4 bb = unit_stats[2 * (size_t)(u0 + k + j) + 1];
-                            x0 = fmin(x0, bb.x); x1 = fmax(x1, bb.y); y0 = fmin(y0, bb.z); y1 = fmax(y1, bb.w);
-                        }
-                        if (x1 >= x0) fits = 0.5 * (x1 - x0) < half_play && 0.5 * (y1 - y0) < half_play;
+                        const float4 bb = run_box(r0 + k, cc);
+                        if (bb.y >= bb.x) fits = 0.5f * (bb.y - bb.x) < hp && 0.5f * (bb.w - bb.z) < hp;
                     }
-                    if (fits || cc == 1) { len[k] = avail; ++nruns; k += cc; }
+                    if (fits || cc == 1) { starts |= 1u << k; ++nruns; k += cc; }
                     else cc >>= 1;                      // try the first half; the second half is tried at the same (halved) length
                 }
             }
         }
-        // position of this block's first run: exclusive scan of nruns over the workgroup, carried across passes
+        // position of this block's first run: exclusive scan of nruns over the planning threads, carried across passes
         int inc = nruns;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) wave_tot[wv] = inc;
+        if (lane == 63 && wv < 4) wave_tot[wv] = inc;
         __syncthreads();
-        int at = carry_sh + inc - nruns;
-        for (int k = 0; k < wv; ++k) at += wave_tot[k];
-        if (b < nblocks) {
-#pragma unroll
-            for (int k = 0; k < kSwRunMax; ++k)
-                if (len[k] > 0) {
-                    // the windows of the run are centred on the bounding box of its particles (cell of the centre + 1: padded)
-                    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-                    for (int j = 0; j < len[k]; ++j) {
-                        const double4 bb = unit_stats[2 * (size_t)(u0 + k + j) + 1];
-                        x0 = fmin(x0, bb.x); x1 = fmax(x1, bb.y); y0 = fmin(y0, bb.z); y1 = fmax(y1, bb.w);
-                    }
-                    const double mx = x1 >= x0 ? 0.5 * (x0 + x1) : 0.0, my = x1 >= x0 ? 0.5 * (y0 + y1) : 0.0;
-                    centres[at] = make_int2((int)floor(mx) + 1, (int)floor(my) + 1);
-                    for (int g = 0; g < ngroups; ++g) items[(size_t)at * ngroups + g] = make_int4(u0 + k, len[k], (g + u0 + k) % ngroups, at);
-                    ++at;
-                }
+        const int at_base = carry_sh;
+        int at = at_base + inc - nruns;
+        for (int k = 0; k < wv && k < 4; ++k) at += wave_tot[k];
+        if (mine) {
+            const int uend = (u0 + kSwRunMax < M) ? kSwRunMax : M - u0;          // units of this block
+            unsigned int rest = starts;
+            while (rest) {
+                const int k = __ffs((int)rest) - 1;
+                rest &= rest - 1u;
+                const int knext = rest ? __ffs((int)rest) - 1 : uend;
+                const int len = knext - k;
+                // power-of-two cover of the run for its box: a run is an aligned power of two, cut short only by the end of the set
+                int cc = 1;
+                while (cc < len) cc <<= 1;
+                const float4 bb = run_box(r0 + k, cc);
+                const float mx = bb.y >= bb.x ? 0.5f * (bb.x + bb.y) : 0.0f, my = bb.y >= bb.x ? 0.5f * (bb.z + bb.w) : 0.0f;
+                runs[at++] = make_int4((int)floorf(mx) + 1, (int)floorf(my) + 1, u0 + k, len);      // padded cell of the centre, first unit, units
+            }
         }
+        __syncthreads();                          // the run table of this pass is complete (and visible: same workgroup)
+        if ((int)threadIdx.x == kPlanBlocks - 1) carry_sh = at;      // the last planning thread's end position = the total so far
         __syncthreads();
-        if (threadIdx.x == 1023) carry_sh = at;      // the last thread's end position = the total so far
-        __syncthreads();
+        // every run once per wedge group, written by all threads
+        const int nr = carry_sh - at_base;
+        for (int idx = threadIdx.x; idx < nr * ngroups; idx += 1024) {
+            const int r = at_base + idx / ngroups, g = idx - (idx / ngroups) * ngroups;
+            const int4 rn = runs[r];
+            items[(size_t)r * ngroups + g] = make_int4(rn.z, rn.w, (g + rn.z) % ngroups, r);
+        }
+        __syncthreads();                          // the pyramid is rebuilt by the next pass
     }
     if (threadIdx.x == 0) nitems_out[0] = carry_sh * ngroups;
 }
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const uint32_t p_begin = a.unit_begin[it.x];
     const uint32_t p_end = a.unit_begin[it.x + it.y];
     if (p_begin >= p_end) continue;
-    const int2 ctr = a.centres[it.w];                                  // window centre of the run (k_sweep_plan): padded cell
+    const int4 ctr = a.centres[it.w];                                  // window centre of the run (k_sweep_plan): padded cell
     for (int gw = 0; gw < G; ++gw) {
     const int kbin = grp * G + gw;
     const int q = kbin >> kWedgeShift;
