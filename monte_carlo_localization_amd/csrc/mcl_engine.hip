@@ -7,7 +7,9 @@
 // There is NO CPU fallback: without a gfx950 device mcl_create fails with MCL_ERR_NO_DEVICE.
 #include "../../include/mcl_hip_engine.h"
 
+#include <cstring>
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -149,6 +151,10 @@ struct mcl_engine {
     double *d_ths = nullptr;            // cap: heading in sorted order
     uint8_t *d_distw = nullptr;         // kWedges wedge fields for k_rays_cell, each Hp x Wps bytes
     uint32_t *d_perm = nullptr, *d_skey = nullptr, *d_srank = nullptr;   // cap each
+    uint32_t *d_skey2 = nullptr, *d_sval2 = nullptr;   // MCL_SORT=radix: sorted keys / indices
+    void *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int env_sort_radix = -1;           // MCL_SORT=radix / hist forces one ordering path; default: by size
     uint32_t *d_tile_used = nullptr;    // one mark per kHistTile buckets of the sort histogram: touched by this update's sort
     uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
     int *d_bbox = nullptr;              // 6: bounding box, occupied tiles, numbering in use
@@ -693,6 +699,30 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                                h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox, tiles_ok ? h->d_tilemark : (int *)nullptr, ntx_abs);
             if (tiles_ok)
                 hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, h->d_tilemark, h->d_tilemap, ntx_abs * nty_abs);
+            // Two ways to the same kind of order (which lanes share a wave; never results).  Counting sort with per-XCD
+            // histograms: one returning L2 atomic per particle (~1 per clock and XCD) + a scatter.  From 3M particles a radix
+            // sort of (key, index) pairs is quicker -- keys only, rocPRIM's device sort (a plain library sort), then a gather:
+            // 4M x 1081 6.57 -> 6.47 ms per update; below, its fixed cost of a dozen launches loses (2M +0.03, 262 144 +0.05 ms).
+            const bool radix = h->env_sort_radix >= 0 ? h->env_sort_radix != 0 : n >= 3000000;
+            if (radix) {
+                if (!h->d_skey2) {
+                    HIPCHK(h, hipMalloc(&h->d_skey2, (size_t)h->cap * 4));
+                    HIPCHK(h, hipMalloc(&h->d_sval2, (size_t)h->cap * 4));
+                }
+                size_t tb = 0;
+                HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tb, h->d_skey, h->d_skey2, h->d_srank, h->d_sval2, (size_t)n, 0, mcl::kSortKeyLog2, h->stream));
+                if (tb > h->sort_tmp_bytes) {
+                    dfree(h->d_sort_tmp);
+                    h->sort_tmp_bytes = 0;
+                    HIPCHK(h, hipMalloc(&h->d_sort_tmp, tb));
+                    h->sort_tmp_bytes = tb;
+                }
+                hipLaunchKernelGGL(mcl::k_sort_keys, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_skey, h->d_srank,
+                                   h->d_tilemap, ntx_abs);
+                tb = h->sort_tmp_bytes;
+                HIPCHK(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tb, h->d_skey, h->d_skey2, h->d_srank, h->d_sval2, (size_t)n, 0, mcl::kSortKeyLog2, h->stream));
+                hipLaunchKernelGGL(mcl::k_sort_gather, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_sval2, h->d_pcs, h->d_ths, h->d_perm);
+            } else {
             hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
                                h->d_skey, h->d_srank, h->d_tile_used, h->d_tilemap, ntx_abs);
             hipLaunchKernelGGL(mcl::k_hist_partials, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
@@ -700,6 +730,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
             hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_skey, h->d_srank,
                                h->d_hist, h->d_pcs, h->d_ths, h->d_perm);
+            }
             if (sweep) {
                 // units of the sorted order (cut at tile borders when the set is ordered by whole tiles), from the bucket
                 // offsets the scatter has just used -- before they are cleared
@@ -713,9 +744,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                 }
                 if (!h->d_nunits) HIPCHK(h, hipMalloc(&h->d_nunits, sizeof(int)));
                 hipLaunchKernelGGL(mcl::k_unit_table, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, n, h->d_hist, h->d_histpart, h->d_tile_used,
-                                   h->d_unit_begin, h->d_nunits, (int)mu);
+                                   radix ? h->d_skey2 : (const uint32_t *)nullptr, h->d_unit_begin, h->d_nunits, (int)mu);
             }
-            hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
+            if (!radix) hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
             if (sweep) {
                 hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)max_sweep_units(n)), dim3(256), 0, h->stream, h->d_pcs, h->d_unit_begin, h->d_nunits,
                                    h->d_unit_sums);
@@ -961,6 +992,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     if (const char *e = getenv("MCL_SWEEP_G")) h->env_sweep_g = atoi(e);
     if (const char *e = getenv("MCL_TINY_POLL")) h->env_tiny_poll = atoi(e);
     if (const char *e = getenv("MCL_NO_COMPACT")) h->env_no_compact = atoi(e);
+    if (const char *e = getenv("MCL_SORT")) h->env_sort_radix = std::strcmp(e, "radix") == 0 ? 1 : (std::strcmp(e, "hist") == 0 ? 0 : -1);
     if (const char *e = getenv("MCL_DEBUG_WG")) h->env_debug_wg = e;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
@@ -1063,7 +1095,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
     dfree(h->d_gcdf); dfree(h->d_gtop);
     dfree(h->d_blockcnt); dfree(h->d_ccdf); dfree(h->d_ctop); dfree(h->d_cidx); dfree(h->d_crec);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);

@@ -1746,6 +1746,31 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const double4 *__restrict_
     perm[slot] = (uint32_t)i;
 }
 
+// ---- the same ordering through a radix sort of (key, index) pairs (MCL_SORT=radix): keys only, no atomics; the sort itself is
+//      rocPRIM's (a plain library sort, like a library GEMM would be), the gather puts the records in sorted order ----
+__global__ __launch_bounds__(256) void k_sort_keys(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n, int Wp, int Hp,
+                                                  const int *__restrict__ bbox, uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out,
+                                                  const int *__restrict__ tilemap, int ntx_abs)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double4 c = pc[i];
+    key_out[i] = sort_key(bbox, tilemap, ntx_abs, cell_of(c.z * kSortSub, Wp * kSortSub - 1), cell_of(c.w * kSortSub, Hp * kSortSub - 1), th[i], n,
+                          c.z * kSortSub - floor(c.z * kSortSub), c.w * kSortSub - floor(c.w * kSortSub));
+    val_out[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_sort_gather(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n,
+                                                    const uint32_t *__restrict__ order, double4 *__restrict__ pcs, double *__restrict__ ths,
+                                                    uint32_t *__restrict__ perm)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t i = order[s];
+    pcs[s] = pc[i];
+    ths[s] = th[i];
+    perm[s] = i;
+}
+
 // after the scatter: the used tiles of the histogram (all XCD copies) and their marks back to zero, so that the next
 // update starts from an all-zero histogram without a pass over its 128 MB
 __global__ __launch_bounds__(256) void k_hist_clear(uint32_t *__restrict__ hist, uint32_t *__restrict__ tile_used)

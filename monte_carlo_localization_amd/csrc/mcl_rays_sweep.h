@@ -63,7 +63,8 @@ __global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restri
 // histogram tiles' totals (the offset of every bucket of a tile nobody fell into).  One workgroup.
 __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbox, int64_t n, const uint32_t *__restrict__ hist,
                                                     const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_used,
-                                                    uint32_t *__restrict__ ub, int *__restrict__ m_out, int max_units)
+                                                    const uint32_t *__restrict__ sorted_keys, uint32_t *__restrict__ ub, int *__restrict__ m_out,
+                                                    int max_units)
 {
     __shared__ uint32_t ws[16];
     __shared__ uint32_t carry_sh;
@@ -84,6 +85,11 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     auto start_of = [&](int t) -> uint32_t {
         if (t >= ntl) return (uint32_t)n;
         const uint32_t key0 = (uint32_t)t << shift;
+        if (sorted_keys) {                          // radix-sorted keys: first slot whose key is not below the tile's first key
+            int64_t lo = 0, hi = n;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < key0) lo = mid + 1; else hi = mid; }
+            return (uint32_t)lo;
+        }
         return tile_used[key0 >> 12] ? hist[key0] : part[key0 >> 12];
     };
     for (int t0 = 0; t0 < ntl; t0 += 1024) {
