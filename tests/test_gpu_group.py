@@ -121,6 +121,35 @@ def test_group_set_particles_with_non_uniform_weights(orc, engine_mod, spielberg
         grp.close(); one.close()
 
 
+def test_group_with_a_shard_that_carries_no_weight(orc, engine_mod, spielberg):
+    """All of the first shard's weights are zero: its compact list is empty (length 0, not "no list"), the merged CDF starts
+    with a plateau, every child comes from the second shard -- and equals one engine's, also on the update after."""
+    from conftest import tracking_cloud
+    ang = orc.beam_angles(angle_step=18)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::18].astype(np.float32).copy()
+    n = 20000
+    rng = np.random.default_rng(18)
+    p = tracking_cloud(rng, n)
+    w = rng.random(n)
+    w[: n // 2] = 0.0
+    w[n // 2:][rng.random(n // 2) < 0.9] = 0.0            # a tenth of the second shard carries weight: that shard has a list
+    w /= w.sum()
+    one = make_engine(engine_mod, spielberg, ang, n, seed=5)
+    one.set_particles(p, w)
+    grp = make_group(engine_mod, spielberg, ang, n // 2, 2, seed=5)
+    grp.set_particles(p, w)
+    assert grp.engine(0).compact_list()[0] == 0 and grp.engine(1).compact_list()[0] == np.count_nonzero(w)      # an empty list and a short one
+    for k in range(3):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        idx = one.resample_indices()
+        assert np.array_equal(grp.resample_indices(), idx), f"update {k}"
+        assert np.array_equal(grp.get_particles(), one.get_particles()), f"update {k}"
+        if k == 0:
+            assert (idx >= n // 2).all() and grp.exchange_bytes()["lists"]
+    grp.close(); one.close()
+
+
 def test_shard_cdf_follows_the_staged_weights(orc, engine_mod, spielberg):
     """After a staged (sharded) update the shard's own CDF must describe its NEW weights: mcl_sample_particles (the
     reference's visualize(), cpp:946-958) on a one-shard group equals the same call on a plain engine."""
