@@ -858,7 +858,8 @@ constexpr int kCellBase = 1 << 19;
 // fp64 skipping march of one ray, on the LDS nibble window (LDSWIN) or on the global byte field.
 template <bool LDSWIN, bool COUNT>
 __device__ __forceinline__ int trace_fp64(const RayArgs &a, const unsigned char *ldsb, int strideB, int base, double p0x, double p0y,
-                                          double ux, double uy, int s0, uint32_t &amb, unsigned &np, const uint8_t *field = nullptr)
+                                          double ux, double uy, int s0, uint32_t &amb, unsigned &np, const uint8_t *field = nullptr,
+                                          bool wedge_coded = false)
 {
     const uint8_t *gf = field ? field : a.dist;
     int s = s0, r = a.P;
@@ -878,6 +879,7 @@ __device__ __forceinline__ int trace_fp64(const RayArgs &a, const unsigned char 
             d = (byte >> ((cx & 1) * 4)) & 15;
         } else {
             d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? gf[(size_t)cy * a.Wps + cx] : 0;
+            if (wedge_coded) d = d == 255 ? 0 : d;        // a wedge field (mcl_wedge.h) as the windows hold it: 0xFF = stop, skips 1..127
         }
         if (COUNT) ++np;
         if (d == 0) { r = s - 1; break; }
@@ -2106,8 +2108,10 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
     const int part = blockIdx.x % split;
     for (int seg = blockIdx.x / split; seg < a.fix_segments; seg += gridDim.x / split) {
     // the counters were updated by memory-side atomics: read them the same way (a cached copy may be stale)
+    // (k_rays_quad / k_rays_cell append with memory-side atomics and are read back the same way; k_rays_sweep's lists and counts
+    //  are plain stores of an earlier kernel -- slot_space -- which plain loads see)
     unsigned long long n = 0;
-    if (threadIdx.x == 0) n = atomicAdd(&a.fix_count[(size_t)seg * 8], 0ull);
+    if (threadIdx.x == 0) n = a.slot_space ? a.fix_count[(size_t)seg * 8] : atomicAdd(&a.fix_count[(size_t)seg * 8], 0ull);
     n = __shfl((long long)n, 0, 64);
     {
         __shared__ unsigned long long n_sh;
@@ -2120,10 +2124,16 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
     cnt_l2 += (threadIdx.x == 0 && part == 0) ? n : 0;
     const unsigned long long *list = a.fix_list + (size_t)seg * a.fix_cap;
     for (unsigned long long k = (unsigned long long)part * blockDim.x + threadIdx.x; k < n; k += (unsigned long long)blockDim.x * split) {
-        const unsigned long long e = atomicAdd(const_cast<unsigned long long *>(&list[k]), 0ull);
+        const unsigned long long e = a.slot_space ? list[k] : atomicAdd(const_cast<unsigned long long *>(&list[k]), 0ull);
         const int64_t p = (int64_t)(e >> 16);                     // particle index, or sorted slot (slot_space)
         const int j = (int)(e & 0xFFFF);
         const double4 pci = a.slot_space ? a.pcs[p] : a.pc[p];
+        // k_rays_sweep's rays are re-traced on the field of their own wedge (half the probes of the isotropic field)
+        const uint8_t *wfield = nullptr;
+        if (a.slot_space && a.distw) {
+            const double hth = a.ths[p];
+            if (hth == hth && fabs(hth) < 1e6) wfield = a.distw + (size_t)(beam_wedge(hth, a.beam_angle[j]) & (kWedges - 1)) * a.distw_stride;
+        }
         const double2 cs = a.beam_cs[j];
         const double ux = pci.x * cs.x - pci.y * cs.y, uy = pci.y * cs.x + pci.x * cs.y;
         const bool sane = (pci.z > -200000.0) && (pci.z < 200000.0) && (pci.w > -200000.0) && (pci.w < 200000.0);
@@ -2136,8 +2146,9 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
             const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
             const int cx = (__double2hiint(p0x) & 0xFFFFF) - base, cy = (__double2hiint(p0y) & 0xFFFFF) - base;
             amb = lox < loy ? lox : loy;
-            const int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? a.dist[(size_t)cy * a.Wps + cx] : 0;
-            r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, d > 1 ? d : 1, amb, np);
+            int d = ((unsigned)cx < (unsigned)a.Wp && (unsigned)cy < (unsigned)a.Hp) ? (wfield ? wfield : a.dist)[(size_t)cy * a.Wps + cx] : 0;
+            if (wfield && d == 255) d = 0;
+            r = trace_fp64<false, COUNT>(a, nullptr, 0, base, p0x, p0y, ux, uy, d > 1 ? d : 1, amb, np, wfield, wfield != nullptr);
         }
         if (!sane || amb < kGuard || a.force_exact == 1) {
             // level 3, the literal march: 207 dependent steps in one thread would set the duration of this kernel, so the
