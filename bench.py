@@ -197,6 +197,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="sharded runs: gather the exchange synchronously")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the sharded (torch.distributed/RCCL) path even with one rank (rehearsal)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of the sharded path; gloo + --one-device rehearses --gpus N on a one-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     return ap.parse_args(argv)
 
 
@@ -258,7 +261,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device and args.backend == "nccl" and world > 1:
+        raise SystemExit("--one-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
@@ -284,8 +289,10 @@ def main():
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     e = engine.Engine(max_particles=n, device=local_rank, seed=42, resample_mode=mode)
     e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
@@ -416,7 +423,8 @@ def main():
                                    f"stock sensor/motion params, {args.resample} resampling, Philox seed 42; the timed updates "
                                    f"follow {args.warmup} warm-up updates (the particle set has resampled to motion-noise width)",
                        "particles_total": n * world, "beams": B,
-                       "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"particle-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU over gloo)" if args.one_device else ""))
+                                      if world > 1 else "single GPU"},
             "first_update_ms": first_ms, "first_update_ray_kernel_ms": first_ray_ms,
             "steady_state_ms": ms,
             "roofline": roof,

@@ -54,3 +54,25 @@ def test_single_gpu_call_runs_in_process():
     b = importlib.import_module("bench")
     a = b.parse_args([])
     assert (a.gpus, a.steps, a.warmup, a.particles_per_gpu) == (1, 20, 3, 4 * 1024 * 1024)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_end_to_end_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` as the driver calls it for N = 1 -- no launcher -- with the rehearsal switches (both ranks on
+    GPU 0, gloo instead of RCCL, which refuses two ranks on one device): the parent spawns the ranks, they run the sharded
+    update (dense first, then list exchanges), rank 0's line comes back with the run's own parity check green."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--particles-per-gpu", "131072", "--beam-step", "4", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["particles_total"] == 262144 and d["config"]["beams"] == 271
+    assert d["parity_check"]["logw_mismatches"] == 0 and d["parity_check"]["n"] == 4000
+    assert d["exchange_bytes_per_update_per_gpu"]["kind"] == "lists"
+    assert d["value"] > 0 and d["roofline"]["kernel"] == "k_rays_sweep"
