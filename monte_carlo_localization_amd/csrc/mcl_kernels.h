@@ -401,8 +401,10 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
             double u1 = (double)(bits53(o.v[0], o.v[1]) + 1) * TWO_M53;
             double u2 = (double)bits53(o.v[2], o.v[3]) * TWO_M53;
             double rad = sqrt(-2.0 * log(u1));
-            n0 = rad * cos(TWO_PI * u2);
-            n1 = rad * sin(TWO_PI * u2);
+            double sn, cs;
+            sincos(TWO_PI * u2, &sn, &cs);            // one argument reduction for the pair; the values are those of sin() and cos()
+            n0 = rad * cs;
+            n1 = rad * sn;
             o = philox4x32((uint32_t)g, a.update_idx, 1u, (uint32_t)(g >> 32), a.seed_lo, a.seed_hi);
             u1 = (double)(bits53(o.v[0], o.v[1]) + 1) * TWO_M53;
             u2 = (double)bits53(o.v[2], o.v[3]) * TWO_M53;
@@ -411,14 +413,19 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
         }
         double nx, ny, nth;
         if (fabs(a.w) < 1e-6) {                       // cpp:480-484
-            nx = x + a.v * a.dt * cos(th);
-            ny = y + a.v * a.dt * sin(th);
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            nx = x + a.v * a.dt * cs;
+            ny = y + a.v * a.dt * sn;
             nth = th;
         } else {                                      // cpp:485-493
             double radius = a.v / a.w;
             double dth = a.w * a.dt;
-            nx = x + radius * (sin(th + dth) - sin(th));
-            ny = y - radius * (cos(th + dth) - cos(th));
+            double s0, c0, s1, c1;
+            sincos(th, &s0, &c0);
+            sincos(th + dth, &s1, &c1);
+            nx = x + radius * (s1 - s0);
+            ny = y - radius * (c1 - c0);
             nth = th + dth;
         }
         nx += n0 * a.disp_x;                          // cpp:496-498
