@@ -62,6 +62,8 @@ struct mcl_engine {
     std::vector<float> angles;
     float *d_angle = nullptr;
     double2 *d_beam_cs = nullptr;
+    double2 *d_beam_csx = nullptr;      // k_rays_sweep's copy with virtual beams either side (set_beam_angles)
+    int beam_pad = 0, beam_margin = 0;
     int32_t *d_obs_idx = nullptr;
     float *d_obs = nullptr;
     float *h_obs = nullptr;             // pinned staging for the per-update scan
@@ -402,7 +404,7 @@ int ensure_lt(mcl_engine *h)
         HIPCHK(h, hipMalloc(&h->d_Lt, 2 * need * sizeof(float)));      // [Lt | Lt with the rows reversed (k_rays_cell)]
         h->lt_capacity = need;
     }
-    h->ltd_cols = (h->B + 64) & ~63;                                    // at least one all-zero column after the last beam
+    h->ltd_cols = (h->B + 2 * h->beam_margin + 64) & ~63;              // beam j in column j + beam_margin; at least one all-zero column after the last beam
     const size_t need_d = (size_t)mcl::sweep_table_rows(h->P) * h->ltd_cols;
     if (need_d > h->ltd_capacity) {
         dfree(h->d_Ltd);
@@ -767,6 +769,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
             if (rc_plan) return rc_plan;
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
+            a.beam_csx = h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
                 HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
@@ -854,7 +857,7 @@ void stage_observation(mcl_engine *h, const float *obs, int stride)
 void build_ltd(mcl_engine *h)
 {
     dim3 gd((h->ltd_cols + 255) / 256, mcl::sweep_table_rows(h->P));
-    hipLaunchKernelGGL(mcl::k_build_ltd, gd, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->ltd_cols, h->P, h->d_Ltd);
+    hipLaunchKernelGGL(mcl::k_build_ltd, gd, dim3(256), 0, h->stream, h->d_L, h->d_obs_idx, h->B, h->ltd_cols, h->P, h->beam_margin, h->d_Ltd);
     h->ltd_ready = true;
 }
 
@@ -1098,7 +1101,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1241,7 +1244,34 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
         double a = (double)angles[j < n_beams ? j : n_beams - 1];   // cpp:533 widens the float angle
         cs[j] = make_double2(std::cos(a), std::sin(a));
     }
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_obs_idx); dfree(h->d_obs);
+    // k_rays_sweep pads the lanes whose scan begins or ends inside a wedge with virtual beams -- the angular grid of the scan
+    // continued beyond its ends -- up to the beams of a full wedge.  Only for an evenly spaced scan (every angle within a quarter
+    // of the spacing of the grid through the first and the last) that leaves a wedge of the turn uncovered (no second range).
+    h->beam_pad = 0; h->beam_margin = 0;
+    const double span = n_beams > 1 ? (double)angles[n_beams - 1] - (double)angles[0] : 0.0;
+    const double inc = n_beams > 1 ? span / (double)(n_beams - 1) : 0.0;
+    const double wedge = 2.0 * M_PI / (double)mcl::kWedges;
+    if (h->quad_ok && inc > 0.0 && span + wedge < 2.0 * M_PI - 1e-3 && !getenv("MCL_NO_BEAM_PAD")) {
+        bool regular = true;
+        for (int j = 0; j < n_beams && regular; ++j)
+            regular = std::fabs((double)angles[j] - ((double)angles[0] + (double)j * inc)) < 0.25 * inc;
+        const double per_wedge = wedge / inc;
+        if (regular && per_wedge >= 2.0 && per_wedge <= 120.0) {
+            h->beam_pad = (int)std::ceil(per_wedge - 1e-9);          // (beam_pad - 1) spacings are less than a wedge
+            h->beam_margin = (h->beam_pad + 2 + 7) & ~7;
+        }
+    }
+    const int ncsx = n_beams + 2 * h->beam_margin + 8;
+    std::vector<double2> csx(ncsx);
+    for (int i = 0; i < ncsx; ++i) {
+        const int j = i - h->beam_margin;
+        double a;
+        if (j >= 0 && j < n_beams) a = (double)angles[j];
+        else if (h->beam_margin > 0) a = (double)angles[0] + (double)j * inc;
+        else a = (double)angles[j < 0 ? 0 : n_beams - 1];
+        csx[i] = make_double2(std::cos(a), std::sin(a));
+    }
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_obs_idx); dfree(h->d_obs);
     if (h->h_obs) { (void)hipHostFree(h->h_obs); h->h_obs = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_obs, (size_t)n_beams * sizeof(float)));
     HIPCHK(h, hipHostMalloc(&h->h_obs, (size_t)n_beams * sizeof(float)));
@@ -1250,6 +1280,8 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     HIPCHK(h, hipMalloc(&h->d_obs_idx, (size_t)n_beams * sizeof(int32_t)));
     HIPCHK(h, hipMemcpy(h->d_angle, angles, (size_t)n_beams * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)ncs * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&h->d_beam_csx, (size_t)ncsx * sizeof(double2)));
+    HIPCHK(h, hipMemcpy(h->d_beam_csx, csx.data(), (size_t)ncsx * sizeof(double2), hipMemcpyHostToDevice));
     h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd); h->ltd_ready = false;
     h->B = n_beams;
     return MCL_OK;

@@ -633,6 +633,8 @@ struct RayArgs {
     int64_t n;
     int B, bpad, P;
     const double2 *beam_cs;        // (cos a_j, sin a_j) of (double)angle_f32[j], host fp64
+    const double2 *beam_csx;       // k_rays_sweep: the same with beam_margin virtual beams before beam 0 and after beam B - 1 (entry j + beam_margin)
+    int beam_pad, beam_margin;     // beams of a full wedge up to which a scan-edge lane is padded with virtual beams (0: never); see k_rays_sweep
     const float *beam_angle;       // float angles (MARCH path uses theta + (double)angle)
     double beam_a0, beam_inv_inc;  // first angle and beams per radian (k_rays_cell's guess of a wedge's first beam)
     const float *Lt;               // (P+1) x bpad

@@ -38,20 +38,22 @@ __host__ __device__ inline bool sweep_window_fits(int P) { return kSwSide - (P +
 __host__ __device__ inline int sweep_table_rows(int P) { return P + kSwUnder + 2; }
 
 // Ltd[r][j]: r = left + kSwUnder for left in [-kSwUnder, P] -> (double)L[obs_idx[j]][P - max(left, 0)];
-// r = P + kSwUnder + 1 -> 0 (undecided rays: k_rays_fix adds their entry); columns j >= B are 0 (lanes without rays).
-__global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int cols, int P,
+// r = P + kSwUnder + 1 -> 0 (undecided rays: k_rays_fix adds their entry).  Beam j lives in column j + margin; the columns
+// before beam 0 and from beam B on are 0 (lanes without rays, and the virtual beams that pad a scan-edge wedge, see k_rays_sweep).
+__global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restrict__ obs_idx, int B, int cols, int P, int margin,
                             double *__restrict__ Ltd)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;        // column c holds beam c - margin
     const int r = blockIdx.y;
-    if (j >= cols) return;
+    if (c >= cols) return;
+    const int j = c - margin;
     double v = 0.0;
-    if (j < B && r <= P + kSwUnder) {
+    if (j >= 0 && j < B && r <= P + kSwUnder) {
         const int left = r - kSwUnder;
         const int d = P - (left > 0 ? left : 0);
         v = (double)L[(size_t)obs_idx[j] * (P + 1) + d];
     }
-    Ltd[(size_t)r * cols + j] = v;
+    Ltd[(size_t)r * cols + c] = v;
 }
 
 // Units of the sorted order: at most kSwUnit consecutive slots each, ub[u] = first slot of unit u, ub[M] = n, *m_out = M.
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2), \
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
         : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e),       \
-          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_cs), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
+          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
           [sel] "s"(permsel), [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff),          \
           [lb] "n"(kQLdsBase)                                                                                                  \
         : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
@@ -502,22 +504,40 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // direction components in the mirrored window: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
         const double dsc = sxp ? kSwDirScale : -kSwDirScale;
         const double aq = live ? pci.x * dsc : 0.0, bq = live ? pci.y * dsc : 0.0;
-        int tmax = total, tmin = live ? total : 0x7fffffff;
+        // A lane whose scan BEGINS or ENDS inside this wedge has fewer beams here than the lanes whose scan covers the wedge
+        // (with sixty-four headings 20 degrees apart -- the chunks of a uniform cloud -- anything from 1 to a full wedge's 90),
+        // and the lock-step walk below only runs as far as the shortest lane goes: the rest went through the slow per-slot loop,
+        // which made such a chunk several times slower than its fifteen neighbours and the workgroup wait for it.  Such a lane now
+        // continues on VIRTUAL beams -- the scan's angular grid continued beyond its ends (host: beam_csx), table columns all
+        // zero -- up to the common length: its rays there are walked and add 0.0.  beam_pad = beams of a full wedge (0: scan not
+        // evenly spaced or too wide, no padding).
+        const bool edge = a.beam_pad > 0 && (n1 + n2 > 0) && n2 == 0 && ((ja == 0) != (jb == a.B));
+        int tmax = total, tmin = (total > 0 && !edge) ? total : 0x7fffffff, temax = edge ? total : 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { tmax = max(tmax, __shfl_xor(tmax, o, 64)); tmin = min(tmin, __shfl_xor(tmin, o, 64)); }
+        for (int o = 32; o > 0; o >>= 1) {
+            tmax = max(tmax, __shfl_xor(tmax, o, 64)); tmin = min(tmin, __shfl_xor(tmin, o, 64)); temax = max(temax, __shfl_xor(temax, o, 64));
+        }
         tmax = __builtin_amdgcn_readfirstlane(tmax);
         tmin = __builtin_amdgcn_readfirstlane(tmin);
+        temax = __builtin_amdgcn_readfirstlane(temax);
+        if (temax > 0) {                      // the common length: the shortest full lane, or the longest edge lane if there is no full one
+            int tstar = tmin != 0x7fffffff ? tmin : temax;
+            tmin = tstar < a.beam_pad ? tstar : a.beam_pad;
+        }
+        const bool padded = edge && total < tmin;
         // a second range only exists for scans wider than three quadrants; the common case steps j by one
         const bool wraps = __builtin_amdgcn_readfirstlane((int)(__ballot(n2 > 0 && n1 > 0) != 0ull)) != 0;
         const int jfirst = n1 > 0 ? ja : (n2 > 0 ? ja2 : 0);
+        const int jwalk = padded && ja == 0 ? jb - tmin : jfirst;       // first (possibly virtual) beam of the lock-step walk
         double acc_fast = 0.0, acc = 0.0;
         uint32_t ambcnt = 0, ambj1 = 0, ambj2 = 0;
         int t_done = 0;
         bool expired_fast = false;
         if (!COUNT && !a.steps && !wraps && tmax > 0 && tmin > 0) {
-            uint32_t j16 = live ? (uint32_t)jfirst << 4 : 0u;
+            // beam_csx and the table's columns are biased by beam_margin entries (virtual beams before beam 0)
+            uint32_t j16 = live ? (uint32_t)(jwalk + a.beam_margin) << 4 : 0u;
             // table column offset, biased by kSwUnder rows so that (samples left) * row bytes + j8b is never negative
-            uint32_t j8b = (uint32_t)kSwUnder * st8 + (live ? (uint32_t)jfirst << 3 : (uint32_t)a.B << 3);
+            uint32_t j8b = (uint32_t)kSwUnder * st8 + ((uint32_t)((live ? jwalk : a.B) + a.beam_margin) << 3);
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             uint32_t tc = (uint32_t)tmin - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
@@ -602,7 +622,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 if (valid && !amb) {
                     const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
                     lt_pending = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.Ltd) +
-                                                                   mad_u24_s((uint32_t)(left + kSwUnder), st8, (uint32_t)jcur << 3));
+                                                                   mad_u24_s((uint32_t)(left + kSwUnder), st8, (uint32_t)(jcur + a.beam_margin) << 3));
                     if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
                 }
                 if (amb) {
@@ -618,8 +638,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         if (!live) ambcnt = 0u;                                    // a lane without rays traces a dummy ray: nothing to redo
         if (ambcnt != 0u) {
             const int nlist = ambcnt > 2u ? t_done : (int)ambcnt;
+            const int jr0 = n1 > 0 ? ja : ja2, jr1 = n1 > 0 ? jb : a.B;      // the lane's real beams of this walk (virtual ones add 0 whatever they hit)
             for (int k = 0; k < nlist; ++k) {
-                const int jamb = ambcnt > 2u ? jfirst + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1;
+                const int jamb = ambcnt > 2u ? jwalk + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1 - a.beam_margin;
+                if (jamb < jr0 || jamb >= jr1) continue;
                 const unsigned int fslot = atomicAdd(&fixn_sh, 1u);
                 if (fslot < a.fix_cap) fix_seg[fslot] = ((unsigned long long)sl << 16) | (unsigned long long)(jamb & 0xFFFF);
             }

@@ -374,3 +374,32 @@ def test_both_orderings_give_the_oracles_sums(orc, engine_mod, spielberg, spielb
         got, _ = sweep_logw(engine_mod, spielberg, ang, p, obs)
         pick = np.random.default_rng(10).choice(n, 5000, replace=False)
         assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs)), cloud
+
+
+@pytest.mark.parametrize("scan", ["regular-1081", "regular-1000", "regular-361", "jittered-721", "no-pad-env"])
+def test_scan_edge_wedges_with_headings_apart(orc, engine_mod, spielberg, spielberg_oracle, monkeypatch, scan):
+    """A lane whose scan begins or ends inside the wedge being walked has fewer beams there than its neighbours; it continues
+    on VIRTUAL beams (the scan's angular grid continued beyond its ends, zero table columns) so that the lock-step walk covers
+    every lane's real beams.  Uniform cloud: the 64 headings of a chunk are ~20 degrees apart, so chunks with such lanes are
+    everywhere.  Scans whose wedge holds a whole number of beams (1081 over 270 degrees: 90), a fraction (1000: 83.3; 361: 30),
+    an unevenly spaced scan (padding off: the grid cannot be continued) and MCL_NO_BEAM_PAD all give the oracle's sums."""
+    from monte_carlo_localization_amd import synth
+    rng = np.random.default_rng(21)
+    if scan == "no-pad-env":
+        monkeypatch.setenv("MCL_NO_BEAM_PAD", "1")
+    if scan.startswith("regular") or scan == "no-pad-env":
+        B = int(scan.split("-")[1]) if scan.startswith("regular") else 541
+        ang = (np.float32(-0.75 * np.pi) + np.arange(B, dtype=np.float32) * np.float32(1.5 * np.pi / (B - 1))).astype(np.float32)
+    else:
+        B = 721
+        base = -0.75 * np.pi + np.arange(B) * (1.5 * np.pi / (B - 1))
+        ang = np.sort((base + rng.uniform(-0.45, 0.45, B) * (1.5 * np.pi / (B - 1))).astype(np.float32))
+        assert np.all(np.diff(ang) > 0)
+    full = scan1081()
+    obs = np.interp(np.linspace(0.0, 1080.0, B), np.arange(1081), full).astype(np.float32)
+    n = 120000
+    p = synth.global_cloud(np.random.default_rng(22), spielberg, n)
+    p[:2] += np.random.default_rng(23).uniform(0.1, 0.9, (2, n)) * float(np.float32(spielberg.resolution))
+    got, _ = sweep_logw(engine_mod, spielberg, ang, p, obs)
+    pick = np.random.default_rng(24).choice(n, 4000, replace=False)
+    assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs))

@@ -9,7 +9,8 @@ n = 4 << 20
 e = engine.Engine(max_particles=n, seed=42)
 e.set_map(m.data, m.resolution, m.origin_x, m.origin_y); e.set_beam_angles(ang)
 scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
-p = synth.tracking_cloud(np.random.default_rng(42), n)
+regime = sys.argv[1] if len(sys.argv) > 1 else "tracking"      # usage: wg_stamps.py [tracking|global]
+p = synth.tracking_cloud(np.random.default_rng(42), n) if regime == "tracking" else synth.global_cloud(np.random.default_rng(42), m, n)
 e.set_particles(p, np.full(n, 1.0 / n))
 for k in range(6):
     e.update((0.05, 0.0, 0.01), scan)
