@@ -297,6 +297,12 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 r0 = g * 4294967296ull + a.k0;
                 lmul = (uint64_t)a.n_children_total * 4294967296ull;
             }
+            // "entry c is above the threshold": c * lmul > r0 * r1 in exact 128-bit arithmetic.  With the multinomial draw's
+            // lmul = 2^53 that is c > floor(r0 r1 / 2^53) for the integer c: one product per child instead of one per probe
+            // (the search was a sixth of this kernel's instructions); the systematic comb keeps the product form.
+            const bool by_thr = a.mode == 0;
+            const uint64_t thr = (__umul64hi(r0, r1) << 11) | ((r0 * r1) >> 53);
+            auto above = [&](uint64_t c) -> bool { return by_thr ? c > thr : mul_gt(c, lmul, r0, r1); };
             if (a.ccdf) {
                 // compact list: first group of 64 whose last entry exceeds the threshold (ctop: dense, a few KB), then
                 // inside that group's 512 bytes
@@ -304,14 +310,14 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 int64_t glo = 0, glen = ng;
                 while (glen > 0) {
                     int64_t half = glen >> 1, mid = glo + half;
-                    if (!mul_gt(a.ctop[mid], lmul, r0, r1)) { glo = mid + 1; glen = glen - half - 1; }
+                    if (!above(a.ctop[mid])) { glo = mid + 1; glen = glen - half - 1; }
                     else glen = half;
                 }
                 int64_t lo = glo << kCompactGroupShift;
                 int64_t len = (lo + (1 << kCompactGroupShift) <= a.n_compact) ? (1 << kCompactGroupShift) : a.n_compact - lo;
                 while (len > 0) {
                     int64_t half = len >> 1, mid = lo + half;
-                    if (!mul_gt(a.ccdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
+                    if (!above(a.ccdf[mid])) { lo = mid + 1; len = len - half - 1; }
                     else len = half;
                 }
                 cpos = (lo >= a.n_compact) ? a.n_compact - 1 : lo;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                 int64_t tlo = 0, tlen = ntiles;           // first tile whose exclusive prefix exceeds the threshold
                 while (tlen > 0) {
                     int64_t half = tlen >> 1, mid = tlo + half;
-                    if (!mul_gt(a.tile_excl[mid], lmul, r0, r1)) { tlo = mid + 1; tlen = tlen - half - 1; }
+                    if (!above(a.tile_excl[mid])) { tlo = mid + 1; tlen = tlen - half - 1; }
                     else tlen = half;
                 }
                 const int64_t t = tlo > 0 ? tlo - 1 : 0;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
                     int64_t glo = g0, glen = ng;
                     while (glen > 0) {
                         int64_t half = glen >> 1, mid = glo + half;
-                        if (!mul_gt(a.leaders[mid], lmul, r0, r1)) { glo = mid + 1; glen = glen - half - 1; }
+                        if (!above(a.leaders[mid])) { glo = mid + 1; glen = glen - half - 1; }
                         else glen = half;
                     }
                     if (glo >= g0 + ng) glo = g0 + ng - 1;          // threshold beyond the tile (only at the very end)
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
             }
             while (len > 0) {
                 int64_t half = len >> 1, mid = lo + half;
-                if (!mul_gt(cdf[mid], lmul, r0, r1)) { lo = mid + 1; len = len - half - 1; }
+                if (!above(cdf[mid])) { lo = mid + 1; len = len - half - 1; }
                 else len = half;
             }
             idx = (lo >= a.n_parents) ? a.n_parents - 1 : lo;
