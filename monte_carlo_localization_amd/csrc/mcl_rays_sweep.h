@@ -440,12 +440,21 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // The waves take 64-slot chunks of the run from a counter instead of a fixed stride: a wave whose particles had short rays
     // takes another chunk while the slow ones finish, so the barrier before the next window waits for the slowest CHUNK, not
     // for the slowest of sixteen fixed shares (the window phase, barrier waits included, was 9 % of a workgroup's time)
+    // A pass of at most eight chunks (the runs of a sparse cloud cut at tile or bucket borders) would leave half of the sixteen
+    // waves or more without work: its chunks are handed out in pieces -- the same 64 slots, 1/parts of their beams -- so that
+    // chunks x parts ~ 16.  A piece repeats the per-particle setup and its load latencies (about a tenth of a chunk), which is
+    // why longer passes are left alone (quartering the last 16 chunks of every pass: 3 % slower on the tracking cloud).
+    const uint32_t nchunks = (p_end - p_begin + 63u) >> 6;
+    const uint32_t parts_all = (COUNT || a.steps || nchunks > 8u) ? 1u : nchunks > 4u ? 2u : nchunks > 2u ? 4u : nchunks > 1u ? 8u : 16u;
+    const uint32_t npieces = nchunks * parts_all;
     for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(&chunk_sh, 1u);
-        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+        uint32_t piece = 0;
+        if (lane == 0) piece = atomicAdd(&chunk_sh, 1u);
+        piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
+        if (piece >= npieces) break;
+        // piece p = part p / nchunks of chunk p % nchunks: the first round gives every chunk's first part to a different wave
+        const uint32_t chunk = parts_all > 1u ? piece % nchunks : piece, part = parts_all > 1u ? piece / nchunks : 0u, parts = parts_all;
         const uint32_t s0g = p_begin + chunk * 64u;
-        if (s0g >= p_end) break;
         const uint32_t slot = s0g + (uint32_t)lane;
         const bool have = slot < p_end;
         const uint32_t sl = have ? slot : p_end - 1u;
@@ -533,18 +542,26 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         uint32_t ambcnt = 0, ambj1 = 0, ambj2 = 0;
         int t_done = 0;
         bool expired_fast = false;
-        if (!COUNT && !a.steps && !wraps && tmax > 0 && tmin > 0) {
+        const bool fast = !COUNT && !a.steps && !wraps && tmax > 0 && tmin > 0;
+        if (!fast && part > 0u) continue;                         // the slow forms of a pass are not split: piece 0 does all of it
+        int walk_t0 = 0, walk_n = 0;                               // slots [walk_t0, walk_t0 + walk_n) of every lane: this piece's share
+        if (fast) {
+            walk_t0 = (int)(((uint32_t)tmin * part) / parts);
+            walk_n = (int)(((uint32_t)tmin * (part + 1u)) / parts) - walk_t0;
+        }
+        if (fast && walk_n > 0) {
             // beam_csx and the table's columns are biased by beam_margin entries (virtual beams before beam 0)
-            uint32_t j16 = live ? (uint32_t)(jwalk + a.beam_margin) << 4 : 0u;
+            const int jw = jwalk + walk_t0;
+            uint32_t j16 = live ? (uint32_t)(jw + a.beam_margin) << 4 : 0u;
             // table column offset, biased by kSwUnder rows so that (samples left) * row bytes + j8b is never negative
-            uint32_t j8b = (uint32_t)kSwUnder * st8 + ((uint32_t)((live ? jwalk : a.B) + a.beam_margin) << 3);
+            uint32_t j8b = (uint32_t)kSwUnder * st8 + ((uint32_t)((live ? jw : a.B) + a.beam_margin) << 3);
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
-            uint32_t tc = (uint32_t)tmin - 1u, expired = 0u, cd;
+            uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
             if (negy) MCL_SW_WALK("-"); else MCL_SW_WALK("");
-            t_done = tmin;
             expired_fast = expired != 0u;
         }
+        if (fast) t_done = part + 1u == parts ? tmin : tmax;       // the ragged rest belongs to the last piece
         // ---- remaining slots (lanes differ in how many rays they have), scans that wrap, probe counting, step output ----
         if (t_done < tmax) {
             // slot t of this lane is beam ja + t for t < n1, then ja2 + (t - n1); past its last slot a lane repeats
@@ -637,10 +654,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         if (expired_fast) ambcnt = 3u;
         if (!live) ambcnt = 0u;                                    // a lane without rays traces a dummy ray: nothing to redo
         if (ambcnt != 0u) {
-            const int nlist = ambcnt > 2u ? t_done : (int)ambcnt;
+            const int nlist = ambcnt > 2u ? walk_n : (int)ambcnt;
             const int jr0 = n1 > 0 ? ja : ja2, jr1 = n1 > 0 ? jb : a.B;      // the lane's real beams of this walk (virtual ones add 0 whatever they hit)
             for (int k = 0; k < nlist; ++k) {
-                const int jamb = ambcnt > 2u ? jwalk + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1 - a.beam_margin;
+                const int jamb = ambcnt > 2u ? jwalk + walk_t0 + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1 - a.beam_margin;
                 if (jamb < jr0 || jamb >= jr1) continue;
                 const unsigned int fslot = atomicAdd(&fixn_sh, 1u);
                 if (fslot < a.fix_cap) fix_seg[fslot] = ((unsigned long long)sl << 16) | (unsigned long long)(jamb & 0xFFFF);
