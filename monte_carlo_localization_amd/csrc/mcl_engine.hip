@@ -159,7 +159,9 @@ struct mcl_engine {
     int env_sort_radix = -1;           // MCL_SORT=radix / hist forces one ordering path; default: by size
     uint32_t *d_tile_used = nullptr;    // one mark per kHistTile buckets of the sort histogram: touched by this update's sort
     uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
-    int *d_bbox = nullptr;              // 6: bounding box, occupied tiles, numbering in use
+    int *d_bbox = nullptr;              // 7: bounding box, occupied tiles, numbering in use, window play
+    uint32_t *d_cut_start = nullptr, *d_cut_end = nullptr;   // kSwMaxCuts each: where the buckets of a sparse set start / end in the radix-sorted order (zero between sorts)
+    bool env_no_bucket_cuts = false;    // MCL_NO_BUCKET_CUTS: sparse sets stay ordered by whole tiles whatever the window play
     int *d_tilemap = nullptr, *d_tilemark = nullptr;   // kSortMaxTiles each: tile of the map -> compact id; marks of the occupied tiles (zero between sorts)
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
     size_t slice_mean_capacity = 0;
@@ -500,8 +502,8 @@ void unpack_result(mcl_engine *h)
 
 // Work items of k_rays_sweep: made on the device from this update's unit statistics (k_sweep_plan, mcl_rays_sweep.h);
 // the host only sizes the list (every unit on its own, once per wedge group, is the longest it can get).
-// upper bound on the units of n sorted particles: the plain grid plus one cut per map tile (mcl::k_unit_table)
-int64_t max_sweep_units(int64_t n) { return (n + mcl::kSwUnit - 1) / mcl::kSwUnit + mcl::kSortMaxTiles + 2; }
+// upper bound on the units of n sorted particles: the plain grid plus one cut per bucket of a sparse set (mcl::k_unit_table)
+int64_t max_sweep_units(int64_t n) { return (n + mcl::kSwUnit - 1) / mcl::kSwUnit + mcl::kSwMaxCuts + 2; }
 
 int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
 {
@@ -680,6 +682,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over; clr.exact_count = h->d_result + 14;
             if (sweep) clr.far_count = h->d_result + 15;
             if (cell) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
+            clr.bbox_play = sweep && !h->env_no_bucket_cuts ? mcl::kSwSide - (h->P + 2) - 3 : 0;     // the window play k_sweep_plan works with
             if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
                 clr.logw_acc = nullptr; clr.far_flags = nullptr;
                 hipLaunchKernelGGL(mcl::k_prep_small, dim3(1), dim3(256), 0, h->stream, clr);
@@ -723,7 +726,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                                    h->d_tilemap, ntx_abs);
                 tb = h->sort_tmp_bytes;
                 HIPCHK(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tb, h->d_skey, h->d_skey2, h->d_srank, h->d_sval2, (size_t)n, 0, mcl::kSortKeyLog2, h->stream));
-                hipLaunchKernelGGL(mcl::k_sort_gather, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_sval2, h->d_pcs, h->d_ths, h->d_perm);
+                hipLaunchKernelGGL(mcl::k_sort_gather, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_sval2, h->d_pcs, h->d_ths, h->d_perm,
+                                   sweep ? h->d_skey2 : (const uint32_t *)nullptr, h->d_bbox, h->d_cut_start, h->d_cut_end);
             } else {
             hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
                                h->d_skey, h->d_srank, h->d_tile_used, h->d_tilemap, ntx_abs);
@@ -746,7 +750,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                 }
                 if (!h->d_nunits) HIPCHK(h, hipMalloc(&h->d_nunits, sizeof(int)));
                 hipLaunchKernelGGL(mcl::k_unit_table, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, n, h->d_hist, h->d_histpart, h->d_tile_used,
-                                   radix ? h->d_skey2 : (const uint32_t *)nullptr, h->d_unit_begin, h->d_nunits, (int)mu);
+                                   radix ? h->d_cut_start : (uint32_t *)nullptr, h->d_cut_end, h->d_unit_begin, h->d_nunits, (int)mu);
             }
             if (!radix) hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
             if (sweep) {
@@ -997,6 +1001,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     if (const char *e = getenv("MCL_NO_COMPACT")) h->env_no_compact = atoi(e);
     if (const char *e = getenv("MCL_SORT")) h->env_sort_radix = std::strcmp(e, "radix") == 0 ? 1 : (std::strcmp(e, "hist") == 0 ? 0 : -1);
     if (const char *e = getenv("MCL_DEBUG_WG")) h->env_debug_wg = e;
+    h->env_no_bucket_cuts = getenv("MCL_NO_BUCKET_CUTS") != nullptr;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
     auto bail = [&](const char *what) {
@@ -1053,6 +1058,10 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMemset(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4));          // kept all-zero between sorts (k_hist_clear)
     CRT(hipMemset(h->d_tile_used, 0, (size_t)(mcl::kSortKeySpace / mcl::kHistTile) * 4));
     CRT(hipMalloc(&h->d_bbox, 8 * sizeof(int)));
+    CRT(hipMalloc(&h->d_cut_start, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
+    CRT(hipMalloc(&h->d_cut_end, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
+    CRT(hipMemset(h->d_cut_start, 0, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
+    CRT(hipMemset(h->d_cut_end, 0, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
     CRT(hipMalloc(&h->d_tilemap, (size_t)mcl::kSortMaxTiles * sizeof(int)));
     CRT(hipMalloc(&h->d_tilemark, (size_t)mcl::kSortMaxTiles * sizeof(int)));
     CRT(hipMemset(h->d_tilemark, 0, (size_t)mcl::kSortMaxTiles * sizeof(int)));
@@ -1098,7 +1107,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
     dfree(h->d_gcdf); dfree(h->d_gtop);
     dfree(h->d_blockcnt); dfree(h->d_ccdf); dfree(h->d_ctop); dfree(h->d_cidx); dfree(h->d_crec);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_cut_start); dfree(h->d_cut_end); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);

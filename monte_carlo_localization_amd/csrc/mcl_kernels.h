@@ -748,7 +748,8 @@ struct PrepClear {
     unsigned long long *fix_over;      // 2 words (overflow flag, work counter)
     unsigned long long *exact_count;   // 1 word
     unsigned long long *far_count;     // 1 word
-    int *bbox;                         // 4: +big, +big, -big, -big
+    int *bbox;                         // 4: +big, +big, -big, -big; [4], [5]: k_tile_compact; [6] = bbox_play
+    int bbox_play;                     // cells a ray window leaves for the particles of a work item (0: no windowed kernel): sort_layout
     uint32_t *hist;                    // hist_n bucket counters
     uint32_t hist_n;
 };
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
     if (clr.fix_over) for (int64_t k = i; k < 2; k += n) clr.fix_over[k] = 0ull;
     if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
     if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
-    if (clr.bbox) for (int64_t k = i; k < 6; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (k < 4 ? (int)0x80000000 : 0);
+    if (clr.bbox) for (int64_t k = i; k < 7; k += n) clr.bbox[k] = k < 2 ? 0x7fffffff : (k < 4 ? (int)0x80000000 : (k == 6 ? clr.bbox_play : 0));
     if (clr.hist) for (int64_t k = i; k < clr.hist_n; k += n) clr.hist[k] = 0u;
     const double t = th[i];
     pc[i] = particle_constants(x[i], y[i], t, ox, oy, res);
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256) void k_prep_small(PrepClear clr)
     if (clr.fix_over && i < 2) clr.fix_over[i] = 0ull;
     if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
     if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
-    if (clr.bbox && i < 6) clr.bbox[i] = i < 2 ? 0x7fffffff : (i < 4 ? (int)0x80000000 : 0);
+    if (clr.bbox && i < 7) clr.bbox[i] = i < 2 ? 0x7fffffff : (i < 4 ? (int)0x80000000 : (i == 6 ? clr.bbox_play : 0));
 }
 
 // D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
@@ -1572,9 +1573,13 @@ struct SortLayout {
     uint32_t ntx;
     int tx0, ty0;
     bool compact;
+    bool sparse;                      // ordered by whole buckets of 2^cs x 2^cs cells (a spread cloud): units are cut at their borders
     uint64_t ntiles;
     __device__ __forceinline__ int tile_shift() const { return 2 * inner + 2 * ss + tb; }
+    __device__ __forceinline__ int cut_shift() const { return 2 * ss + tb; }                         // key bits below the bucket
+    __device__ __forceinline__ uint64_t cut_groups() const { return ntiles << (2 * inner); }         // buckets of the key space
 };
+constexpr int kSwMaxCuts = 65536;     // buckets up to which a sparse set's units are cut at bucket borders (k_unit_table)
 __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, int64_t n)
 {
     SortLayout L;
@@ -1596,7 +1601,15 @@ __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, 
     // (first update of the global regime: ray kernel 13.8 -> 11.4 ms).  A dense set keeps single cells: there the
     // compactness of a unit is what the windows and the probe loop live on (coarser buckets cost 4-30 %).
     int cs = 0, tb = 6;
-    if (cells_est > 0.0 && (double)n < 8.0 * cells_est) cs = 5;
+    L.sparse = cells_est > 0.0 && (double)n < 8.0 * cells_est;
+    if (L.sparse) {
+        cs = 5;
+        // ... of the size the play of a ray window can hold: a unit is one bucket's particles, and a unit wider than the play
+        // loses its particles to the far pass (the levine stand-in's 239-px range leaves 12 cells: whole tiles put 3.5M of the
+        // 4M particles of a uniform cloud there, 35 ms).  Smaller buckets only while one still holds a couple of chunks.
+        const int play = bbox[6];
+        while (play > 0 && cs > 1 && (1 << cs) >= play - 2 && (double)n * (double)(1 << (2 * cs - 2)) >= 128.0 * cells_est) --cs;
+    }
     while (cs < 5 && ((L.ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) ++cs;
     while (tb > 0 && ((L.ntiles << (10 - 2 * cs + tb)) > kSortKeySpace)) --tb;
     const int inner = 5 - cs;                             // log2 of the bucket grid inside one tile
@@ -1776,9 +1789,14 @@ __global__ __launch_bounds__(256) void k_sort_keys(const double4 *__restrict__ p
                           c.z * kSortSub - floor(c.z * kSortSub), c.w * kSortSub - floor(c.w * kSortSub));
     val_out[i] = (uint32_t)i;
 }
+// cut_start[g] + 1 / cut_end[g]: first slot + 1 and end of bucket g in the sorted order (0 / anything: nobody there), written where
+// the sorted keys change bucket -- what k_unit_table needs to cut a sparse set's units at bucket borders (it zeroes the
+// entries it reads).  sorted_keys null: no borders wanted.
 __global__ __launch_bounds__(256) void k_sort_gather(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n,
                                                     const uint32_t *__restrict__ order, double4 *__restrict__ pcs, double *__restrict__ ths,
-                                                    uint32_t *__restrict__ perm)
+                                                    uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_keys = nullptr,
+                                                    const int *__restrict__ bbox = nullptr, uint32_t *__restrict__ cut_start = nullptr,
+                                                    uint32_t *__restrict__ cut_end = nullptr)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
@@ -1786,6 +1804,19 @@ __global__ __launch_bounds__(256) void k_sort_gather(const double4 *__restrict__
     pcs[s] = pc[i];
     ths[s] = th[i];
     perm[s] = i;
+    if (sorted_keys) {
+        const SortLayout L = sort_layout(bbox, n);
+        if (L.sparse && L.compact && L.cut_groups() <= (uint64_t)kSwMaxCuts) {
+            const int sh = L.cut_shift();
+            const uint32_t g = sorted_keys[s] >> sh;
+            const uint32_t gp = s > 0 ? sorted_keys[s - 1] >> sh : 0xFFFFFFFFu;
+            if (g != gp && g < (uint32_t)kSwMaxCuts) {
+                cut_start[g] = (uint32_t)s + 1u;
+                if (s > 0 && gp < (uint32_t)kSwMaxCuts) cut_end[gp] = (uint32_t)s;
+            }
+            if (s == n - 1 && g < (uint32_t)kSwMaxCuts) cut_end[g] = (uint32_t)n;
+        }
+    }
 }
 
 // after the scatter: the used tiles of the histogram (all XCD copies) and their marks back to zero, so that the next

@@ -57,47 +57,53 @@ __global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restri
 }
 
 // Units of the sorted order: at most kSwUnit consecutive slots each, ub[u] = first slot of unit u, ub[M] = n, *m_out = M.
-// A set ordered by whole map tiles (SortLayout: one group of heading buckets per 32 x 32-cell tile -- the sparse cloud of a
-// global re-localisation) is cut at the tile borders as well: the particles of a unit then lie within ONE tile, which the
-// play of a window covers at ranges up to 256 - 35 - 5 = 216 px, where a unit that straddles two tiles (64 x 32 cells or
-// worse) loses its minority side to the far pass.  Any other set gets the plain grid of kSwUnit slots.
-// hist: the bucket offsets k_hist_final left (copy of XCD 0 = the first slot of a bucket), part: the exclusive prefix of the
-// histogram tiles' totals (the offset of every bucket of a tile nobody fell into).  One workgroup.
+// A SPARSE set (SortLayout: ordered by whole buckets of cells -- 32 x 32 tiles, or smaller ones where the play of a window is
+// less than a tile -- with the heading below: the spread cloud of a global re-localisation) is cut at the bucket borders as
+// well: the particles of a unit then lie within ONE bucket, which the play of a window covers, where a unit that straddles
+// two (64 x 32 cells or worse) loses its minority side to the far pass.  Any other set gets the plain grid of kSwUnit slots.
+// Where a bucket starts: counting sort -- hist, the bucket offsets k_hist_final left (copy of XCD 0 = the first slot of a key),
+// and part, the exclusive prefix of the histogram tiles' totals (the offset of every key of a tile nobody fell into); radix
+// sort -- cut_start / cut_end, written by k_sort_gather where the sorted keys change bucket (zeroed here for the next update).
+// One workgroup.
 __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbox, int64_t n, const uint32_t *__restrict__ hist,
                                                     const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_used,
-                                                    const uint32_t *__restrict__ sorted_keys, uint32_t *__restrict__ ub, int *__restrict__ m_out,
-                                                    int max_units)
+                                                    uint32_t *__restrict__ cut_start, uint32_t *__restrict__ cut_end, uint32_t *__restrict__ ub,
+                                                    int *__restrict__ m_out, int max_units)
 {
     __shared__ uint32_t ws[16];
     __shared__ uint32_t carry_sh;
     const SortLayout L = sort_layout(bbox, n);
-    const int shift = L.tile_shift();
-    const bool tilecut = L.compact && shift <= 12 && (int64_t)L.ntiles <= (int64_t)kSortMaxTiles + 1 && (L.ntiles << shift) <= kSortKeySpace;
+    const int shift = L.cut_shift();
+    const bool cut = L.sparse && L.compact && L.cut_groups() <= (uint64_t)kSwMaxCuts && (L.cut_groups() << shift) <= kSortKeySpace;
     const int64_t Mgrid = (n + kSwUnit - 1) / kSwUnit;
-    if (!tilecut) {
+    if (!cut) {
         for (int64_t u = threadIdx.x; u <= Mgrid; u += 1024) ub[u] = (uint32_t)(u * kSwUnit < n ? u * kSwUnit : n);
         if (threadIdx.x == 0) m_out[0] = (int)Mgrid;
         return;
     }
-    static_assert(kHistTile == 4096, "a map tile's buckets (at most 2^12) lie inside one histogram tile");
-    const int ntl = (int)L.ntiles;
+    static_assert(kHistTile == 4096, "a bucket's keys (at most 2^8 headings) lie inside one histogram tile");
+    const int ntl = (int)L.cut_groups();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_sh = 0u;
     __syncthreads();
-    auto start_of = [&](int t) -> uint32_t {
+    auto start_of = [&](int t) -> uint32_t {               // counting sort: first slot of bucket t's first key
         if (t >= ntl) return (uint32_t)n;
         const uint32_t key0 = (uint32_t)t << shift;
-        if (sorted_keys) {                          // radix-sorted keys: first slot whose key is not below the tile's first key
-            int64_t lo = 0, hi = n;
-            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < key0) lo = mid + 1; else hi = mid; }
-            return (uint32_t)lo;
-        }
         return tile_used[key0 >> 12] ? hist[key0] : part[key0 >> 12];
     };
     for (int t0 = 0; t0 < ntl; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
         uint32_t s0 = 0, cnt = 0;
-        if (t < ntl) { s0 = start_of(t); const uint32_t s1 = start_of(t + 1); cnt = s1 > s0 ? s1 - s0 : 0u; }
+        if (t < ntl) {
+            if (cut_start) {
+                const uint32_t a1 = cut_start[t];
+                if (a1 != 0u) { s0 = a1 - 1u; const uint32_t e = cut_end[t]; cnt = e > s0 ? e - s0 : 0u; cut_start[t] = 0u; cut_end[t] = 0u; }
+            } else {
+                s0 = start_of(t);
+                const uint32_t s1 = start_of(t + 1);
+                cnt = s1 > s0 ? s1 - s0 : 0u;
+            }
+        }
         const uint32_t nu = (cnt + kSwUnit - 1) / kSwUnit;
         uint32_t inc = nu;
 #pragma unroll
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     }
     if (threadIdx.x == 0) {
         int M = (int)carry_sh;
-        if (M > max_units) M = max_units;                  // cannot happen: max_units = ceil(n / kSwUnit) + tiles (never write out of bounds)
+        if (M > max_units) M = max_units;                  // cannot happen: max_units = ceil(n / kSwUnit) + buckets (never write out of bounds)
         ub[M] = (uint32_t)n;
         m_out[0] = M;
     }

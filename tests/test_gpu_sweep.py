@@ -256,13 +256,16 @@ def test_beam_count_multiple_of_256(orc, engine_mod, spielberg, spielberg_oracle
 
 
 @pytest.mark.parametrize("keep_steps", [0, 1])
-def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, sibal1, sibal1_oracle, spielberg, spielberg_oracle, keep_steps):
-    """The uniform cloud of a global re-localisation (cpp:401-446) on a map whose 240-px range leaves a window 11 cells of play:
+def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, sibal1, sibal1_oracle, spielberg, spielberg_oracle, keep_steps, monkeypatch):
+    """(MCL_NO_BUCKET_CUTS: with the cloud ordered by buckets the window play can hold -- the default since, see
+    test_narrow_play_sparse_cloud_is_cut_at_bucket_borders -- far fewer particles of this cloud are left for the far pass.)
+    The uniform cloud of a global re-localisation (cpp:401-446) on a map whose 240-px range leaves a window 11 cells of play:
     no 32 x 32-cell tile of particles fits, every (particle, quadrant) pair is flagged and goes to the windowed far pass
     (k_rays_skip<.., FAR> over the ordered list of flagged slots: 568-cell nibble windows, only the flagged quadrants' beams).
     Log-weights (and ray steps) equal the oracle's, bit for bit.  On Spielberg_map (44 cells of play) the same kind of cloud
     needs no far pass at all since the units of a sparse set are cut at the tile borders."""
     from monte_carlo_localization_amd import synth
+    monkeypatch.setenv("MCL_NO_BUCKET_CUTS", "1")
     ang = orc.beam_angles(angle_step=4)
     obs = np.full(ang.size, 3.0, np.float32)
     n = 100000
@@ -403,3 +406,31 @@ def test_scan_edge_wedges_with_headings_apart(orc, engine_mod, spielberg, spielb
     got, _ = sweep_logw(engine_mod, spielberg, ang, p, obs)
     pick = np.random.default_rng(24).choice(n, 4000, replace=False)
     assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs))
+
+
+@pytest.mark.parametrize("how", ["hist", "radix"])
+def test_narrow_play_sparse_cloud_is_cut_at_bucket_borders(orc, engine_mod, sibal1, sibal1_oracle, monkeypatch, how):
+    """sibal1's 239-px range leaves 12 cells of play in a 256-cell window: a uniform cloud ordered by whole 32 x 32 tiles lost most
+    of its particles to the far pass.  A sparse set is now ordered by buckets the play can hold (8 x 8 cells here) and its units
+    are cut at the bucket borders -- from the bucket offsets of the counting sort, or from where the radix-sorted keys change
+    bucket -- so the windowed kernel keeps (nearly) all of them; the sums equal the oracle's either way, and over an update."""
+    from monte_carlo_localization_amd import synth
+    monkeypatch.setenv("MCL_SORT", how)
+    ang = orc.beam_angles(angle_step=8)
+    scan = scan1081()[::8].copy()
+    n = 200000
+    p = synth.global_cloud(np.random.default_rng(3), sibal1, n)
+    p[:2] += np.random.default_rng(4).uniform(0.1, 0.9, (2, n)) * float(np.float32(sibal1.resolution))
+    e = make_engine(engine_mod, sibal1, ang, n)
+    e.set_particles(p, np.full(n, 1.0 / n))
+    e.sensor_update(scan)
+    assert e.ray_kernel_name() == "k_rays_sweep"
+    c = e.counters()
+    assert c["off_window_particles"] < n // 50, c
+    got = e.log_weights()
+    pick = np.random.default_rng(5).choice(n, 4000, replace=False)
+    assert np.array_equal(got[pick], oracle_logw(orc, sibal1_oracle, p[:, pick], ang, scan))
+    e.update((0.05, 0.0, 0.01), scan)                      # resample + motion + the same stage on the children
+    q = e.get_particles()
+    assert np.array_equal(e.log_weights()[pick], oracle_logw(orc, sibal1_oracle, q[:, pick], ang, scan))
+    e.close()
