@@ -1578,8 +1578,14 @@ struct SortLayout {
     __device__ __forceinline__ int tile_shift() const { return 2 * inner + 2 * ss + tb; }
     __device__ __forceinline__ int cut_shift() const { return 2 * ss + tb; }                         // key bits below the bucket
     __device__ __forceinline__ uint64_t cut_groups() const { return ntiles << (2 * inner); }         // buckets of the key space
+    // units are cut at the bucket borders (k_sort_gather notes the borders, k_unit_table uses them: one rule for both)
+    __device__ __forceinline__ bool cuts() const;
 };
 constexpr int kSwMaxCuts = 65536;     // buckets up to which a sparse set's units are cut at bucket borders (k_unit_table)
+__device__ __forceinline__ bool SortLayout::cuts() const
+{
+    return sparse && compact && cut_groups() <= (uint64_t)kSwMaxCuts && (cut_groups() << cut_shift()) <= kSortKeySpace;
+}
 __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, int64_t n)
 {
     SortLayout L;
@@ -1806,7 +1812,7 @@ __global__ __launch_bounds__(256) void k_sort_gather(const double4 *__restrict__
     perm[s] = i;
     if (sorted_keys) {
         const SortLayout L = sort_layout(bbox, n);
-        if (L.sparse && L.compact && L.cut_groups() <= (uint64_t)kSwMaxCuts) {
+        if (L.cuts()) {
             const int sh = L.cut_shift();
             const uint32_t g = sorted_keys[s] >> sh;
             const uint32_t gp = s > 0 ? sorted_keys[s - 1] >> sh : 0xFFFFFFFFu;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     __shared__ uint32_t carry_sh;
     const SortLayout L = sort_layout(bbox, n);
     const int shift = L.cut_shift();
-    const bool cut = L.sparse && L.compact && L.cut_groups() <= (uint64_t)kSwMaxCuts && (L.cut_groups() << shift) <= kSortKeySpace;
+    const bool cut = L.cuts();
     const int64_t Mgrid = (n + kSwUnit - 1) / kSwUnit;
     if (!cut) {
         for (int64_t u = threadIdx.x; u <= Mgrid; u += 1024) ub[u] = (uint32_t)(u * kSwUnit < n ? u * kSwUnit : n);
