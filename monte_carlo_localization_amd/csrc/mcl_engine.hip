@@ -161,7 +161,7 @@ struct mcl_engine {
     uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
     int *d_bbox = nullptr;              // 7: bounding box, occupied tiles, numbering in use, window play
     uint32_t *d_cut_start = nullptr, *d_cut_end = nullptr;   // kSwMaxCuts each: where the buckets of a sparse set start / end in the radix-sorted order (zero between sorts)
-    bool env_no_bucket_cuts = false;    // MCL_NO_BUCKET_CUTS: sparse sets stay ordered by whole tiles whatever the window play
+    bool env_no_bucket_cuts = false;    // MCL_NO_BUCKET_CUTS: units on the plain grid of 1024 slots, sparse sets ordered by whole tiles (rounds 2-3 before the cuts)
     int *d_tilemap = nullptr, *d_tilemark = nullptr;   // kSortMaxTiles each: tile of the map -> compact id; marks of the occupied tiles (zero between sorts)
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
     size_t slice_mean_capacity = 0;
@@ -682,7 +682,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over; clr.exact_count = h->d_result + 14;
             if (sweep) clr.far_count = h->d_result + 15;
             if (cell) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
-            clr.bbox_play = sweep && !h->env_no_bucket_cuts ? mcl::kSwSide - (h->P + 2) - 3 : 0;     // the window play k_sweep_plan works with
+            // the window play k_sweep_plan works with (0: no windowed kernel; -1: no cuts at all, MCL_NO_BUCKET_CUTS)
+            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? mcl::kSwSide - (h->P + 2) - 3 : 0);
             if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
                 clr.logw_acc = nullptr; clr.far_flags = nullptr;
                 hipLaunchKernelGGL(mcl::k_prep_small, dim3(1), dim3(256), 0, h->stream, clr);

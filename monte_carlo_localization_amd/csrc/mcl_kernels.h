@@ -1573,18 +1573,22 @@ struct SortLayout {
     uint32_t ntx;
     int tx0, ty0;
     bool compact;
+    bool nocut;                       // bbox[6] < 0 (MCL_NO_BUCKET_CUTS): the plain grid of units, sparse sets by whole tiles
     bool sparse;                      // ordered by whole buckets of 2^cs x 2^cs cells (a spread cloud): units are cut at their borders
     uint64_t ntiles;
     __device__ __forceinline__ int tile_shift() const { return 2 * inner + 2 * ss + tb; }
-    __device__ __forceinline__ int cut_shift() const { return 2 * ss + tb; }                         // key bits below the bucket
-    __device__ __forceinline__ uint64_t cut_groups() const { return ntiles << (2 * inner); }         // buckets of the key space
-    // units are cut at the bucket borders (k_sort_gather notes the borders, k_unit_table uses them: one rule for both)
+    // Units are cut where the sorted order changes GROUP: a sparse set's bucket, a dense set's 32 x 32 tile (a set that sits on
+    // a few far-apart clusters -- the steady state of a global re-localisation -- otherwise has units that end in one cluster
+    // and begin in the next, whose minority side no window reaches: 0.85 ms of far pass per update at 4M on ~30 clusters).
+    __device__ __forceinline__ int cut_shift() const { return sparse ? 2 * ss + tb : tile_shift(); }                 // key bits below the group
+    __device__ __forceinline__ uint64_t cut_groups() const { return sparse ? ntiles << (2 * inner) : ntiles; }       // groups of the key space
+    // (k_sort_gather notes the borders, k_unit_table uses them: one rule for both)
     __device__ __forceinline__ bool cuts() const;
 };
 constexpr int kSwMaxCuts = 65536;     // buckets up to which a sparse set's units are cut at bucket borders (k_unit_table)
 __device__ __forceinline__ bool SortLayout::cuts() const
 {
-    return sparse && compact && cut_groups() <= (uint64_t)kSwMaxCuts && (cut_groups() << cut_shift()) <= kSortKeySpace;
+    return compact && !nocut && cut_groups() <= (uint64_t)kSwMaxCuts && (cut_groups() << cut_shift()) <= kSortKeySpace;
 }
 __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, int64_t n)
 {
@@ -1607,6 +1611,7 @@ __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, 
     // (first update of the global regime: ray kernel 13.8 -> 11.4 ms).  A dense set keeps single cells: there the
     // compactness of a unit is what the windows and the probe loop live on (coarser buckets cost 4-30 %).
     int cs = 0, tb = 6;
+    L.nocut = bbox[6] < 0;
     L.sparse = cells_est > 0.0 && (double)n < 8.0 * cells_est;
     if (L.sparse) {
         cs = 5;

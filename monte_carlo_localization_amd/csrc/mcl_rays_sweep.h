@@ -71,7 +71,8 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
                                                     int *__restrict__ m_out, int max_units)
 {
     __shared__ uint32_t ws[16];
-    __shared__ uint32_t carry_sh;
+    __shared__ uint32_t carry_sh, nbig_sh;
+    __shared__ uint4 big_sh[1024];
     const SortLayout L = sort_layout(bbox, n);
     const int shift = L.cut_shift();
     const bool cut = L.cuts();
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     static_assert(kHistTile == 4096, "a bucket's keys (at most 2^8 headings) lie inside one histogram tile");
     const int ntl = (int)L.cut_groups();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_sh = 0u;
+    if (threadIdx.x == 0) { carry_sh = 0u; nbig_sh = 0u; }
     __syncthreads();
     auto start_of = [&](int t) -> uint32_t {               // counting sort: first slot of bucket t's first key
         if (t >= ntl) return (uint32_t)n;
@@ -112,10 +113,23 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
         __syncthreads();
         uint32_t at = carry_sh + inc - nu;
         for (int k = 0; k < wv; ++k) at += ws[k];
-        for (uint32_t j = 0; j < nu; ++j)
-            if (at + j < (uint32_t)max_units) ub[at + j] = s0 + j * kSwUnit;
+        // a group of a few units is written by its thread; a long one (a dense set has thousands of particles per tile) by all
+        if (nu <= 4u) {
+            for (uint32_t j = 0; j < nu; ++j)
+                if (at + j < (uint32_t)max_units) ub[at + j] = s0 + j * kSwUnit;
+        } else {
+            const uint32_t e = atomicAdd(&nbig_sh, 1u);
+            big_sh[e] = make_uint4(at, s0, nu, 0u);
+        }
         __syncthreads();
+        for (uint32_t e = 0; e < nbig_sh; ++e) {
+            const uint4 b = big_sh[e];
+            for (uint32_t j = threadIdx.x; j < b.z; j += 1024u)
+                if (b.x + j < (uint32_t)max_units) ub[b.x + j] = b.y + j * kSwUnit;
+        }
         if (threadIdx.x == 1023) carry_sh = at + nu;
+        __syncthreads();
+        if (threadIdx.x == 0) nbig_sh = 0u;
         __syncthreads();
     }
     if (threadIdx.x == 0) {

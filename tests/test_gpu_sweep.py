@@ -291,7 +291,8 @@ def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, sibal1, sibal
     if keep_steps:
         assert np.array_equal(e.ray_steps()[pick], steps)
     e.close()
-    # Spielberg_map, same kind of cloud: units cut at the tile borders fit their windows
+    # Spielberg_map, same kind of cloud: units cut at the tile borders fit their windows (the default order again)
+    monkeypatch.delenv("MCL_NO_BUCKET_CUTS")
     q = synth.global_cloud(np.random.default_rng(7), spielberg, 200000)
     q[:2] += np.random.default_rng(8).uniform(0.1, 0.9, (2, 200000)) * float(np.float32(spielberg.resolution))
     obs2 = scan1081()[::4].copy()
@@ -299,7 +300,9 @@ def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, sibal1, sibal
     assert c2["off_window_particles"] < 0.02 * 200000
     pick2 = np.random.default_rng(9).choice(200000, 4000, replace=False)
     assert np.array_equal(got2[pick2], oracle_logw(orc, spielberg_oracle, q[:, pick2], ang, obs2))
-    # a handful of stragglers beside a tight cloud: below the threshold, k_rays_far keeps them
+    # a handful of stragglers beside a tight cloud on the plain grid of units: below the threshold, k_rays_far keeps them
+    # (with the cuts they are a unit of their own: test_far_apart_clusters_need_no_far_pass)
+    monkeypatch.setenv("MCL_NO_BUCKET_CUTS", "1")
     t = tracking_cloud(np.random.default_rng(7), 70000, sig=(0.2, 0.2, 0.4))
     t[0, :500] += 40.0
     got3, c3 = sweep_logw(engine_mod, spielberg, ang, t, obs2)
@@ -434,3 +437,22 @@ def test_narrow_play_sparse_cloud_is_cut_at_bucket_borders(orc, engine_mod, siba
     q = e.get_particles()
     assert np.array_equal(e.log_weights()[pick], oracle_logw(orc, sibal1_oracle, q[:, pick], ang, scan))
     e.close()
+
+
+@pytest.mark.parametrize("how", ["hist", "radix"])
+def test_far_apart_clusters_need_no_far_pass(orc, engine_mod, spielberg, spielberg_oracle, monkeypatch, how):
+    """A set that sits on a few far-apart clusters (the steady state of a global re-localisation): the units of the sorted
+    order are cut at the 32 x 32-cell tile borders, so no unit ends in one cluster and begins in the next (whose minority
+    side no window would reach).  No particle is left for the far pass, whichever sort made the order; the oracle's sums."""
+    monkeypatch.setenv("MCL_SORT", how)
+    ang = orc.beam_angles(angle_step=4)
+    obs = scan1081()[::4].copy()
+    n = 180000
+    rng = np.random.default_rng(31)
+    centres = np.array([[0.0, 0.0, 0.0], [14.0, 3.0, 1.0], [-20.0, 9.0, -2.0], [5.5, -11.0, 3.0], [-7.0, 30.0, 0.5]])
+    which = rng.integers(0, len(centres), n)
+    p = (centres[which] + rng.normal(0.0, 1.0, (n, 3)) * np.array([0.12, 0.12, 0.2])).T.copy()
+    got, c = sweep_logw(engine_mod, spielberg, ang, p, obs)
+    assert c["off_window_particles"] == 0, c
+    pick = rng.choice(n, 4000, replace=False)
+    assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs))
