@@ -5,7 +5,7 @@ os.environ["MCL_DEBUG_WG"] = "/tmp/wg.bin"
 from monte_carlo_localization_amd import engine, maps, synth
 m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
 ang = synth.beam_angles()
-n = 4 << 20
+n = int(os.environ.get("WG_N", 4 << 20))
 e = engine.Engine(max_particles=n, seed=42)
 e.set_map(m.data, m.resolution, m.origin_x, m.origin_y); e.set_beam_angles(ang)
 scan = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
