@@ -891,6 +891,7 @@ void graph_reset(mcl_engine *h)
     for (int k = 0; k < 2; ++k)
         if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
     h->graph_warm = false;
+    h->pc_ready = false;                    // whatever changed (map, beams, particles, a buffer): the ray stage makes its own constants
 }
 
 int sensor_and_weights(mcl_engine *h, const double *d_global_max)
@@ -2085,8 +2086,18 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     if (action) motion_scalars(action, a.dt, a.v, a.w);
     a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
     a.do_resample = 1; a.do_motion = 1;
+    if (!index_only) {
+        // as in mcl_update: the ray stage's per-particle constants (and its zeroed per-particle scratch) come out of this
+        // kernel, a pass over the children less in mcl_stage_rays
+        const int rmode = choose_ray_mode(h, n, false);
+        if (rmode == 2 || rmode >= 4) {
+            a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
+            if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
+        }
+    }
     hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
+    h->pc_ready = a.pc_out != nullptr;
     if (index_only) {
         HIPCHK(h, hipMemcpyAsync(src.idx_only_out, h->d_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
         h->have_idx = true;
