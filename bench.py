@@ -27,6 +27,7 @@ tenth of those samples (same results) and is NOT a bound.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -129,7 +130,7 @@ def _sha16(path):
         return None
 
 
-def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True):
+def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_live=None):
     """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time.
 
     gfx950 issues a wave64 instruction of the simple classes (v_add/v_sub/v_and/v_or/v_lshrrev/v_mov, fp32 add/mul/fma) in
@@ -146,7 +147,17 @@ def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True):
     alg = {"bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar, "achieved": alg_bytes / (k_ms * 1e-3) / 1e9,
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "note": "SURVEY 8(d) algorithmic bytes / kernel time / 8 TB/s: not a bound (the kernel skips ~90 % of the priced samples)"}
-    block = {"bound": "valu", "kernel": kernel_name, "kernel_ms": k_ms, "algorithmic": alg, "traffic": None}
+    block = {"bound": "valu", "kernel": kernel_name, "kernel_ms": k_ms, "algorithmic": alg, "traffic": None, "useful": None}
+    # USEFUL work, live: what the rays of this launch need with all 64 lanes busy -- per ray 11 VALU instructions outside the
+    # probe loop (9 four-cycle + 2 two-cycle: rotation of the beam direction, table offset, sums) and 7 per probe trip (5 + 2:
+    # MCL_SW_TRIP) -- priced at the class rates against 1024 SIMDs x 2.4 GHz.  Unlike `frac` the numerator does not grow with
+    # the kernel's own instruction count: idle lanes in the probe loop, per-chunk set-up, window loads and barriers all lower it.
+    if trips_live is not None and kernel_name == "k_rays_sweep":
+        per_ray_cycles = (9 * 4 + 2 * 2) + (5 * 4 + 2 * 2) * trips_live
+        useful_ms = n * B / 64.0 * per_ray_cycles / (SIMDS * MAX_CLOCK_GHZ * 1e6)
+        block["useful"] = {"frac": useful_ms / k_ms, "floor_ms": useful_ms, "rays": n * B, "probe_trips_per_ray": trips_live,
+                           "valu_per_ray": 11 + 7 * trips_live, "issue_cycles_per_ray": per_ray_cycles,
+                           "note": "rays x (11 + 7 x live trips per ray) VALU at the class rates / 64 lanes / (1024 SIMDs x 2.4 GHz) / live kernel ms"}
     inp = None
     if os.path.exists(ROOFLINE_INPUTS):
         try:
@@ -186,8 +197,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--beam-step", type=int, default=1, help="keep every k-th of the 1081 beams (angle_step, cpp:307-310)")
-    ap.add_argument("--map", choices=["spielberg", "levine"], default="spielberg",
-                    help="levine = the synthetic 2049x2049 @0.05 stand-in (maps/levine.pgm is absent from the reference)")
+    ap.add_argument("--map", choices=["spielberg", "levine", "fine025"], default="spielberg",
+                    help="levine = the synthetic 2049x2049 @0.05 stand-in (maps/levine.pgm is absent from the reference); fine025 = "
+                         "a synthetic 0.025 m map (MAX_RANGE_PX = 479: cpp:195 puts no bound on it), the long-range case")
     ap.add_argument("--regime", choices=["tracking", "global"], default="tracking")
     ap.add_argument("--resample", choices=["multinomial", "systematic"], default="multinomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,6 +232,12 @@ def launch_ranks(n_ranks):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's stdout is a pipe: it is drained while the ranks run (a line longer than the pipe buffer would otherwise block
+    # rank 0 in write() while this process waits for it to exit)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     failed = None
     live = set(range(n_ranks))
     while live and failed is None:
@@ -242,7 +260,8 @@ def launch_ranks(n_ranks):
                 procs[r].kill()
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
         raise SystemExit(1)
-    out = procs[0].stdout.read().decode()
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode()
     sys.stdout.write(out)
     sys.stdout.flush()
     if not out.strip():
@@ -274,6 +293,9 @@ def main():
     if args.map == "spielberg":
         m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
         true_pose = TRUE_POSE
+    elif args.map == "fine025":
+        m = maps.synthetic_fine025(maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz")))
+        true_pose = TRUE_POSE
     else:
         m = maps.synthetic_levine()
         true_pose = (-34.0, -34.9, 0.0)          # corridor centre near the lower-left corner of the loop
@@ -297,6 +319,7 @@ def main():
     e = engine.Engine(max_particles=n, device=local_rank, seed=42, resample_mode=mode)
     e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
     e.set_beam_angles(ang)
+    planned_kernel, planned_reason = e.planned_ray_kernel(n)      # known before the first update (mcl_get_planned_ray_kernel)
     # noise-free scan from the true pose: the committed fixture (tests assert the engine regenerates it
     # bit for bit); keeps the profiled run free of a stray 1-particle k_rays launch
     if args.map == "spielberg":
@@ -362,6 +385,31 @@ def main():
     pose = sf.expected_pose() if use_dist else e.expected_pose()
     counters = e.counters()
     exit_code = 0
+    kernel_name = e.ray_kernel_name()
+
+    # ---- after the timed region: the state the last timed update left, then ONE more untimed update (probe counter on) whose
+    #      resample indices the oracle checks.  A sharded run gathers every rank's log-weights and children's parents on rank 0
+    #      (all ranks take part in the two gathers), so that a line with N > 1 proves its indices like the single-GPU line does.
+    n_total = n * world
+    pt_last = e.get_particles() if rank == 0 else None
+    lw_last = e.log_weights()
+    lw_all, idx_all, probes_live = (lw_last if world == 1 else None), None, None
+    if not args.no_parity_check:
+        def gather_all(a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if args.backend == "nccl":
+                t = t.to(torch.device("cuda", local_rank))
+            out = torch.empty(t.numel() * world, dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t)
+            return out.cpu().numpy() if rank == 0 else None
+        if world > 1:
+            lw_all = gather_all(lw_last)
+        e.set_debug_count_probes(1)
+        step()
+        e.set_debug_count_probes(0)
+        probes_live = e.counters()["probes"] / float(n * B)
+        idx_mine = np.ascontiguousarray(e.resample_indices(), np.int32)
+        idx_all = gather_all(idx_mine) if world > 1 else idx_mine
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
@@ -369,43 +417,46 @@ def main():
         base, sbar_first, sbar_timed = None, None, None
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(m, ang, scan, true_pose, big=args.cpu_baseline_256k)
-        parity, probes_live, sbar_err = None, None, None
+        parity, sbar_err = None, None
+        orc = None
         try:
-            # The oracle as the CHECKER of the run that was just timed (never inside the timed region): the log-weights the
-            # last timed update left for 4000 sampled particles against orc_eng_log_weights on those particles (which also
-            # gives S-bar, the reference's samples per ray, cpp:622-647), then one more UNTIMED update -- with the probe
-            # counter on, for the live trips per ray -- whose resample indices are compared with the oracle's exact-CDF
-            # draw from the weights the timed update left (all children; single-engine path).
+            # the oracle is test infrastructure: a box without it (no gcc, no oracle/) still gets its line, marked unchecked
             from oracle import oracle as orc
+            orc.lib()
+        except (ImportError, OSError, subprocess.CalledProcessError) as ex:
+            orc, sbar_err = None, repr(ex)
+        if orc is not None:
+            # The oracle as the CHECKER of the run that was just timed (never inside the timed region): the log-weights the
+            # last timed update left for 4000 sampled particles of rank 0 against orc_eng_log_weights on those particles (which
+            # also gives S-bar, the reference's samples per ray, cpp:622-647), then the resample indices of the untimed update
+            # above -- all children of all ranks -- against the oracle's exact-CDF draw from the weights the timed update left.
+            # An oracle error or a mismatch from here on fails the run.
             om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
             L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
             oi = orc.obs_index(scan, om)
-            pt, lw = e.get_particles(), e.log_weights()
             pick = np.random.default_rng(7).choice(n, size=min(4000, n), replace=False)
-            logw_o, _, probes_o = orc.eng_log_weights(om, np.ascontiguousarray(pt[:, pick]), ang, oi, L)
+            logw_o, _, probes_o = orc.eng_log_weights(om, np.ascontiguousarray(pt_last[:, pick]), ang, oi, L)
             sbar_timed = probes_o / float(pick.size * B)
             _, _, probes_f = orc.eng_log_weights(om, sample_first, ang, oi, L)
             sbar_first = probes_f / float(sample_first.shape[1] * B)
-            parity = {"n": int(pick.size), "logw_mismatches": int(np.count_nonzero(lw[pick] != logw_o))}
-            del pt
-            if not args.no_parity_check and not use_dist:
-                _, q_prev, _ = orc.eng_weights_from_log(lw)
-                e.set_debug_count_probes(1)
-                e.update(ACTION, scan)
-                e.set_debug_count_probes(0)
-                probes_live = e.counters()["probes"] / float(n * B)
+            parity = {"n": int(pick.size), "logw_mismatches": int(np.count_nonzero(lw_last[pick] != logw_o))}
+            if idx_all is not None:
+                _, q_prev, _ = orc.eng_weights_from_log(lw_all)          # fixed-point weights of the WHOLE set (global maximum)
                 if mode == engine.RESAMPLE_MULTINOMIAL:
-                    want = orc.eng_resample_indices(q_prev, 0, k53=orc.eng_philox_k53(42, n_updates, 0, n))
+                    want = orc.eng_resample_indices(q_prev, 0, k53=orc.eng_philox_k53(42, n_updates, 0, n_total))
                 else:
                     want = orc.eng_resample_indices(q_prev, 1, k0=orc.eng_philox_k0(42, n_updates))
-                parity.update({"idx_n": int(n), "idx_mismatches": int(np.count_nonzero(e.resample_indices() != want))})
+                parity.update({"idx_n": int(n_total), "idx_mismatches": int(np.count_nonzero(idx_all != want)),
+                               "idx_scope": "all children of all ranks (global parent indices)" if world > 1 else "all children"})
                 del q_prev, want
-            del lw
-        except ImportError as ex:
-            sbar_err = repr(ex)                  # no oracle on this box: the algorithmic figure falls back to the survey's value
+        del pt_last, lw_all, idx_all
         k_ms = float(np.mean(ray_ms))
-        roof = roofline_block(e.ray_kernel_name(), k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4,
-                              profiled_workload=(args.map == "spielberg" and args.regime == "tracking"))
+        roof = roofline_block(kernel_name, k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4,
+                              profiled_workload=(args.map == "spielberg" and args.regime == "tracking"), trips_live=probes_live)
+        # which kernel class AUTO gave this map / scan / size, and why, when it is not the fast windowed kernel
+        roof["kernel_class_planned"] = planned_kernel
+        if kernel_name != "k_rays_sweep":
+            roof["kernel_class_reason"] = planned_reason
         roof["algorithmic"]["s_bar_first_update"] = sbar_first
         # what the kernel itself examines: loop trips per ray counted by an extra, untimed update (debug_count_probes)
         roof["probe_trips_per_ray_live"] = probes_live
@@ -416,6 +467,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n} particles/GPU x {B} beams, "
                                    + ("Spielberg_map (2000x2000 @ 0.05796), " if args.map == "spielberg"
+                                      else "SYNTHETIC Spielberg_map grid split 2 x 2 per cell and declared 0.025 m (4000x4000, MAX_RANGE_PX 479), " if args.map == "fine025"
                                       else "SYNTHETIC levine stand-in (2049x2049 @ 0.05), ")
                                    + (f"initial cloud N({true_pose},(0.5 m,0.5 m,0.4 rad)) (tracking regime), " if args.regime == "tracking"
                                       else "initial cloud uniform over the free cells (global regime), ")

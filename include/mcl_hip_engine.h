@@ -207,6 +207,13 @@ int mcl_set_debug_count_probes(mcl_engine_t *h, int32_t on);
 int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
 /* which ray kernel the last update ran: 1 k_rays_march, 2 k_rays_skip, 3 k_rays_quad, 4 k_rays_cell, 5 k_rays_sweep */
 int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel);
+/* Which ray kernel an update over n_particles (<= 0: the active count, or max_particles before any particles are set) WILL run
+ * with the current configuration, map and beam set -- the same pure function mcl_update consults, callable before the first
+ * update (needs the map and the beam angles).  *kernel as mcl_get_ray_kernel_id, 0 = the configured kernel cannot run with
+ * this map / beam set (mcl_update would return MCL_ERR_UNSUPPORTED).  *reason (may be NULL) receives a static string naming
+ * what decided, e.g. why AUTO stays off k_rays_sweep: the fast windowed kernels need beam angles that increase over less
+ * than a turn and MAX_RANGE_PX <= 243; anything else takes k_rays_skip (same results, several times slower at size). */
+int mcl_get_planned_ray_kernel(const mcl_engine_t *h, int64_t n_particles, int32_t *kernel, const char **reason);
 /* Effective sample size (sum w)^2 / sum w^2 of the current weights, and whether the last mcl_update resampled
  * (always 1 with resample_neff_permille == 0). */
 int mcl_get_effective_sample_size(const mcl_engine_t *h, double *n_eff, int32_t *resampled_last_update);
@@ -339,8 +346,9 @@ int mcl_group_get_particles(mcl_group_t *g, double *xyz, int64_t n_total);
 int mcl_group_get_weights(mcl_group_t *g, double *weights, int64_t n_total);
 int mcl_group_get_resample_indices(mcl_group_t *g, int32_t *idx, int64_t n_total);   /* global parent indices */
 int mcl_group_get_stage_timings(const mcl_group_t *g, double ms[6]);           /* per stage: the slowest device */
-/* bytes the last update moved between devices: [0] received PER DEVICE for the parent population -- the other shards' compact
- * lists (44 B per particle that carries weight) or, when some shard had no list, their fixed-point weights (8 B per particle);
+/* bytes the last update moved between devices: [0] received by the device that received MOST for the parent population -- the
+ * other shards' compact lists (44 B per particle that carries weight, copied entry-exact) or, when some shard had no list, their
+ * fixed-point weights (8 B per particle);
  * [1] parent records read from peers by ALL devices (weights exchange only; children with a remote parent x 32 B: an upper
  * bound, a shared parent is cached after its first fetch).  mcl_group_exchanged_lists: 1 when the last update exchanged lists. */
 int mcl_group_exchange_bytes(const mcl_group_t *g, uint64_t out[2]);

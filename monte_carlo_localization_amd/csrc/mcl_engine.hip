@@ -77,6 +77,8 @@ struct mcl_engine {
     int ltd_cols = 0;
     bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
+    bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
+    bool skip_layout_ok = false;        // k_rays_skip has no static LDS (its window is addressed from LDS offset 0)
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
     int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), planned on the device every update
     int4 *d_centres = nullptr;          // per run of units: window centre, first unit, units (k_sweep_plan)
@@ -526,24 +528,43 @@ int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
 
 // Which ray kernel a launch over n particles takes: 1 march, 2 skip, 3 quad, 4 cell, 5 sweep; 0 = the configured kernel
 // cannot run with this map / beam set.  A pure function of the configuration, the map, the beam set and n, so that
-// callers (graph eligibility, table building) can ask before anything is launched.
-int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip)
+// callers (graph eligibility, table building, mcl_get_planned_ray_kernel) can ask before anything is launched.  *why, when
+// given, receives a static sentence saying what decided (the kernels that address their LDS window from a raw offset are
+// only chosen when the host-side layout check of mcl_create passed: no configuration can make the device abort).
+int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char **why = nullptr)
 {
+    const char *dummy;
+    const char *&w = why ? *why : dummy;
     const int rk = h->cfg.ray_kernel;
-    if (rk == MCL_RAYS_MARCH) return 1;
-    if (rk == MCL_RAYS_SKIP || force_skip) return 2;
-    const bool windows_ok = h->quad_ok && h->qside > 0;      // monotone beams over less than a turn, room for a byte window
-    if (rk == MCL_RAYS_QUAD) return windows_ok ? 3 : 0;
-    if (rk == MCL_RAYS_CELL) return windows_ok ? 4 : 0;
+    if (rk == MCL_RAYS_MARCH) { w = "configured: MCL_RAYS_MARCH"; return 1; }
+    // k_rays_skip without its LDS layout (never seen): the literal march, same results
+    if (rk == MCL_RAYS_SKIP || force_skip) {
+        if (!h->skip_layout_ok) { w = "k_rays_skip's LDS layout check failed at mcl_create: literal march"; return 1; }
+        w = force_skip ? "fix-up list overflow: the stage is re-run with k_rays_skip" : "configured: MCL_RAYS_SKIP";
+        return 2;
+    }
+    const char *no_windows = nullptr;                        // why the windowed kernels (quad / cell / sweep) are out, if they are
+    if (!h->quad_ok) no_windows = "beam angles are not monotone over less than a turn (or more than 16383 beams): the windowed kernels need contiguous beam ranges per direction wedge";
+    else if (h->qside <= 0) no_windows = "MAX_RANGE_PX leaves less than 32 cells of play in a 280-cell byte window: the windowed kernels cannot hold a ray";
+    const bool windows_ok = no_windows == nullptr;           // monotone beams over less than a turn, room for a byte window
+    if (rk == MCL_RAYS_QUAD) { w = windows_ok && h->quad_layout_ok ? "configured: MCL_RAYS_QUAD" : (no_windows ? no_windows : "k_rays_quad's LDS layout check failed"); return windows_ok && h->quad_layout_ok ? 3 : 0; }
+    if (rk == MCL_RAYS_CELL) { w = windows_ok && h->cell_layout_ok ? "configured: MCL_RAYS_CELL" : (no_windows ? no_windows : "k_rays_cell's LDS layout check failed"); return windows_ok && h->cell_layout_ok ? 4 : 0; }
     // its windows are 256 cells wide (mcl_rays_sweep.h) and addressed from a raw LDS offset checked at mcl_create
-    const bool sweep_ok = windows_ok && mcl::sweep_window_fits(h->P) && h->sweep_layout_ok;
-    if (rk == MCL_RAYS_SWEEP) return sweep_ok ? 5 : 0;
+    const char *no_sweep = no_windows;
+    if (!no_sweep && !mcl::sweep_window_fits(h->P)) no_sweep = "MAX_RANGE_PX > 243: a 256-cell window of k_rays_sweep cannot hold a ray plus 8 cells of play";
+    if (!no_sweep && !h->sweep_layout_ok) no_sweep = "k_rays_sweep's LDS layout check failed at mcl_create";
+    const bool sweep_ok = no_sweep == nullptr;
+    if (rk == MCL_RAYS_SWEEP) { w = sweep_ok ? "configured: MCL_RAYS_SWEEP" : no_sweep; return sweep_ok ? 5 : 0; }
     // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
     // with 64-particle groups and enough rays to amortise the sort (measured, wall ms skip / quad / cell:
     // 4096 x 1081 0.16/0.28/0.40, 65536 x 1081 0.55/0.56/0.44, 65536 x 61 0.21/0.33/0.25, 262144 x 61 0.47/0.76/0.40);
     // below that the self-contained k_rays_skip (one launch, no work lists) is the quickest
     const int64_t cell_min = h->env_cell_min > 0 ? h->env_cell_min : 65536;
-    if (windows_ok && n >= cell_min && n * (int64_t)h->B >= (8 << 20)) return sweep_ok ? 5 : 4;
+    const bool big = n >= cell_min && n * (int64_t)h->B >= (8 << 20);
+    if (big && sweep_ok) { w = "AUTO: at least 65536 particles and 2^23 rays, monotone beams, MAX_RANGE_PX <= 243"; return 5; }
+    if (big && windows_ok && h->cell_layout_ok) { w = no_sweep; return 4; }
+    if (!h->skip_layout_ok) { w = "k_rays_skip's LDS layout check failed at mcl_create: literal march"; return 1; }
+    w = !big ? "AUTO: fewer than 65536 particles or 2^23 rays: the self-contained k_rays_skip is the quickest" : no_sweep;
     return 2;
 }
 
@@ -1086,12 +1107,22 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_sweep_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    {   // k_rays_sweep addresses its window from the raw LDS offset kQLdsBase: its static LDS must end exactly there.  A
-        // toolchain that lays the two static words out differently turns AUTO back to k_rays_cell instead of a device trap
-        hipFuncAttributes fa0{}, fa1{};
-        const bool ok0 = hipFuncGetAttributes(&fa0, reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>)) == hipSuccess;
-        const bool ok1 = hipFuncGetAttributes(&fa1, reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>)) == hipSuccess;
-        h->sweep_layout_ok = ok0 && ok1 && fa0.sharedSizeBytes == (size_t)mcl::kQLdsBase && fa1.sharedSizeBytes == (size_t)mcl::kQLdsBase;
+    {   // The hand-written probe loops address their LDS window from a raw offset: k_rays_sweep / k_rays_cell / k_rays_quad
+        // from kQLdsBase (their static LDS must end exactly there), k_rays_skip from 0 (it must have no static LDS).  A
+        // toolchain that lays a kernel out differently takes that kernel out of choose_ray_mode's choices -- the engine then
+        // runs the next one down, same results -- so that no configuration can reach a malformed launch.
+        auto static_lds_is = [](const void *fn, size_t want) {
+            hipFuncAttributes fa{};
+            return hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes == want;
+        };
+        const size_t qb = (size_t)mcl::kQLdsBase;
+        h->sweep_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), qb);
+        h->cell_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), qb);
+        h->quad_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), qb);
+        h->skip_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), 0) &&
+                            static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false, true>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true, true>), 0) &&
+                            static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<3, false>), 0) &&
+                            static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<4, false>), 0);
         (void)hipGetLastError();
     }
 #undef CRT
@@ -1829,6 +1860,17 @@ int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel)
 {
     if (!h || !kernel) return MCL_ERR_INVALID_ARG;
     *kernel = h->last_mode;
+    return MCL_OK;
+}
+
+int mcl_get_planned_ray_kernel(const mcl_engine_t *h, int64_t n_particles, int32_t *kernel, const char **reason)
+{
+    if (!h || !kernel) return MCL_ERR_INVALID_ARG;
+    if (!h->have_map || h->B <= 0) return MCL_ERR_NOT_READY;
+    const int64_t n = n_particles > 0 ? n_particles : (h->have_particles ? h->N : h->cap);
+    const char *why = "";
+    *kernel = choose_ray_mode(h, n, false, &why);
+    if (reason) *reason = why ? why : "";
     return MCL_OK;
 }
 
@@ -2690,7 +2732,10 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
     g->q_total = qt;
     for (int d = 0; d < G; ++d) mcl_stage_finish(g->eng[d], gs);
     // received per device: the other shards' lists / weights; parents read from peers (dense exchange only)
-    g->bytes_weights = compact ? (listed - (uint64_t)(listed / G)) * 44u : (uint64_t)(G - 1) * (uint64_t)n * 8u;
+    // (lists are copied entry-exact, not as padded chunks: the device that holds the shortest list receives the most)
+    uint64_t shortest = ~0ull;
+    for (int d = 0; d < G; ++d) shortest = std::min<uint64_t>(shortest, compact ? (uint64_t)counts[d] : 0u);
+    g->bytes_weights = compact ? (listed - shortest) * 44u : (uint64_t)(G - 1) * (uint64_t)n * 8u;
     g->bytes_parents = compact ? 0u : (uint64_t)remote * 32u;         // upper bound: children of remote parents x record size
     g->compact_last = compact;
     for (int k = 0; k < 5; ++k) {

@@ -997,8 +997,8 @@ __global__ __launch_bounds__(kRayThreads) void k_rays_skip(RayArgs a)
     }
     const unsigned char *ldsb = lds_raw;
     const int ngroups = (a.B + 64 * R - 1) / (64 * R);
-    // the level-1 loop addresses the window with raw LDS offsets: the dynamic segment must start at 0
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != 0u) __builtin_trap();
+    // the level-1 loop addresses the window with raw LDS offsets: the dynamic segment must start at 0, i.e. the kernel has no
+    // static LDS -- checked on the host at mcl_create (hipFuncGetAttributes), which keeps the engine off this kernel otherwise
     // level-1 error bound: (1 + s) / 2 units for s <= P samples (+ 4 of slack); kG1 covers the byte ranges
     const uint32_t g1 = (uint32_t)a.P > 255u ? (uint32_t)(a.P + 2) / 2u + 4u : kG1;
     uint32_t strideB_v = (uint32_t)strideB, gbias_v = g1 << (32 - kFx);
@@ -1236,7 +1236,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
     const int64_t per = (a.n + a.nslices - 1) / a.nslices;
     const int nitems = 4 * a.nslices;
     // the probe block addresses the window with raw LDS offsets (ds_read_u8 ... offset:kQLdsBase)
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
+    // the window is addressed from the raw LDS offset kQLdsBase: checked on the host at mcl_create (choose_ray_mode keeps the
+    // engine off this kernel when the layout differs); a mismatch reports a full fix-up list (the host re-runs the stage with
+    // k_rays_skip) instead of aborting the device
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
+        if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = a.fix_cap + 1ull;
+        return;
+    }
     // Persistent workgroups (2 per CU) pull (slice, quadrant) items from a device-side queue: quadrants carry
     // very different numbers of beams (a 270-degree scan puts ~360 beams in two quadrants and ~180 in the
     // other two), and a static grid of one workgroup per item kept only half of the slots busy (measured).
@@ -1910,7 +1916,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_cell(RayArgs a)
     unsigned long long cnt_probe = 0;
     const int64_t per = (a.n + a.nslices - 1) / a.nslices;
     const int nitems = kWedges * a.nslices;
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
+    // the window is addressed from the raw LDS offset kQLdsBase: checked on the host at mcl_create (choose_ray_mode keeps the
+    // engine off this kernel when the layout differs); a mismatch reports a full fix-up list (the host re-runs the stage with
+    // k_rays_skip) instead of aborting the device
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
+        if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = a.fix_cap + 1ull;
+        return;
+    }
     for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) item_sh = (int)atomicAdd(a.work_counter, 1ull);
@@ -2177,7 +2189,8 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
         n = n_sh;
         __syncthreads();
     }
-    if (n > a.fix_cap) n = a.fix_cap;                      // overflow: the host re-runs the stage with k_rays_skip
+    if (n > a.fix_cap) n = 0;                              // overflow (or a ray kernel that stood down): the host re-runs the stage with
+                                                           // k_rays_skip and discards this one, so nothing of the segment is traced
     cnt_l2 += (threadIdx.x == 0 && part == 0) ? n : 0;
     const unsigned long long *list = a.fix_list + (size_t)seg * a.fix_cap;
     for (unsigned long long k = (unsigned long long)part * blockDim.x + threadIdx.x; k < n; k += (unsigned long long)blockDim.x * split) {

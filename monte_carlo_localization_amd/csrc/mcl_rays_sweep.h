@@ -379,7 +379,14 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     unsigned long long cnt_probe = 0;
     const int G = a.sweep_g;                                   // wedges per work item (divides kWedges)
     const int nitems = a.nitems_ptr ? a.nitems_ptr[0] : a.nitems;       // the plan is made on the device (k_sweep_plan)
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) __builtin_trap();
+    // The probe trip addresses the window from the raw LDS offset kQLdsBase.  mcl_create checks the layout on the host and keeps
+    // AUTO / MCL_RAYS_SWEEP off this kernel when it differs (choose_ray_mode), so this branch is not reachable through the ABI;
+    // should a toolchain ever lay the static words out differently anyway, the launch reports a full fix-up list -- which the
+    // host answers by re-running the stage with k_rays_skip -- instead of aborting the device.
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
+        if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = a.fix_cap + 1ull;
+        return;
+    }
     constexpr int S = kSwSide;
     // level-1 error bound per axis, in units of 2^-24 px: 0.5 for the origin + (0.5 rounding + 0.625 scale, kSwDirScale)
     // per sample, s <= P + 1 samples, + 5 for the fp64 rounding of the rotated direction

@@ -66,7 +66,7 @@ class ShardedFilter:
         self.slot_buf = torch.empty(n, dtype=i32, device=device)        # every child's position among them
         self.pose = np.zeros(3)
         self.exchange_bytes = dict(kind="none", weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0,
-                                   list_bytes_received=0)
+                                   list_bytes_received=0, list_payload_bytes=0)
         # list exchange: every rank's list length (-1: none) and fixed-point total, known from the previous update's sums
         self.counts = None
         self.totals = None
@@ -181,7 +181,10 @@ class ShardedFilter:
             _, entries = self._start_list_gather(False)
         self._sync()
         listed = int(self.counts.sum())
-        self.exchange_bytes.update(kind="lists", list_bytes_received=44 * (listed - int(self.counts[self.rank])), weights_received=0,
+        # what crosses the links is the padded chunk of every other rank (the all-gather moves `entries` entries per rank: the
+        # longest list rounded up to 64); the entries that carry data are reported beside it
+        self.exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (self.world - 1),
+                                   list_payload_bytes=44 * (listed - int(self.counts[self.rank])), weights_received=0,
                                    requests_sent=0, records_received=0, distinct_remote_parents=0)
         self.shard.stage_resample_compact(self.chunk_all.data_ptr(), self.world, entries, self.counts, self.totals, self.n, self.rank,
                                           self.rank * self.n, self.n_total, action)
@@ -195,7 +198,7 @@ class ShardedFilter:
             self.pending_q.wait()                                        # issued at the end of the previous update
             self.pending_q = None
         self._sync()
-        self.exchange_bytes.update(kind="dense", weights_received=8 * self.n * (self.world - 1), list_bytes_received=0)
+        self.exchange_bytes.update(kind="dense", weights_received=8 * self.n * (self.world - 1), list_bytes_received=0, list_payload_bytes=0)
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
         s.stage_resample_indices(self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, self.parent.data_ptr())

@@ -34,7 +34,7 @@ EXPORTS = [
     "mcl_group_update", "mcl_group_expected_pose", "mcl_group_get_particles", "mcl_group_get_weights",
     "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
     "mcl_set_debug_count_probes", "mcl_set_particles_shard", "mcl_get_compact_list", "mcl_compact_chunk_bytes", "mcl_export_compact",
-    "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16",
+    "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
 ]
 
 
@@ -346,6 +346,15 @@ class Engine:
         v = C.c_int32()
         self._chk(self.lib.mcl_get_ray_kernel_id(self._h, C.byref(v)), "mcl_get_ray_kernel_id")
         return {1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}.get(v.value, "?")
+
+    RAY_KERNEL_NAMES = {0: None, 1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}
+
+    def planned_ray_kernel(self, n_particles=0):
+        """(kernel an update over n_particles WILL run -- None: the configured one cannot run with this map / beam set --, what
+        decided): callable before the first update, once the map and the beam angles are set."""
+        v, why = C.c_int32(), C.c_char_p()
+        self._chk(self.lib.mcl_get_planned_ray_kernel(self._h, C.c_int64(int(n_particles)), C.byref(v), C.byref(why)), "mcl_get_planned_ray_kernel")
+        return self.RAY_KERNEL_NAMES.get(v.value, "?"), (why.value or b"").decode()
 
     # -- multi-GPU staging (raw device pointers as ints)
     def device_ptr(self, which) -> int:

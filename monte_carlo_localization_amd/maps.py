@@ -165,3 +165,13 @@ def synthetic_levine(width: int = 2049, height: int = 2049, seed: int = 7) -> Oc
         g[y:y + 3, x:x + 3] = 100
     # keep the start pose clear: corridor centre near the bottom-left
     return OccupancyMap(np.ascontiguousarray(g), np.float32(0.05), -51.224998, -51.224998, "levine_synthetic")
+
+
+def synthetic_fine025(base: OccupancyMap) -> OccupancyMap:
+    """SYNTHETIC long-range case: `base`'s grid with every cell split into 2 x 2, declared at 0.025 m per cell.  At the stock
+    12 m range that is MAX_RANGE_PX = 479 (cpp:195 puts no bound on it; the float32 resolution is a hair above 0.025, SURVEY
+    D9) -- twice what the reference's own maps give.  The origin keeps pixel (2 * 1464 + 1, 2 * 626 + 1) -- the start / finish
+    straight of Spielberg_map -- at world (0, 0)."""
+    g = np.ascontiguousarray(np.repeat(np.repeat(base.data, 2, axis=0), 2, axis=1))
+    res = np.float32(0.025)
+    return OccupancyMap(g, res, -(2 * 1464 + 1) * float(res), -(2 * 626 + 1) * float(res), base.name + "_x2_at_0.025")

@@ -15,7 +15,14 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # MCL_TEST_NCCL=1: RCCL with one DISTINCT device per rank (needs at least `world` GPUs); else gloo, the ranks share GPU 0
+    nccl = os.environ.get("MCL_TEST_NCCL") == "1"
+    dev_index = rank if nccl else 0
+    if nccl:
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     from monte_carlo_localization_amd import maps
     from monte_carlo_localization_amd.dist import ShardedFilter
     from oracle import oracle as orc
@@ -43,14 +50,14 @@ def main():
         device = torch.device("cpu")
     else:
         from monte_carlo_localization_amd import engine
-        shard = engine.Engine(max_particles=n_local, device=0, seed=2024, resample_mode=mode)
+        shard = engine.Engine(max_particles=n_local, device=dev_index, seed=2024, resample_mode=mode)
         shard.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
         shard.set_beam_angles(ang)
         if device_init:
             shard.init_particles_pose((0.0, 0.0, 0.0), n_local, rank * n_local, ntot)
         else:
             shard.set_particles(p[:, mine], w)
-        device = torch.device("cuda", 0)
+        device = torch.device("cuda", dev_index)
     overlap = len(sys.argv) > 6 and sys.argv[6] == "overlap"
     sf = ShardedFilter(shard, n_local, device, overlap=overlap)
     if skewed:

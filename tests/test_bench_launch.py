@@ -74,5 +74,9 @@ def test_bench_gpus_2_end_to_end_on_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["particles_total"] == 262144 and d["config"]["beams"] == 271
     assert d["parity_check"]["logw_mismatches"] == 0 and d["parity_check"]["n"] == 4000
+    # ... including the resample indices of ALL children of BOTH ranks (global parent indices gathered on rank 0) against the
+    # oracle's exact-CDF draw from the whole set's weights: a line with N > 1 proves its indices like the one-GPU line does
+    assert d["parity_check"]["idx_n"] == 262144 and d["parity_check"]["idx_mismatches"] == 0
+    assert d["roofline"]["probe_trips_per_ray_live"] > 1.0 and 0.0 < d["roofline"]["useful"]["frac"] < 1.0
     assert d["exchange_bytes_per_update_per_gpu"]["kind"] == "lists"
     assert d["value"] > 0 and d["roofline"]["kernel"] == "k_rays_sweep"

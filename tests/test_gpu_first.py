@@ -80,3 +80,44 @@ def test_small_update_path_against_the_oracle(orc, engine_mod, spielberg, spielb
         assert np.allclose(w * (ref.sum() / w.sum()), ref, rtol=1e-12, atol=0.0), k
         assert e.ray_kernel_name() == "k_rays_skip"
     e.close()
+
+
+def test_planned_ray_kernel_is_known_before_the_first_update(orc, engine_mod, spielberg, maps_mod):
+    """mcl_get_planned_ray_kernel: the kernel class an update WILL get (the pure function mcl_update consults) and the reason,
+    before anything runs -- the fast windowed kernel needs >= 65536 particles and 2^23 rays, beam angles that increase over
+    less than a turn and MAX_RANGE_PX <= 243; anything else takes k_rays_skip, and says so."""
+    ang = orc.beam_angles(angle_step=1)
+    e = engine_mod.Engine(max_particles=131072)
+    with pytest.raises(engine_mod.EngineError):
+        e.planned_ray_kernel()                       # no map, no beams: MCL_ERR_NOT_READY
+    e.set_map(spielberg.data, spielberg.resolution, spielberg.origin_x, spielberg.origin_y)
+    e.set_beam_angles(ang)
+    assert e.planned_ray_kernel()[0] == "k_rays_sweep"          # default: max_particles
+    k, why = e.planned_ray_kernel(4000)
+    assert k == "k_rays_skip" and "fewer than 65536" in why
+    # ... and it is what runs
+    rng = np.random.default_rng(3)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
+    e.set_particles(tracking_cloud(rng, 131072), np.full(131072, 1.0 / 131072))
+    e.update((0.05, 0.0, 0.01), obs)
+    assert e.ray_kernel_name() == e.planned_ray_kernel()[0] == "k_rays_sweep"
+    # beam angles that do not increase: no contiguous beam range per direction wedge
+    shuffled = ang.copy(); shuffled[[10, 20]] = shuffled[[20, 10]]
+    e.set_beam_angles(shuffled)
+    k, why = e.planned_ray_kernel()
+    assert k == "k_rays_skip" and "monotone" in why
+    e.close()
+    # a 0.025 m map: MAX_RANGE_PX = 479 (cpp:195 has no bound), beyond the 256-cell windows
+    fine = maps_mod.synthetic_fine025(spielberg)
+    e = engine_mod.Engine(max_particles=131072)
+    e.set_map(fine.data, fine.resolution, fine.origin_x, fine.origin_y)
+    e.set_beam_angles(ang)
+    assert e.max_range_px() == 479
+    k, why = e.planned_ray_kernel()
+    assert k == "k_rays_skip" and "MAX_RANGE_PX" in why
+    # a configured kernel that cannot run with this map: 0 / None up front, MCL_ERR_UNSUPPORTED from the update
+    e2 = engine_mod.Engine(max_particles=1024, ray_kernel=engine_mod.RAYS_SWEEP)
+    e2.set_map(fine.data, fine.resolution, fine.origin_x, fine.origin_y)
+    e2.set_beam_angles(ang)
+    assert e2.planned_ray_kernel()[0] is None
+    e.close(); e2.close()

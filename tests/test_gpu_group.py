@@ -179,3 +179,47 @@ def test_group_argument_errors(engine_mod, spielberg, orc):
     with pytest.raises(engine_mod.EngineError):
         g.update(ACTION, np.ones(19, np.float32))        # particles not set
     g.close()
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: the group's peer copies and cross-device events between DISTINCT devices")
+@pytest.mark.parametrize("mode", ["multinomial", "systematic"])
+def test_group_on_two_distinct_devices_equals_one_engine(orc, engine_mod, spielberg, mode):
+    """The same comparison as test_group_equals_one_engine with the shards on devices 0 and 1: hipMemcpyPeerAsync between two
+    devices, peer-pointer parent reads (first update) and the ev_ready / ev_children waits across devices.  Skipped on a
+    one-GPU box -- there every group test puts its shards on device 0, which is a REHEARSAL of this path."""
+    ang = orc.beam_angles(angle_step=4)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::4].astype(np.float32).copy()
+    n = 262144
+    rm = engine_mod.RESAMPLE_MULTINOMIAL if mode == "multinomial" else engine_mod.RESAMPLE_SYSTEMATIC
+    one = make_engine(engine_mod, spielberg, ang, n, seed=7, resample_mode=rm)
+    one.init_particles_pose((0.0, 0.0, 0.0), n)
+    grp = engine_mod.Group([0, 1], max_particles=n // 2, seed=7, resample_mode=rm)
+    grp.set_map(spielberg.data, spielberg.resolution, spielberg.origin_x, spielberg.origin_y)
+    grp.set_beam_angles(ang)
+    grp.init_particles_pose((0.0, 0.0, 0.0), n)
+    for k in range(5):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        assert np.array_equal(grp.resample_indices(), one.resample_indices()), f"update {k}"
+        assert np.array_equal(grp.get_particles(), one.get_particles()), f"update {k}"
+    assert grp.exchange_bytes()["lists"]
+    grp.close(); one.close()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: RCCL with one rank per device")
+@pytest.mark.parametrize("mode", [0, 1])
+def test_two_ranks_over_rccl_on_two_devices_equal_one_rank(tmp_path, mode):
+    """ShardedFilter over the nccl (= RCCL) backend, one rank per DISTINCT device: the all-gather of the compact lists and the
+    small all-reduces as bench.py --gpus 2 issues them.  Skipped on a one-GPU box, where the same code runs over gloo."""
+    from test_dist import run_world, check_equal
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir(); d1.mkdir()
+    two = run_world("engine", d2, 2, 131072, 4, mode, True, MCL_TEST_BEAM_STEP="4", MCL_TEST_NCCL="1")
+    one = run_world("engine", d1, 1, 262144, 4, mode, False, MCL_TEST_BEAM_STEP="4")
+    check_equal(two, one, 131072)
+    assert list(two[0]["kinds"]) == ["dense", "lists", "lists", "lists"]
