@@ -42,6 +42,8 @@ struct mcl_engine {
     mcl_config_t cfg{};
     int num_cu = 256;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // the per-update observation tables are built here, beside the resampling and ordering kernels
+    hipEvent_t ev_obs = nullptr;        // ... and the ray stage waits for this
     hipEvent_t ev[EV_COUNT]{};
     std::string err;
 
@@ -79,6 +81,20 @@ struct mcl_engine {
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
     bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
     bool skip_layout_ok = false;        // k_rays_skip has no static LDS (its window is addressed from LDS offset 0)
+    // k_rays_sweep on the wedge fields in GLOBAL memory (ranges a 256-cell LDS window cannot hold; MCL_SWEEP_GLOBAL=1 forces it)
+    uint8_t *d_distg = nullptr;         // kWedges fields with a two-cell stop ring: (Hp + 4) x distg_pitch bytes each
+    int distg_pitch = 0, g_cb = 0;      // row pitch; cell bits of a window-relative position (10 .. 12)
+    size_t distg_stride = 0;
+    bool sweep_global = false;          // this map takes the global-field variant (decided at mcl_set_map)
+    bool env_sweep_global = false;
+    int env_sw_split16 = -1;            // MCL_SW_SPLIT16=0/1 forces RayArgs::split16 (default: by size)
+    bool env_no_obs_overlap = false;    // MCL_NO_OBS_OVERLAP: the observation tables are built on the main stream, after the resampling kernel
+    bool env_no_prep_fold = false;      // MCL_NO_PREP_FOLD: k_prep_small stays a launch of its own
+    // the few words the ray stage wants cleared (k_prep_small's job): what the last windowed launch passed, so that the NEXT
+    // update's resampling kernel can do it (prep_folded: it did, with exactly prep_cache)
+    mcl::PrepClear prep_cache{};
+    bool prep_cache_valid = false, prep_folded = false;
+    int64_t prep_cache_n = 0;
     bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
     int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), planned on the device every update
     int4 *d_centres = nullptr;          // per run of units: window centre, first unit, units (k_sweep_plan)
@@ -134,7 +150,9 @@ struct mcl_engine {
     size_t steps_capacity = 0, blocktot_capacity = 0;
     const uint64_t *blocktot_for = nullptr;   // which CDF array d_blocktot currently describes
     int64_t blocktot_n = 0;
-    double *d_part = nullptr;           // kRedBlocks * 8
+    double *d_part = nullptr;           // kRedBlocks * 8: per-workgroup partial sums (k_weights)
+    double *d_maxpart = nullptr;        // kRedBlocks: per-workgroup maxima of d_logw (k_combine_logw / k_reduce_max)
+    bool sums_pending = false;          // k_weights left partial sums that the next scan's spine turns into scalars[1..7]
     double *d_scalars = nullptr;        // 8
     unsigned long long *d_counters = nullptr;  // 4
     double *d_inject = nullptr;         // cap*4 (normals + uniforms)
@@ -434,7 +452,11 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
         co.cap = (uint32_t)h->compact_cap; co.total = h->d_result + 16;
     }
     hipLaunchKernelGGL(mcl::k_scan_partials, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, co.block_cnt);
-    hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total, co.block_cnt, co.total);
+    // (the spine is one workgroup that runs right after k_weights: it also finishes that kernel's partial sums, when asked)
+    const bool fold = h->sums_pending && d_q == h->d_q;
+    hipLaunchKernelGGL(mcl::k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->d_blocktot, nb, offset, d_total, co.block_cnt, co.total,
+                       fold ? h->d_part : (const double *)nullptr, mcl::kRedBlocks, h->d_scalars);
+    if (fold) h->sums_pending = false;
     const size_t nlead = (size_t)((n + 15) >> mcl::kLeaderShift) + 1;
     if (nlead > h->leaders_capacity) {
         graph_reset(h);                    // a captured update graph holds the old pointer
@@ -449,23 +471,27 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
     return MCL_OK;
 }
 
-// weights/q/sums from either log-weights (from_log) or raw weights already in d_w
-int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override)
+// weights/q/sums from either log-weights (from_log) or raw weights already in d_w.  defer_sums: the caller scans d_q next
+// (scan_weights), whose one-workgroup spine then also reduces the partial sums -- one launch less.
+int weight_stats(mcl_engine *h, bool from_log, const double *d_max_override, bool defer_sums = false)
 {
     const int64_t n = h->N;
     const double *src = from_log ? h->d_logw : h->d_w;
+    const double *max_parts = nullptr;
     if (!d_max_override) {
-        if (!(from_log && h->max_partials_ready))        // k_combine_logw already left the per-workgroup maxima in d_part
-            hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, n, h->d_part);
-        hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+        if (!(from_log && h->max_partials_ready))        // k_combine_logw already left the per-workgroup maxima in d_maxpart
+            hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, n, h->d_maxpart);
+        max_parts = h->d_maxpart;                        // every workgroup of k_weights reduces them itself (no k_final_max in between)
     }
-    h->max_partials_ready = false;                       // k_weights overwrites d_part
+    h->max_partials_ready = false;
     hipLaunchKernelGGL(mcl::k_weights, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, src, from_log ? 1 : 0,
-                       h->d_scalars, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, h->d_w, h->d_q, h->d_part,
-                       (from_log && h->cfg.resample_neff_permille > 0) ? h->d_carry[h->carry_idx ^ 1] : (double *)nullptr);
+                       d_max_override ? d_max_override : h->d_scalars, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n, h->d_w, h->d_q, h->d_part,
+                       (from_log && h->cfg.resample_neff_permille > 0) ? h->d_carry[h->carry_idx ^ 1] : (double *)nullptr,
+                       max_parts, mcl::kRedBlocks);
     h->carry_pending = from_log && h->cfg.resample_neff_permille > 0;     // the caller commits it (commit_carry)
     if (!from_log) h->carry_valid = false;
-    hipLaunchKernelGGL(mcl::k_final_sums, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+    if (defer_sums) h->sums_pending = true;
+    else hipLaunchKernelGGL(mcl::k_final_sums, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -505,6 +531,14 @@ void unpack_result(mcl_engine *h)
 // Work items of k_rays_sweep: made on the device from this update's unit statistics (k_sweep_plan, mcl_rays_sweep.h);
 // the host only sizes the list (every unit on its own, once per wedge group, is the longest it can get).
 // upper bound on the units of n sorted particles: the plain grid plus one cut per bucket of a sparse set (mcl::k_unit_table)
+// cells the particles of one k_rays_sweep work item may spread over (per axis): what the 256-cell LDS window leaves beside a
+// ray's reach, or -- on the global wedge fields -- the span of the cell field minus the reach on both sides
+int sweep_play(const mcl_engine *h)
+{
+    if (h->sweep_global) return 2 * ((1 << (h->g_cb - 1)) - (h->P + 3) - 2);
+    return mcl::kSwSide - (h->P + 2) - 3;
+}
+
 int64_t max_sweep_units(int64_t n) { return (n + mcl::kSwUnit - 1) / mcl::kSwUnit + mcl::kSwMaxCuts + 2; }
 
 int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
@@ -519,7 +553,7 @@ int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
         h->items_capacity = need;
     }
     if (!h->d_nitems) HIPCHK(h, hipMalloc(&h->d_nitems, sizeof(int)));
-    const int play = mcl::kSwSide - (h->P + 2) - 3;                     // cells a window leaves for the particles of an item
+    const int play = sweep_play(h);                                     // cells a window leaves for the particles of an item
     hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), mcl::kPlanLds, h->stream, h->d_unit_sums, h->d_nunits, ngroups, nwg, (double)(play / 2 - 1),
                        h->d_items, h->d_centres, h->d_nitems);
     HIPCHK(h, hipGetLastError());
@@ -550,9 +584,13 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
     if (rk == MCL_RAYS_QUAD) { w = windows_ok && h->quad_layout_ok ? "configured: MCL_RAYS_QUAD" : (no_windows ? no_windows : "k_rays_quad's LDS layout check failed"); return windows_ok && h->quad_layout_ok ? 3 : 0; }
     if (rk == MCL_RAYS_CELL) { w = windows_ok && h->cell_layout_ok ? "configured: MCL_RAYS_CELL" : (no_windows ? no_windows : "k_rays_cell's LDS layout check failed"); return windows_ok && h->cell_layout_ok ? 4 : 0; }
     // its windows are 256 cells wide (mcl_rays_sweep.h) and addressed from a raw LDS offset checked at mcl_create
-    const char *no_sweep = no_windows;
-    if (!no_sweep && !mcl::sweep_window_fits(h->P)) no_sweep = "MAX_RANGE_PX > 243: a 256-cell window of k_rays_sweep cannot hold a ray plus 8 cells of play";
-    if (!no_sweep && !h->sweep_layout_ok) no_sweep = "k_rays_sweep's LDS layout check failed at mcl_create";
+    // ... or, for ranges beyond that (MAX_RANGE_PX up to kSweepGlobalMaxP), probes the same wedge fields in global memory
+    const char *no_sweep = h->quad_ok ? nullptr : no_windows;
+    if (!no_sweep) {
+        if (h->sweep_global) { if (!h->d_distg) no_sweep = "MAX_RANGE_PX > 1981: beyond the 12-bit cell field of k_rays_sweep's global-field variant"; }
+        else if (!mcl::sweep_window_fits(h->P)) no_sweep = "MAX_RANGE_PX > 243: a 256-cell window of k_rays_sweep cannot hold a ray plus 8 cells of play";
+        else if (!h->sweep_layout_ok) no_sweep = "k_rays_sweep's LDS layout check failed at mcl_create";
+    }
     const bool sweep_ok = no_sweep == nullptr;
     if (rk == MCL_RAYS_SWEEP) { w = sweep_ok ? "configured: MCL_RAYS_SWEEP" : no_sweep; return sweep_ok ? 5 : 0; }
     // AUTO: one particle per lane on cell-sorted particles pays once there are enough particles to fill the machine
@@ -561,7 +599,11 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
     // below that the self-contained k_rays_skip (one launch, no work lists) is the quickest
     const int64_t cell_min = h->env_cell_min > 0 ? h->env_cell_min : 65536;
     const bool big = n >= cell_min && n * (int64_t)h->B >= (8 << 20);
-    if (big && sweep_ok) { w = "AUTO: at least 65536 particles and 2^23 rays, monotone beams, MAX_RANGE_PX <= 243"; return 5; }
+    if (big && sweep_ok) {
+        w = h->sweep_global ? "AUTO: at least 65536 particles and 2^23 rays, monotone beams; MAX_RANGE_PX > 243 (or MCL_SWEEP_GLOBAL): k_rays_sweep probes the wedge fields in global memory"
+                            : "AUTO: at least 65536 particles and 2^23 rays, monotone beams, MAX_RANGE_PX <= 243";
+        return 5;
+    }
     if (big && windows_ok && h->cell_layout_ok) { w = no_sweep; return 4; }
     if (!h->skip_layout_ok) { w = "k_rays_skip's LDS layout check failed at mcl_create: literal march"; return 1; }
     w = !big ? "AUTO: fewer than 65536 particles or 2^23 rays: the self-contained k_rays_skip is the quickest" : no_sweep;
@@ -675,7 +717,10 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int items_per_slice = sweep ? mcl::kWedges / sweep_g : (cell ? mcl::kWedges : 4);
         const int nseg = (int)std::min<int64_t>(max_wg, items_per_slice * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
-        unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / 256 + 7) & ~7ull);
+        // (the global-field form of k_rays_sweep works with 20-22 fractional bits instead of 24: its guard is 4-16 times wider in
+        //  pixels and it hands up to ~0.4 % of the rays of a long-range map to the fix-up pass: room for 3 %)
+        const unsigned long long seg_div = (sweep && h->sweep_global) ? 32 : 256;
+        unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / seg_div + 7) & ~7ull);
         if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
         if ((unsigned long long)nseg * segcap > h->fix_alloc) {
             dfree(h->d_fix_list);
@@ -704,10 +749,16 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             if (sweep) clr.far_count = h->d_result + 15;
             if (cell) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
             // the window play k_sweep_plan works with (0: no windowed kernel; -1: no cuts at all, MCL_NO_BUCKET_CUTS)
-            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? mcl::kSwSide - (h->P + 2) - 3 : 0);
+            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? sweep_play(h) : 0);
             if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
                 clr.logw_acc = nullptr; clr.far_flags = nullptr;
-                hipLaunchKernelGGL(mcl::k_prep_small, dim3(1), dim3(256), 0, h->stream, clr);
+                // ... and, from the second update of a configuration on, the few words that are not per particle as well
+                const mcl::PrepClear &pc0 = h->prep_cache;
+                const bool done = h->prep_folded && h->prep_cache_valid && clr.fix_count == pc0.fix_count && clr.fix_words == pc0.fix_words &&
+                                  clr.fix_over == pc0.fix_over && clr.exact_count == pc0.exact_count && clr.far_count == pc0.far_count &&
+                                  clr.bbox == pc0.bbox && clr.bbox_play == pc0.bbox_play && !clr.hist && !pc0.hist;
+                if (!done) hipLaunchKernelGGL(mcl::k_prep_small, dim3(1), dim3(256), 0, h->stream, clr);
+                if (!h->capturing) { h->prep_cache = clr; h->prep_cache_valid = true; h->prep_cache_n = n; }
             } else {
                 hipLaunchKernelGGL(mcl::k_particle_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, y, th, n, h->ox, h->oy,
                                    h->res, h->d_pc, h->d_angle, h->B, cell ? (short4 *)nullptr : h->d_qr, clr);
@@ -776,7 +827,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             }
             if (!radix) hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
             if (sweep) {
-                hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)max_sweep_units(n)), dim3(256), 0, h->stream, h->d_pcs, h->d_unit_begin, h->d_nunits,
+                hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)std::min<int64_t>(max_sweep_units(n), (n + mcl::kSwUnit - 1) / mcl::kSwUnit + 256)), dim3(256), 0, h->stream, h->d_pcs, h->d_unit_begin, h->d_nunits,
                                    h->d_unit_sums);
             } else {
                 if ((size_t)nsl > h->slice_mean_capacity) {
@@ -795,7 +846,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
             if (rc_plan) return rc_plan;
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
+            a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
             a.beam_csx = h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
+            a.distg = h->d_distg; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch; a.g_cb = h->g_cb;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
                 HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
@@ -810,7 +863,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             h->far_fresh = false;
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
-        size_t qlds = sweep ? (size_t)mcl::kSwSide * mcl::kSwSide : (size_t)h->qside * h->qside;
+        const bool sweep_glob = sweep && h->sweep_global;       // probes in global memory: no window in LDS
+        size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwSide * mcl::kSwSide) : (size_t)h->qside * h->qside;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();
@@ -820,7 +874,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU
         HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, a);
+            if (sweep_glob) hipLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, a);
+            else if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
@@ -829,7 +884,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
         } else {
-            if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, a);
+            if (sweep_glob) hipLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, a);
+            else if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
             HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
@@ -838,13 +894,14 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<false>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
         }
-        hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
         if (sweep) {
             // the slot accumulators (k_rays_sweep's per-wedge sums + what the far / fix / exact kernels added) -> d_logw in particle
-            // order, and the per-workgroup maxima
-            hipLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, n, h->d_perm, h->d_logw_acc, h->d_logw, h->d_part);
+            // order, the per-workgroup maxima, and the overflow flag of the fix-up lists (k_fix_overflow's job for the other kernels)
+            hipLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, n, h->d_perm, h->d_logw_acc, h->d_logw, h->d_maxpart,
+                               h->d_fix_count, nseg, segcap, h->d_fix_over);
             h->max_partials_ready = true;
         } else {
+            hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
             hipLaunchKernelGGL(mcl::k_gather_logw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw_acc, n, h->d_logw);
         }
         if (d_dbg) {
@@ -867,6 +924,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     }
     if (!windows && !h->capturing && !direct_table) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
     h->last_mode = mode;
+    h->prep_folded = false;
     if (!h->capturing) h->pc_ready = false;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
@@ -912,10 +970,11 @@ void graph_reset(mcl_engine *h)
     for (int k = 0; k < 2; ++k)
         if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
     h->graph_warm = false;
+    h->prep_cache_valid = false; h->prep_folded = false;
     h->pc_ready = false;                    // whatever changed (map, beams, particles, a buffer): the ray stage makes its own constants
 }
 
-int sensor_and_weights(mcl_engine *h, const double *d_global_max)
+int sensor_and_weights(mcl_engine *h, const double *d_global_max, bool defer_sums = false)
 {
     // d_logw holds the log-weights of the current particle set
     if (h->cfg.weight_mode == MCL_WEIGHT_PRODUCT) {
@@ -924,9 +983,9 @@ int sensor_and_weights(mcl_engine *h, const double *d_global_max)
         hipLaunchKernelGGL(mcl::k_product_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->P > 255 ? (const uint8_t *)nullptr : h->d_steps,
                            h->P > 255 ? reinterpret_cast<const uint16_t *>(h->d_steps) : (const uint16_t *)nullptr, h->d_obs_idx, n, h->B, h->d_table, h->P + 1, 1.0 / h->cfg.squash_factor, h->d_w);
         HIPCHK(h, hipGetLastError());
-        return weight_stats(h, false, nullptr);
+        return weight_stats(h, false, nullptr, defer_sums);
     }
-    return weight_stats(h, true, d_global_max);
+    return weight_stats(h, true, d_global_max, defer_sums);
 }
 
 // weights, sums and the CDF of the current log-weights (the tail of an update).  Small updates take one launch.
@@ -946,7 +1005,7 @@ int weights_and_cdf(mcl_engine *h, bool result_to_host = false)
         h->compact_n = -1; h->compact_pending = false;
         return MCL_OK;
     }
-    int rc = sensor_and_weights(h, nullptr);
+    int rc = sensor_and_weights(h, nullptr, true);             // (the sums are finished by the scan's spine)
     if (rc) return rc;
     return scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);   // CDF for the next resample / visualize
 }
@@ -1025,6 +1084,10 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     if (const char *e = getenv("MCL_SORT")) h->env_sort_radix = std::strcmp(e, "radix") == 0 ? 1 : (std::strcmp(e, "hist") == 0 ? 0 : -1);
     if (const char *e = getenv("MCL_DEBUG_WG")) h->env_debug_wg = e;
     h->env_no_bucket_cuts = getenv("MCL_NO_BUCKET_CUTS") != nullptr;
+    if (const char *e = getenv("MCL_SWEEP_GLOBAL")) h->env_sweep_global = atoi(e) != 0;
+    if (const char *e = getenv("MCL_SW_SPLIT16")) h->env_sw_split16 = atoi(e) != 0;
+    h->env_no_obs_overlap = getenv("MCL_NO_OBS_OVERLAP") != nullptr;
+    h->env_no_prep_fold = getenv("MCL_NO_PREP_FOLD") != nullptr;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
     auto bail = [&](const char *what) {
@@ -1038,6 +1101,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
         if (e_ != hipSuccess) { h->err = hipGetErrorString(e_); return bail(#call); } \
     } while (0)
     CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    CRT(hipEventCreateWithFlags(&h->ev_obs, hipEventDisableTiming));
     for (int i = 0; i < EV_COUNT; ++i) CRT(hipEventCreate(&h->ev[i]));
     const size_t nb = (size_t)h->cap * sizeof(double);
     for (int b = 0; b < 2; ++b) {
@@ -1058,6 +1123,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMalloc(&h->d_crec, (size_t)h->compact_cap * sizeof(double4)));
     CRT(hipMalloc(&h->d_idx, (size_t)h->cap * 4));
     CRT(hipMalloc(&h->d_part, (size_t)mcl::kRedBlocks * 8 * sizeof(double)));
+    CRT(hipMalloc(&h->d_maxpart, (size_t)mcl::kRedBlocks * sizeof(double)));
     CRT(hipMalloc(&h->d_result, 32 * 8));
     CRT(hipMemset(h->d_result, 0, 32 * 8));
     CRT(hipHostMalloc(&h->h_result, 48 * 8));
@@ -1140,13 +1206,15 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
     dfree(h->d_gcdf); dfree(h->d_gtop);
     dfree(h->d_blockcnt); dfree(h->d_ccdf); dfree(h->d_ctop); dfree(h->d_cidx); dfree(h->d_crec);
-    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_cut_start); dfree(h->d_cut_end); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
+    dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_maxpart); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_distg); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_cut_start); dfree(h->d_cut_end); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->ev_obs) (void)hipEventDestroy(h->ev_obs);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1172,6 +1240,15 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     // k_rays_quad: byte window of side S in half the LDS (S*S <= 80 KiB, S % 8 == 0); usable when the extent
     // budget S - (P+2) - 3 is at least 48 cells, otherwise k_rays_skip's full-LDS nibble window is used
     { const int S = h->env_qside > 0 ? h->env_qside : 280; h->qside = (S - (P + 2) - 3 >= 32) ? S : 0; }
+    // k_rays_sweep: the 256-cell LDS windows hold ranges up to 243 px; beyond that (or with MCL_SWEEP_GLOBAL=1) the same walk
+    // probes the wedge fields in global memory, positions in a cell field of g_cb bits that leaves at least 64 cells either side
+    // of a ray's reach (10 bits up to 445 px, 11 up to 957, 12 up to 1981)
+    h->sweep_global = h->env_sweep_global || !mcl::sweep_window_fits(P);
+    h->g_cb = 0;
+    if (h->sweep_global)
+        for (int cb = 10; cb <= 12 && !h->g_cb; ++cb)
+            if ((1 << (cb - 1)) - (P + 3) >= 64) h->g_cb = cb;
+    const bool want_wedges = h->qside > 0 || (h->sweep_global && h->g_cb != 0);     // wedge + quadrant fields (k_rays_far reads the latter)
     build_sensor_table(h->cfg, P, h->table);
     const int tw = P + 1;
     std::vector<float> L((size_t)tw * tw);
@@ -1196,7 +1273,7 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
         HIPCHK(h, hipMalloc(&h->d_dist4, d4.size()));
         HIPCHK(h, hipMemcpy(h->d_dist4, d4.data(), d4.size(), hipMemcpyHostToDevice));
     }
-    if (h->qside > 0) {
+    if (want_wedges) {
         static const int qsx[4] = {1, -1, -1, 1}, qsy[4] = {1, 1, -1, -1};
         std::vector<uint8_t> dq;
         for (int q = 0; q < 4; ++q) {
@@ -1205,8 +1282,8 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
             HIPCHK(h, hipMemcpy(h->d_distq[q], dq.data(), dq.size(), hipMemcpyHostToDevice));
         }
     }
-    dfree(h->d_distw);
-    if (h->qside > 0) {
+    dfree(h->d_distw); dfree(h->d_distg);
+    if (want_wedges) {
         // wedge fields for k_rays_cell (mcl_wedge.h), built on the device from the isotropic field's stop cells
         const size_t fsz = (size_t)h->Hp * h->Wps, ncell = (size_t)h->Hp * h->Wp;
         int32_t *d_nxt = nullptr, *d_prv = nullptr;
@@ -1229,6 +1306,17 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
         }
         (void)hipFree(d_nxt); (void)hipFree(d_prv); (void)hipFree(d_rows);
         if (rc_w != MCL_OK) return fail(h, rc_w, "building the wedge fields failed");
+        if (h->sweep_global && h->g_cb != 0) {
+            // the copies k_rays_sweep<.., GLOBAL> probes: every field with a two-cell ring of stop bytes (k_ring_field)
+            h->distg_pitch = (h->Wp + 4 + 63) & ~63;
+            h->distg_stride = (size_t)(h->Hp + 4) * (size_t)h->distg_pitch;
+            HIPCHK(h, hipMalloc(&h->d_distg, h->distg_stride * mcl::kWedges));
+            for (int k = 0; k < mcl::kWedges; ++k)
+                hipLaunchKernelGGL(mcl::k_ring_field, dim3((h->distg_pitch + 255) / 256, h->Hp + 4), dim3(256), 0, h->stream, h->d_distw + (size_t)k * fsz,
+                                   h->Wp, h->Hp, h->Wps, h->distg_pitch, h->d_distg + (size_t)k * h->distg_stride);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
     }
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_table, h->table.data(), h->table.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1349,7 +1437,7 @@ static int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *
         std::memcpy(&h->h_result[kResultStage], weight_scale, sizeof(double));        // pinned: stays valid until the copy has run
         HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[kResultStage], sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
-    int rc = weight_stats(h, false, weight_scale ? h->d_scalars : nullptr);
+    int rc = weight_stats(h, false, weight_scale ? h->d_scalars : nullptr, true);
     if (rc) return rc;
     rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
     if (rc) return rc;
@@ -1378,7 +1466,7 @@ static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
     h->N = n;
     hipLaunchKernelGGL(mcl::k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_w, n, 1.0 / (double)n_total);
     HIPCHK(h, hipGetLastError());
-    int rc = weight_stats(h, false, nullptr);
+    int rc = weight_stats(h, false, nullptr, true);
     if (rc) return rc;
     rc = scan_weights(h, h->d_q, h->d_cdf, n, 0, nullptr);
     if (rc) return rc;
@@ -1525,6 +1613,19 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     const bool tiny = resample_and_move && h->cfg.graph_mode != 1 && h->graph_warm && n <= mcl::kTinyTailMax && !keep &&
                       choose_ray_mode(h, n, false) == 2 && h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0;
     if (!tiny) HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
+    // The tables of this update's scan (table rows of the observed ranges, Lt, Ltd) depend on nothing the resampling and ordering
+    // kernels produce: with a windowed ray kernel they are built on a second stream beside those, and the ray stage waits for
+    // them (a copy and two or three small launches off the critical path of an update: ~15 us).
+    bool obs_early = false;
+    if (resample_and_move && !tiny && !h->env_no_obs_overlap && choose_ray_mode(h, n, false) >= 3) {
+        std::swap(h->stream, h->stream2);
+        const int rc_obs = prepare_observation(h, obs, obs_stride);
+        hipError_t ee = rc_obs ? hipSuccess : hipEventRecord(h->ev_obs, h->stream);
+        std::swap(h->stream, h->stream2);
+        if (rc_obs) return rc_obs;
+        HIPCHK(h, ee);
+        obs_early = true;
+    }
     if (resample_and_move) {
         const int c = h->cur, nx = c ^ 1;
         mcl::ResampleArgs a{};
@@ -1582,6 +1683,10 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
                 a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
                 if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
                 h->pc_ready = true;
+                if (rmode >= 4 && h->prep_cache_valid && h->prep_cache_n == n && !h->env_no_prep_fold) {
+                    a.prep = h->prep_cache; a.prep_on = 1;      // launch_rays checks that this is what it would have cleared
+                    h->prep_folded = true;
+                }
             }
         }
         size_t cdf_lds = 0;
@@ -1688,8 +1793,12 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         return MCL_OK;
     }
     h->ray_ms_is_graph_tail = false;
-    rc = prepare_observation(h, obs, obs_stride);
-    if (rc) return rc;
+    if (obs_early) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_obs, 0));
+    } else {
+        rc = prepare_observation(h, obs, obs_stride);
+        if (rc) return rc;
+    }
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
     if (rc) return rc;
@@ -2296,8 +2405,8 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     if (!h->max_partials_ready)
-        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_part);
-    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_part, mcl::kRedBlocks, h->d_scalars);
+        hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_maxpart);
+    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_maxpart, mcl::kRedBlocks, h->d_scalars);
     h->max_partials_ready = false;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
@@ -2362,7 +2471,7 @@ static int stage_weights_launch(mcl_engine_t *h, double global_max_logw)
     h->h_result[kResultStage] = 0;
     std::memcpy(&h->h_result[kResultStage], &global_max_logw, sizeof(double));   // pinned: stays valid until the copy has run
     HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[kResultStage], sizeof(double), hipMemcpyHostToDevice, h->stream));
-    int rc = weight_stats(h, true, h->d_scalars);
+    int rc = weight_stats(h, true, h->d_scalars, true);        // (the scan below finishes the sums)
     if (rc) return rc;
     h->carry_pending = false;
     // the shard's own CDF follows its new weights: mcl_sample_particles (visualize) and a later plain mcl_update search it

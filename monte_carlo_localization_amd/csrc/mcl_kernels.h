@@ -21,6 +21,10 @@ namespace mcl {
 // Integer addition is associative, so the result does not depend on N, the block size or the
 // number of GPUs the particle set is sharded over.
 // ------------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;              // K4 / K7 reductions (below): fixed grid, fixed-order final pass
+constexpr int kRedThreads = 256;
+__device__ __forceinline__ void final_sums_of(const double *__restrict__ part, int nb, double *__restrict__ scalars, double (*sm)[7]);
+
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
@@ -82,11 +86,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_partials(const uint64_t *
 }
 
 // exclusive scan of nb block totals in place (single block of 1024 threads), adds `offset`; the alive counts likewise.
+// sum_part (optional): the per-workgroup partial sums k_weights has just left -> scalars[1..7], what a k_final_sums launch in
+// between would do (this kernel is one workgroup anyway and runs after k_weights).
 __global__ __launch_bounds__(1024) void k_scan_spine(uint64_t *__restrict__ block_tot, int nb, uint64_t offset,
                                                      uint64_t *__restrict__ grand_total, uint32_t *__restrict__ block_cnt,
-                                                     unsigned long long *__restrict__ alive_total)
+                                                     unsigned long long *__restrict__ alive_total,
+                                                     const double *__restrict__ sum_part = nullptr, int n_sum_part = 0, double *__restrict__ scalars = nullptr)
 {
     __shared__ uint64_t sm[16];
+    if (sum_part) {
+        __shared__ double sums_sm[kRedThreads / 64][7];
+        final_sums_of(sum_part, n_sum_part, scalars, sums_sm);
+    }
     __shared__ uint32_t smc[16];
     __shared__ uint64_t carry_s;
     __shared__ uint32_t carry_c;
@@ -188,6 +199,30 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint64_t *__r
 //   NaN CDF -> every draw returns 0).
 //   then row gather (cpp:664) and the motion model (cpp:474-502) with the three normals.
 // ------------------------------------------------------------------------------------------------
+// scratch the ray stage needs zeroed, cleared here instead of by one memset each (null = not used by this launch)
+struct PrepClear {
+    double *logw_acc;                  // n
+    uint32_t *far_flags;               // n
+    unsigned long long *fix_count;     // fix_words 64-bit words
+    int fix_words;
+    unsigned long long *fix_over;      // 2 words (overflow flag, work counter)
+    unsigned long long *exact_count;   // 1 word
+    unsigned long long *far_count;     // 1 word
+    int *bbox;                         // 4: +big, +big, -big, -big; [4], [5]: k_tile_compact; [6] = bbox_play
+    int bbox_play;                     // cells a ray window leaves for the particles of a work item (0: no windowed kernel): sort_layout
+    uint32_t *hist;                    // hist_n bucket counters
+    uint32_t hist_n;
+};
+
+__device__ __forceinline__ void prep_small_clear(const PrepClear &clr, int i, int nthreads)
+{
+    if (clr.fix_count) for (int k = i; k < clr.fix_words; k += nthreads) clr.fix_count[k] = 0ull;
+    if (clr.fix_over && i < 2) clr.fix_over[i] = 0ull;
+    if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
+    if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
+    if (clr.bbox && i < 7) clr.bbox[i] = i < 2 ? 0x7fffffff : (i < 4 ? (int)0x80000000 : (i == 6 ? clr.bbox_play : 0));
+}
+
 constexpr int kMaxShards = 16;
 struct ResampleArgs {
     const double *px, *py, *pth;      // parents
@@ -237,6 +272,8 @@ struct ResampleArgs {
     const double4 *crec;              // ... and its record
     const unsigned char *cchunks;     // gathered lists (cidx / crec null): entry p lives in chunk p / ccap
     int64_t cchunk_bytes, ccap;
+    PrepClear prep;                   // prep_on: the first workgroup also clears the few words of the ray stage that are not per
+    int prep_on;                      //   particle (what k_prep_small would do in a launch of its own)
     const float *obs_src;             // this update's ranges (pinned host memory, read once by the first workgroup), or null
     int32_t *obs_idx_out;             // their table rows (obs_index_of), for a ray kernel that reads the static table directly
     int obs_B, obs_P;
@@ -262,6 +299,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     if (a.clear_counters && m == 0) { a.clear_counters[0] = 0ull; a.clear_counters[1] = 0ull; a.clear_counters[2] = 0ull; a.clear_counters[3] = 0ull; }
     if (a.obs_src && blockIdx.x == 0)
         for (int j = threadIdx.x; j < a.obs_B; j += blockDim.x) a.obs_idx_out[j] = obs_index_of(a.obs_src[j], a.res, a.obs_P);
+    if (a.prep_on && blockIdx.x == 0) prep_small_clear(a.prep, (int)threadIdx.x, (int)blockDim.x);
     const uint64_t *cdf = a.cdf;
     if (a.cdf_lds_entries > 0) {
         // a small CDF: one coalesced pass into LDS, then the bisection runs at LDS latency (11 dependent L2 round trips
@@ -624,6 +662,10 @@ struct RayArgs {
     const double2 *slice_mean;     // k_rays_cell: mean pixel position of every slice of the sorted order (k_slice_means)
     const uint8_t *distw;          // k_rays_cell: kWedges wedge fields (mcl_wedge.h), field k at distw + k * distw_stride
     size_t distw_stride;
+    const uint8_t *distg;          // k_rays_sweep<.., GLOBAL>: the same fields with a two-cell ring of stop bytes around the padded grid:
+    size_t distg_stride;           //   padded cell (y, x) of field k at distg + k * distg_stride + (y + 2) * distg_pitch + (x + 2)
+    int distg_pitch;
+    int g_cb;                      // k_rays_sweep<.., GLOBAL>: cell bits of a window-relative position (fraction bits = 32 - g_cb)
     int qside;                     // k_rays_quad: window side in cells (1 byte per cell)
     int nslices;                   // k_rays_quad: particle slices; grid = 4 * nslices
     unsigned long long *fix_list;  // k_rays_quad -> k_rays_fix: (particle << 16 | beam) of undecided rays
@@ -648,6 +690,7 @@ struct RayArgs {
     const double *Ltd;             // k_rays_sweep: fp64 table indexed by samples left + kSwUnder (mcl_rays_sweep.h), ltd_cols columns
     int ltd_cols;
     int sweep_g;                   // k_rays_sweep: wedges per work item
+    int split16;                   // k_rays_sweep: passes of 9..16 chunks are handed out in halves too (small launches)
     const int4 *items;             // k_rays_sweep: work items (first unit, units, wedge group, run), big first (guided schedule)
     const int4 *centres;           // k_rays_sweep: per run of units (window centre as a padded cell x, y; first unit; units), k_sweep_plan
     int nitems;
@@ -739,21 +782,6 @@ __device__ __forceinline__ short4 quadrant_ranges_of(double t, bool heading_ok, 
     return make_short4((short)(st[0] | (q0 << 14)), st[1], st[2], st[3]);
 }
 
-// scratch the ray stage needs zeroed, cleared here instead of by one memset each (null = not used by this launch)
-struct PrepClear {
-    double *logw_acc;                  // n
-    uint32_t *far_flags;               // n
-    unsigned long long *fix_count;     // fix_words 64-bit words
-    int fix_words;
-    unsigned long long *fix_over;      // 2 words (overflow flag, work counter)
-    unsigned long long *exact_count;   // 1 word
-    unsigned long long *far_count;     // 1 word
-    int *bbox;                         // 4: +big, +big, -big, -big; [4], [5]: k_tile_compact; [6] = bbox_play
-    int bbox_play;                     // cells a ray window leaves for the particles of a work item (0: no windowed kernel): sort_layout
-    uint32_t *hist;                    // hist_n bucket counters
-    uint32_t hist_n;
-};
-
 __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict__ x, const double *__restrict__ y,
                                                       const double *__restrict__ th, int64_t n, double ox, double oy, double res,
                                                       double4 *__restrict__ pc, const float *__restrict__ beam_angle, int B,
@@ -778,12 +806,7 @@ __global__ __launch_bounds__(256) void k_particle_prep(const double *__restrict_
 // already written the constants and zeroed the per-particle scratch
 __global__ __launch_bounds__(256) void k_prep_small(PrepClear clr)
 {
-    const int i = threadIdx.x;
-    if (clr.fix_count) for (int k = i; k < clr.fix_words; k += 256) clr.fix_count[k] = 0ull;
-    if (clr.fix_over && i < 2) clr.fix_over[i] = 0ull;
-    if (clr.exact_count && i == 0) clr.exact_count[0] = 0ull;
-    if (clr.far_count && i == 0) clr.far_count[0] = 0ull;
-    if (clr.bbox && i < 7) clr.bbox[i] = i < 2 ? 0x7fffffff : (i < 4 ? (int)0x80000000 : (i == 6 ? clr.bbox_play : 0));
+    prep_small_clear(clr, (int)threadIdx.x, 256);
 }
 
 // D = a*b + c on the low 24 bits of a and b (v_mad_i32_i24): the level-1 position update
@@ -1449,6 +1472,20 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
 
 // ---- wedge fields (mcl_wedge.h) built on the device at set_map ------------------------------------------------
 // one thread per row of the padded grid: next / previous stop cell in the row (dist == 0 marks a stop)
+// A wedge field (Hp x Wps bytes, LDS encoding: stop = 0xFF, skips 1..127) -> the copy k_rays_sweep<.., GLOBAL> probes in global
+// memory: (Hp + 4) rows of `pitch` bytes, the padded grid at offset (2, 2), everything else -- the two-cell ring around it and the
+// row padding -- stop.  A jump from inside the grid lands inside it or at most one cell beyond (the skip field counts the
+// outside as stop), so no address a walk computes leaves the array.
+__global__ __launch_bounds__(256) void k_ring_field(const uint8_t *__restrict__ src, int Wp, int Hp, int Wps, int pitch, uint8_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;          // destination column / row
+    if (x >= pitch) return;
+    const int gx = x - 2, gy = y - 2;
+    uint8_t v = 0xFF;
+    if (gx >= 0 && gx < Wp && gy >= 0 && gy < Hp) v = src[(size_t)gy * Wps + gx];
+    dst[(size_t)y * pitch + x] = v;
+}
+
 __global__ void k_row_tables(const uint8_t *__restrict__ dist, int Wp, int Hp, int Wps, int32_t *__restrict__ nxt, int32_t *__restrict__ prv)
 {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2232,7 +2269,7 @@ __global__ __launch_bounds__(256) void k_rays_fix(RayArgs a)
             ++cnt_exact;
         }
         atomicAdd(&a.logw[p], (double)a.Lt[(size_t)r * a.bpad + j]);
-        if (a.steps) a.steps[(size_t)(a.slot_space ? (int64_t)a.perm[p] : p) * a.B + j] = (uint8_t)r;
+        if (a.steps || a.steps16) store_step(a, a.slot_space ? (int64_t)a.perm[p] : p, j, r);
         if (COUNT) cnt_probe += np;
     }
     }
@@ -2282,7 +2319,7 @@ __global__ __launch_bounds__(256) void k_rays_exact(RayArgs a)
         }
         if (lane == 0) {
             atomicAdd(&a.logw[p], (double)a.Lt[(size_t)r * a.bpad + j]);
-            if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+            if (a.steps || a.steps16) store_step(a, i, j, r);
             ++done;
         }
     }
@@ -2460,7 +2497,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_far(RayArgs a)
                         ++cnt_exact;
                     }
                     acc += (double)a.Lt[(size_t)r * a.bpad + j];
-                    if (a.steps) a.steps[(size_t)i * a.B + j] = (uint8_t)r;
+                    if (a.steps || a.steps16) store_step(a, i, j, r);
                     if (COUNT) cnt_probe += np;
                 }
             }
@@ -2498,9 +2535,6 @@ __global__ void k_product_weights(const uint8_t *__restrict__ steps, const uint1
 // K4 / K7: reductions.  Fixed grid (kRedBlocks x 256) with grid-stride loops and a fixed-order
 // final pass: deterministic for a given N.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRedBlocks = 1024;
-constexpr int kRedThreads = 256;
-
 __global__ __launch_bounds__(kRedThreads) void k_reduce_max(const double *__restrict__ v, int64_t n, double *__restrict__ part)
 {
     __shared__ double sm[kRedThreads / 64];
@@ -2537,10 +2571,27 @@ __global__ __launch_bounds__(kRedThreads) void k_weights(const double *__restric
                                                         const double *__restrict__ y, const double *__restrict__ th, int64_t n,
                                                         double *__restrict__ w_out, uint64_t *__restrict__ q_out,
                                                         double *__restrict__ part /* gridDim.x * 8 */,
-                                                        double *__restrict__ carry_out /* logw - max, or null */)
+                                                        double *__restrict__ carry_out /* logw - max, or null */,
+                                                        const double *__restrict__ max_parts = nullptr, int n_max_parts = 0)
 {
     __shared__ double sm[kRedThreads / 64][7];
-    const double mx = *maxp;
+    // max_parts: the maximum is still in pieces (per-workgroup maxima of an earlier kernel; a separate array from `part`): every
+    // workgroup reduces the few KB itself -- a maximum does not depend on the order -- instead of a one-workgroup launch in
+    // between, and the first leaves it in *maxp for the host
+    double mx;
+    if (max_parts) {
+        __shared__ double mxs[kRedThreads / 64];
+        double m = -INFINITY;
+        for (int i = threadIdx.x; i < n_max_parts; i += kRedThreads) m = fmax(m, max_parts[i]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) mxs[threadIdx.x >> 6] = m;
+        __syncthreads();
+        mx = mxs[0];
+        for (int k = 1; k < kRedThreads / 64; ++k) mx = fmax(mx, mxs[k]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<double *>(maxp)[0] = mx;
+    } else {
+        mx = *maxp;
+    }
     double sw = 0, swx = 0, swy = 0, sws = 0, swc = 0, sww = 0;
     uint64_t sq = 0;
     for (int64_t i = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRedThreads) {
@@ -2575,20 +2626,23 @@ __global__ __launch_bounds__(kRedThreads) void k_weights(const double *__restric
         p[0] = t[0]; p[1] = __longlong_as_double((long long)tq); p[2] = t[2]; p[3] = t[3]; p[4] = t[4]; p[5] = t[5]; p[6] = t[6];
     }
 }
-// scalars[1..6] = fixed-order sums of the partials (scalars[0] = max stays)
-__global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__restrict__ part, int nb, double *__restrict__ scalars)
+// scalars[1..6] = fixed-order sums of the partials (scalars[0] = max stays): the first kRedThreads threads of the workgroup,
+// thread t over partials t, t + kRedThreads, ..., wave butterflies, waves in order.  sm: [kRedThreads / 64][7] doubles of LDS.
+// Every thread of the workgroup must call it (one barrier inside).
+__device__ __forceinline__ void final_sums_of(const double *__restrict__ part, int nb, double *__restrict__ scalars, double (*sm)[7])
 {
-    __shared__ double sm[kRedThreads / 64][7];
+    const bool mine = threadIdx.x < kRedThreads;
     double t[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t tq = 0;
-    for (int i = threadIdx.x; i < nb; i += kRedThreads) {
-        const double *p = part + (size_t)i * 8;
-        t[0] += p[0]; tq += (uint64_t)__double_as_longlong(p[1]); t[2] += p[2]; t[3] += p[3]; t[4] += p[4]; t[5] += p[5]; t[6] += p[6];
-    }
+    if (mine)
+        for (int i = threadIdx.x; i < nb; i += kRedThreads) {
+            const double *p = part + (size_t)i * 8;
+            t[0] += p[0]; tq += (uint64_t)__double_as_longlong(p[1]); t[2] += p[2]; t[3] += p[3]; t[4] += p[4]; t[5] += p[5]; t[6] += p[6];
+        }
     t[0] = wave_sum(t[0]); t[2] = wave_sum(t[2]); t[3] = wave_sum(t[3]); t[4] = wave_sum(t[4]); t[5] = wave_sum(t[5]); t[6] = wave_sum(t[6]);
     tq = wave_sum_u64(tq);
     int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    if (mine && (threadIdx.x & 63) == 0) {
         sm[wv][0] = t[0]; sm[wv][1] = __longlong_as_double((long long)tq); sm[wv][2] = t[2]; sm[wv][3] = t[3]; sm[wv][4] = t[4]; sm[wv][5] = t[5]; sm[wv][6] = t[6];
     }
     __syncthreads();
@@ -2603,6 +2657,11 @@ __global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__rest
         scalars[3] = r[2]; scalars[4] = r[3]; scalars[5] = r[4]; scalars[6] = r[5];
         scalars[7] = r[6];                      // sum w^2: effective sample size = (sum w)^2 / sum w^2
     }
+}
+__global__ __launch_bounds__(kRedThreads) void k_final_sums(const double *__restrict__ part, int nb, double *__restrict__ scalars)
+{
+    __shared__ double sm[kRedThreads / 64][7];
+    final_sums_of(part, nb, scalars, sm);
 }
 
 // The whole tail of a SMALL update (N <= kTinyTailMax) by ONE workgroup: maximum, max-subtracted weights, fixed-point

@@ -147,9 +147,12 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
                                                   double4 *__restrict__ out)
 {
     __shared__ double sm[4][7];
-    if ((int)blockIdx.x >= m_ptr[0]) return;
-    const int64_t p_begin = (int64_t)ub[blockIdx.x];
-    const int64_t p_end = (int64_t)ub[blockIdx.x + 1];
+    // (the number of units is only known on the device: a fixed grid strides over them -- one block per POSSIBLE unit was 65 000
+    //  empty blocks, 10 us of a 262 144-particle update)
+    for (int u = (int)blockIdx.x; u < m_ptr[0]; u += (int)gridDim.x) {
+    if (u != (int)blockIdx.x) __syncthreads();             // sm is reused
+    const int64_t p_begin = (int64_t)ub[u];
+    const int64_t p_end = (int64_t)ub[u + 1];
     double sx = 0.0, sy = 0.0, cnt = 0.0, x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
     for (int64_t s = p_begin + threadIdx.x; s < p_end; s += blockDim.x) {
         const double4 c = pcs[s];
@@ -164,10 +167,11 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
     if ((threadIdx.x & 63) == 0) { sm[w][0] = sx; sm[w][1] = sy; sm[w][2] = cnt; sm[w][3] = x0; sm[w][4] = x1; sm[w][5] = y0; sm[w][6] = y1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[2 * (size_t)blockIdx.x] = make_double4(sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0], sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1],
+        out[2 * (size_t)u] = make_double4(sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0], sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1],
                                                   sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2], 0.0);
-        out[2 * (size_t)blockIdx.x + 1] = make_double4(fmin(fmin(sm[0][3], sm[1][3]), fmin(sm[2][3], sm[3][3])), fmax(fmax(sm[0][4], sm[1][4]), fmax(sm[2][4], sm[3][4])),
+        out[2 * (size_t)u + 1] = make_double4(fmin(fmin(sm[0][3], sm[1][3]), fmin(sm[2][3], sm[3][3])), fmax(fmax(sm[0][4], sm[1][4]), fmax(sm[2][4], sm[3][4])),
                                                       fmin(fmin(sm[0][5], sm[1][5]), fmin(sm[2][5], sm[3][5])), fmax(fmax(sm[0][6], sm[1][6]), fmax(sm[2][6], sm[3][6])));
+    }
     }
 }
 
@@ -213,13 +217,15 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
     auto join = [](float4 p, float4 q) { return make_float4(fminf(p.x, q.x), fmaxf(p.y, q.y), fminf(p.z, q.z), fmaxf(p.w, q.w)); };
     for (int b0 = 0; b0 < nblocks; b0 += kPlanBlocks) {
         const int ubase = b0 * kSwRunMax;
-        for (int k = threadIdx.x; k < U / 2; k += 1024) pyr[off1 + k] = join(unit_box(ubase + 2 * k), unit_box(ubase + 2 * k + 1));
+        // (only the blocks of this pass that hold units: a 262 144-particle set is 256 units of the 4096 a pass has room for)
+        const int ucnt = min(U, ((M - ubase + kSwRunMax - 1) / kSwRunMax) * kSwRunMax);
+        for (int k = threadIdx.x; k < ucnt / 2; k += 1024) pyr[off1 + k] = join(unit_box(ubase + 2 * k), unit_box(ubase + 2 * k + 1));
         __syncthreads();
-        for (int k = threadIdx.x; k < U / 4; k += 1024) pyr[off2 + k] = join(pyr[off1 + 2 * k], pyr[off1 + 2 * k + 1]);
+        for (int k = threadIdx.x; k < ucnt / 4; k += 1024) pyr[off2 + k] = join(pyr[off1 + 2 * k], pyr[off1 + 2 * k + 1]);
         __syncthreads();
-        for (int k = threadIdx.x; k < U / 8; k += 1024) pyr[off3 + k] = join(pyr[off2 + 2 * k], pyr[off2 + 2 * k + 1]);
+        for (int k = threadIdx.x; k < ucnt / 8; k += 1024) pyr[off3 + k] = join(pyr[off2 + 2 * k], pyr[off2 + 2 * k + 1]);
         __syncthreads();
-        for (int k = threadIdx.x; k < U / 16; k += 1024) pyr[off4 + k] = join(pyr[off3 + 2 * k], pyr[off3 + 2 * k + 1]);
+        for (int k = threadIdx.x; k < ucnt / 16; k += 1024) pyr[off4 + k] = join(pyr[off3 + 2 * k], pyr[off3 + 2 * k + 1]);
         __syncthreads();
         // box of the aligned run of cc units (a power of two) that starts at unit index r of this pass
         auto run_box = [&](int r, int cc) -> float4 {
@@ -368,7 +374,84 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
           "v55", "v56", "v57")
 
-template <bool COUNT>
+// ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
+// holds (MAX_RANGE_PX up to 2000; cpp:195 puts no bound on it).  Positions are [cell:cb][fraction:fb] relative to the run's
+// window origin, cb + fb = 32 (cb = 11 up to 1000 px of range, else 12), NOT mirrored: direction components are signed and fit
+// v_mad_i32_i24 (|X| <= 2^fb <= 2^21).  The cell's byte comes from a copy of the wedge field with a two-cell ring of stop bytes
+// around the padded grid (RayArgs::distg), so that no address a ray can reach lies outside the array: a jump from inside the grid
+// lands inside it or on the ring (the skip field counts the outside as stop), and a stop ends the walk.  A trip is 9 VALU
+// (5 four-cycle + 4 two-cycle) + one global byte load; its latency (L1 / L2 hits: the fields around the cloud stay resident) is
+// covered by the other seven waves of the SIMD where the LDS round trip was before.
+#define MCL_SWG_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, XX, XY, FB, PITCH, MASK, BASE) \
+    "v_mad_i32_i24 " TX ", " BYIN ", " XX ", " TXIN "\n\t"                                                \
+    "v_mad_i32_i24 " TY ", " BYIN ", " XY ", " TYIN "\n\t"                                                \
+    "v_lshrrev_b32 " T0 ", " FB ", " TY "\n\t"                                                            \
+    "v_lshrrev_b32 " T1 ", " FB ", " TX "\n\t"                                                            \
+    "v_mad_u32_u24 " AD ", " T0 ", " PITCH ", " T1 "\n\t"                                                 \
+    "global_load_sbyte " BY ", " AD ", " BASE "\n\t"                                                      \
+    "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                              \
+    "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                              \
+    "v_min3_u32 " GOUT ", " GIN ", " T0 ", " T1 "\n\t"                                                    \
+    "s_waitcnt vmcnt(0)\n\t"                                                                              \
+    "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                   \
+    "s_andn2_b64 exec, exec, vcc\n\t"
+
+// (memory reads return in order: the trip's vmcnt(0) also lands the next beam's direction and the previous beam's table entry,
+//  which were requested before it -- the two vmcnt(1) of the LDS walk are satisfied trivially here)
+#define MCL_SWG_WALK()                                                                                                         \
+    asm volatile(                                                                                                              \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
+        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
+        "3:\n\t"                                                                                                               \
+        "s_waitcnt vmcnt(1)\n\t"                                                                                               \
+        "v_mul_f64 v[48:49], %[bq], v[42:43]\n\t"                                                                              \
+        "v_fma_f64 v[44:45], %[aq], v[40:41], -v[48:49]\n\t"                                                                   \
+        "v_mul_f64 v[48:49], %[aq], v[42:43]\n\t"                                                                              \
+        "v_fma_f64 v[46:47], %[bq], v[40:41], v[48:49]\n\t"                                                                    \
+        "v_add_f64 v[44:45], v[44:45], %[magic]\n\t"                                                                           \
+        "v_add_f64 v[46:47], v[46:47], %[magic]\n\t"                                                                           \
+        "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
+        "s_mov_b32 %[cd], %[cdinit]\n\t"                                                                                       \
+        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]") \
+        "s_cbranch_execz 2f\n"                                                                                                 \
+        "1:\n\t"                                                                                                               \
+        MCL_SWG_TRIP("v57", "v56", "v49", "v54", "v55", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]") \
+        "s_cbranch_execz 2f\n\t"                                                                                               \
+        "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 1b\n\t"                                                                                                \
+        "s_mov_b32 %[expired], 1\n"                                                                                            \
+        "2:\n\t"                                                                                                               \
+        "s_mov_b64 exec, -1\n\t"                                                                                               \
+        "v_cmp_gt_u32 vcc, %[thr], v56\n\t"                                                                                    \
+        "s_cbranch_vccz 4f\n\t"                                                                                                \
+        "s_mov_b64 exec, vcc\n\t"                                                                                              \
+        "v_mov_b32 %[ambj2], %[ambj1]\n\t"                                                                                     \
+        "v_mov_b32 %[ambj1], %[j16]\n\t"                                                                                       \
+        "v_add_u32 %[ambcnt], 1, %[ambcnt]\n\t"                                                                                \
+        "v_mov_b32 v57, %[zrow]\n\t"                                                                                           \
+        "s_mov_b64 exec, -1\n"                                                                                                 \
+        "4:\n\t"                                                                                                               \
+        "s_waitcnt vmcnt(1)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
+        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
+        "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"                                                                                \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
+        "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 3b\n\t"                                                                                                \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[50:51]"                                                                                   \
+        : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2), \
+          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
+        : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e),       \
+          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
+          [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit),                                       \
+          [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff)                               \
+        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
+          "v55", "v56", "v57")
+
+template <bool COUNT, bool GLOBAL = false>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -383,16 +466,22 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // AUTO / MCL_RAYS_SWEEP off this kernel when it differs (choose_ray_mode), so this branch is not reachable through the ABI;
     // should a toolchain ever lay the static words out differently anyway, the launch reports a full fix-up list -- which the
     // host answers by re-running the stage with k_rays_skip -- instead of aborting the device.
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
+    if (!GLOBAL && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
         if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = a.fix_cap + 1ull;
         return;
     }
-    constexpr int S = kSwSide;
+    // window side in cells and fractional bits of a position: the 256-cell LDS window with 24 bits, or (GLOBAL) the span of the
+    // cb-bit cell field with 32 - cb bits
+    const int S = GLOBAL ? (1 << a.g_cb) : kSwSide;
+    const uint32_t fbits = GLOBAL ? (uint32_t)(32 - a.g_cb) : (uint32_t)kSwFx;
     // level-1 error bound per axis, in units of 2^-24 px: 0.5 for the origin + (0.5 rounding + 0.625 scale, kSwDirScale)
-    // per sample, s <= P + 1 samples, + 5 for the fp64 rounding of the rotated direction
-    const uint32_t guard_units = (9u * (uint32_t)(a.P + 1) + 7u) / 8u + 6u;
+    // per sample, s <= P + 1 samples, + 5 for the fp64 rounding of the rotated direction.  GLOBAL (units of 2^-fb px, the
+    // direction scaled by exactly 2^fb): 0.5 for the origin + 0.5 per sample + 2 of slack
+    const uint32_t guard_units = GLOBAL ? ((uint32_t)(a.P + 1) + 1u) / 2u + 3u : (9u * (uint32_t)(a.P + 1) + 7u) / 8u + 6u;
     const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : 2u * guard_units;
-    const uint32_t fmask = (1u << kSwFx) - 1u;
+    const uint32_t fmask = (1u << fbits) - 1u;
+    const uint32_t gpitch = (uint32_t)a.distg_pitch;           // GLOBAL: row pitch of the ringed wedge fields
+    const uint32_t cdinit = (uint32_t)a.P + 64u;               // GLOBAL: trip countdown (a walk makes at most P trips)
     const uint32_t permsel = 0x0C0C0703u;                      // v_perm_b32(Ty, Tx): byte 0 = Tx[31:24], byte 1 = Ty[31:24], rest 0
     const uint32_t st8 = (uint32_t)__builtin_amdgcn_readfirstlane(a.ltd_cols * 8);
     const uint32_t zrow = (uint32_t)(a.P + 1);                 // "samples left" that selects the all-zero row
@@ -423,11 +512,29 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     for (int gw = 0; gw < G; ++gw) {
     const int kbin = grp * G + gw;
     const int q = kbin >> kWedgeShift;
-    const int sxp = (q == 0 || q == 3), syp = (q == 0 || q == 1);
+    // GLOBAL: nothing is mirrored (direction components are signed there)
+    const int sxp = GLOBAL || (q == 0 || q == 3), syp = GLOBAL || (q == 0 || q == 1);
     const bool negy = sxp != syp;
     const int mlo = 3;
     int wx0, wy0;
-    {
+    // GLOBAL: the cell bytes come from gbase[row * pitch + column] with (row, column) relative to the window origin; lanes without
+    // rays probe the in-grid cell (dcx, dcy), item_ok = that cell exists inside the cell field (else the run's box lies off the
+    // map by more than half the span: no particle of it can be traced here, all go to k_rays_far)
+    const uint8_t *gbase = nullptr;
+    int dcx = 2, dcy = 2;
+    bool item_ok = true;
+    if (GLOBAL) {
+        wx0 = ctr.x - (S >> 1);
+        wy0 = ctr.y - (S >> 1);
+        gbase = a.distg + (size_t)kbin * a.distg_stride + ((ptrdiff_t)(wy0 + 2) * (ptrdiff_t)a.distg_pitch + (ptrdiff_t)(wx0 + 2));
+        dcx = min(max(ctr.x, 0), a.Wp - 1) - wx0;
+        dcy = min(max(ctr.y, 0), a.Hp - 1) - wy0;
+        item_ok = dcx >= 1 && dcx <= S - 2 && dcy >= 1 && dcy <= S - 2;
+        if (gw > 0) __syncthreads();                                       // every wave is done with the previous pass's chunk counter
+        if (threadIdx.x == 0) chunk_sh = 0u;
+        __syncthreads();
+    } else {
+        constexpr int S = kSwSide;
         const int E = S - (a.P + 2) - mlo;
         const int back = E / 2 + mlo;
         const int cxm = ctr.x, cym = ctr.y;
@@ -472,7 +579,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // chunks x parts ~ 16.  A piece repeats the per-particle setup and its load latencies (about a tenth of a chunk), which is
     // why longer passes are left alone (quartering the last 16 chunks of every pass: 3 % slower on the tracking cloud).
     const uint32_t nchunks = (p_end - p_begin + 63u) >> 6;
-    const uint32_t parts_all = (COUNT || a.steps || nchunks > 8u) ? 1u : nchunks > 4u ? 2u : nchunks > 2u ? 4u : nchunks > 1u ? 8u : 16u;
+    const bool want_steps = a.steps != nullptr || a.steps16 != nullptr;
+    // (split16: passes of nine to sixteen chunks -- one per wave, nothing for a quick wave to take over -- are halved as well;
+    //  set by the host for small launches, where a workgroup sees a handful of items and waits at the end of every one)
+    const uint32_t parts_all = (COUNT || want_steps || nchunks > (a.split16 ? 16u : 8u)) ? 1u : nchunks > 4u ? 2u : nchunks > 2u ? 4u : nchunks > 1u ? 8u : 16u;
     const uint32_t npieces = nchunks * parts_all;
     for (;;) {
         uint32_t piece = 0;
@@ -506,10 +616,12 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         if (!have) { n1 = 0; n2 = 0; }
         const double wpx = pci.z - (double)(wx0 - 1);
         const double wpy = pci.w - (double)(wy0 - 1);
-        const double fwd = (double)(a.P + 2), bwd = 2.0;
+        // GLOBAL: a ray may run either way along both axes, and the particle's own cell must exist in the (ringed) field
+        const double fwd = (double)(a.P + (GLOBAL ? 3 : 2)), bwd = GLOBAL ? fwd : 2.0;
         const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
         const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
-        const bool inwin = inx && iny;
+        const bool ingrid = !GLOBAL || (item_ok && pci.z >= -1.0 && pci.z < (double)(a.Wp - 1) && pci.w >= -1.0 && pci.w < (double)(a.Hp - 1));
+        const bool inwin = inx && iny && ingrid;
         uint32_t i = 0xFFFFFFFFu;                                  // particle index, loaded by the rare paths that need it
         if (!inwin && n1 + n2 > 0) {                           // not in this window (or NaN): k_rays_far does this pair
             // flags, lists and sums are slot-indexed; the first flag of a slot also lists it for k_rays_far
@@ -524,21 +636,25 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // makes reads that cell, whose byte is never 0, and leaves the loop at once; its table column is the zero column B
         const bool live = total > 0;
         // position in the mirrored window (the rays of the wedge run towards +x, +y there)
-        const double lpx = live ? (sxp ? wpx : (double)S - wpx) : 2.5, lpy = live ? (syp ? wpy : (double)S - wpy) : 2.5;
+        const double lpx = live ? (sxp ? wpx : (double)S - wpx) : (double)dcx + 0.5, lpy = live ? (syp ? wpy : (double)S - wpy) : (double)dcy + 0.5;
         const double p0x = lpx + kMagic, p0y = lpy + kMagic;
         const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
         const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
-        const int d0 = ldsb[((cy0 & (S - 1)) << 8) | (cx0 & (S - 1))];
+        int d0;
+        if (GLOBAL) d0 = live ? (int)gbase[(ptrdiff_t)cy0 * (ptrdiff_t)a.distg_pitch + cx0] : 1;      // (a live lane is in the window and in the grid)
+        else d0 = ldsb[((cy0 & (kSwSide - 1)) << 8) | (cx0 & (kSwSide - 1))];
         const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
         // no stop within range: look at sample P only (it is free: the skip says so), which ends the walk with "no hit"
         const uint32_t s0e = (uint32_t)(s0 <= a.P ? s0 : a.P);
         const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
         // window-relative origin in 2^-24 px, biased by the guard (see MCL_SW_TRIP)
-        const uint32_t P0x = (uint32_t)rint_i32(lpx * 16777216.0 - 2147483648.0) + 0x80000000u + guard_units;
-        const uint32_t P0y = (uint32_t)rint_i32(lpy * 16777216.0 - 2147483648.0) + 0x80000000u + guard_units;
+        const double pscale = GLOBAL ? (double)(1u << fbits) : 16777216.0;
+        const uint32_t P0x = (uint32_t)rint_i32(lpx * pscale - 2147483648.0) + 0x80000000u + guard_units;
+        const uint32_t P0y = (uint32_t)rint_i32(lpy * pscale - 2147483648.0) + 0x80000000u + guard_units;
         const int rem_start = live ? a.P - (int)s0e : 0;
         // direction components in the mirrored window: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
-        const double dsc = sxp ? kSwDirScale : -kSwDirScale;
+        // (GLOBAL: signed components scaled by exactly 2^fb)
+        const double dsc = GLOBAL ? (double)(1u << fbits) : (sxp ? kSwDirScale : -kSwDirScale);
         const double aq = live ? pci.x * dsc : 0.0, bq = live ? pci.y * dsc : 0.0;
         // A lane whose scan BEGINS or ENDS inside this wedge has fewer beams here than the lanes whose scan covers the wedge
         // (with sixty-four headings 20 degrees apart -- the chunks of a uniform cloud -- anything from 1 to a full wedge's 90),
@@ -569,7 +685,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         uint32_t ambcnt = 0, ambj1 = 0, ambj2 = 0;
         int t_done = 0;
         bool expired_fast = false;
-        const bool fast = !COUNT && !a.steps && !wraps && tmax > 0 && tmin > 0;
+        const bool fast = !COUNT && !want_steps && !wraps && tmax > 0 && tmin > 0;
         if (!fast && part > 0u) continue;                         // the slow forms of a pass are not split: piece 0 does all of it
         int walk_t0 = 0, walk_n = 0;                               // slots [walk_t0, walk_t0 + walk_n) of every lane: this piece's share
         if (fast) {
@@ -585,7 +701,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
-            if (negy) MCL_SW_WALK("-"); else MCL_SW_WALK("");
+            if constexpr (GLOBAL) { MCL_SWG_WALK(); }
+            else { if (negy) MCL_SW_WALK("-"); else MCL_SW_WALK(""); }
             expired_fast = expired != 0u;
         }
         if (fast) t_done = part + 1u == parts ? tmin : tmax;       // the ragged rest belongs to the last piece
@@ -596,7 +713,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             const int jlast = total > 0 ? (n2 > 0 ? a.B - 1 : jb - 1) : 0;
             int j = jfirst + t_done;                                  // t_done > 0 only without a second range
             if (j > jlast) j = jlast;
-            if (i == 0xFFFFFFFFu && (a.steps || COUNT)) i = a.perm[sl];
+            if (i == 0xFFFFFFFFu && (want_steps || COUNT)) i = a.perm[sl];
             double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
             double lt_pending = 0.0;
             for (int t = t_done; t < tmax; ++t) {
@@ -616,7 +733,29 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 int rem;
                 uint32_t g;
                 bool expired = false;
-                if (!COUNT) {
+                if (!COUNT && GLOBAL) {
+                    uint32_t Tx, Ty, t0, t1, addr, byte;
+                    unsigned long long saved_exec;
+                    uint32_t countdown;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "s_mov_b32 %[cd], %[cdinit]\n\t"
+                        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]")
+                        "s_cbranch_execz 2f\n"
+                        "1:\n\t"
+                        MCL_SWG_TRIP("%[rem]", "%[g]", "%[by]", "%[tx]", "%[ty]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]")
+                        "s_cbranch_execz 2f\n\t"
+                        "s_sub_u32 %[cd], %[cd], 1\n\t"
+                        "s_cbranch_scc0 1b\n"
+                        "2:\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
+                          [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                        : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
+                          [mask] "s"(fmask), [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit)
+                        : "memory", "vcc", "scc");
+                    expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
+                } else if (!COUNT) {
                     uint32_t Tx, Ty, t0, t1, addr, byte;
                     unsigned long long saved_exec;
                     uint32_t countdown;
@@ -646,17 +785,23 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     g = g0;
                     uint32_t Tx = P0x, Ty = P0y, by = s0e;
                     do {
-                        Tx += (by & 0xFFFFFFu) * (Xx & 0xFFFFFFu);
-                        Ty += (by & 0xFFFFFFu) * (Xy & 0xFFFFFFu);
+                        if (GLOBAL) {                     // signed components (v_mad_i32_i24)
+                            Tx += (uint32_t)((int)by * (int)Xx);
+                            Ty += (uint32_t)((int)by * (int)Xy);
+                        } else {
+                            Tx += (by & 0xFFFFFFu) * (Xx & 0xFFFFFFu);
+                            Ty += (by & 0xFFFFFFu) * (Xy & 0xFFFFFFu);
+                        }
                         const uint32_t gm = (Tx & fmask) < (Ty & fmask) ? (Tx & fmask) : (Ty & fmask);
                         g = g < gm ? g : gm;
-                        by = (uint32_t)(int)(int8_t)ldsb[((Ty >> kSwFx) << 8) | (Tx >> kSwFx)];
+                        if (GLOBAL) by = (uint32_t)(int)(int8_t)gbase[(size_t)(Ty >> fbits) * gpitch + (Tx >> fbits)];
+                        else by = (uint32_t)(int)(int8_t)ldsb[((Ty >> kSwFx) << 8) | (Tx >> kSwFx)];
                         uint32_t nr;
                         const bool over = __builtin_usub_overflow((uint32_t)rem, by, &nr);
                         go = !over;
                         rem = (int)nr;
                         cnt_probe += (go && valid) ? 1 : 0;
-                    } while (go && ++trips <= 300);
+                    } while (go && ++trips <= (GLOBAL ? (int)cdinit : 300));
                     if (go) g = 0u;
                 }
                 if (COUNT && valid) ++cnt_probe;
@@ -667,7 +812,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     const int left = rem > 0 ? rem : 0;                 // samples left at the hit; 0 = no hit (step index P)
                     lt_pending = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.Ltd) +
                                                                    mad_u24_s((uint32_t)(left + kSwUnder), st8, (uint32_t)(jcur + a.beam_margin) << 3));
-                    if (a.steps) a.steps[(size_t)i * a.B + jcur] = (uint8_t)(a.P - left);
+                    if (want_steps) store_step(a, (int64_t)i, jcur, a.P - left);
                 }
                 if (amb) {
                     const unsigned int fslot = atomicAdd(&fixn_sh, 1u);
@@ -714,10 +859,24 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
 // k_rays_fix / k_rays_exact added: fp64 atomics of earlier kernels, which plain loads see, profiles/r02_coherence.txt), read
 // coalesced in sorted-slot order; one scattered 8-byte store per particle puts it where the rest of the update expects it.
 // Also the per-workgroup maximum for the normalisation (k_final_max reduces `maxpart`).
+// The first workgroup also raises the overflow flag of the fix-up lists (what k_fix_overflow does for the other ray kernels: *over =
+// number of segments whose append count exceeded the capacity; the counts are final, every kernel that appends ran before this one).
 __global__ __launch_bounds__(256) void k_combine_logw(int64_t n, const uint32_t *__restrict__ perm, const double *__restrict__ acc,
-                                                     double *__restrict__ logw, double *__restrict__ maxpart)
+                                                     double *__restrict__ logw, double *__restrict__ maxpart,
+                                                     const unsigned long long *__restrict__ fix_counts, int nseg, unsigned long long fix_cap,
+                                                     unsigned long long *__restrict__ over)
 {
     __shared__ double sm[4];
+    __shared__ unsigned int over_sh;
+    if (blockIdx.x == 0 && over) {
+        if (threadIdx.x == 0) over_sh = 0u;
+        __syncthreads();
+        unsigned int c = 0;
+        for (int k = threadIdx.x; k < nseg; k += blockDim.x) c += fix_counts[(size_t)k * 8] > fix_cap ? 1u : 0u;
+        if (c) atomicAdd(&over_sh, c);
+        __syncthreads();
+        if (threadIdx.x == 0) *over = over_sh;
+    }
     double m = -INFINITY;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         const double v = acc[s];

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lds_windows: (tests/test_gpu_sweep_global.py) the test sets MCL_SWEEP_GLOBAL itself, if at all")
 
 
 @pytest.fixture(scope="session")

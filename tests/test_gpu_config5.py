@@ -103,7 +103,8 @@ def one_engine_1081(orc, engine_mod, spielberg, spielberg_oracle):
     p0 = e.get_particles()
     # the device-made cloud is the spec's (Philox keyed by the global index): a slice in the middle and the last particles
     for first in (0, n // 2 + 12345, n - 4096):
-        assert np.array_equal(p0[:, first:first + 4096], orc.eng_init_pose(SEED, 0, (0.0, 0.0, 0.0), first, 4096))
+        np.testing.assert_allclose(p0[:, first:first + 4096], orc.eng_init_pose(SEED, 0, (0.0, 0.0, 0.0), first, 4096),
+                                   rtol=1e-13, atol=1e-13)                   # Box-Muller: device libm vs glibc
     L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
     oi = orc.obs_index(obs, om)
     poses = []

@@ -107,17 +107,19 @@ def test_planned_ray_kernel_is_known_before_the_first_update(orc, engine_mod, sp
     k, why = e.planned_ray_kernel()
     assert k == "k_rays_skip" and "monotone" in why
     e.close()
-    # a 0.025 m map: MAX_RANGE_PX = 479 (cpp:195 has no bound), beyond the 256-cell windows
+    # a 0.025 m map: MAX_RANGE_PX = 479 (cpp:195 has no bound), beyond the 256-cell LDS windows: the same kernel on the wedge
+    # fields in global memory
     fine = maps_mod.synthetic_fine025(spielberg)
     e = engine_mod.Engine(max_particles=131072)
     e.set_map(fine.data, fine.resolution, fine.origin_x, fine.origin_y)
     e.set_beam_angles(ang)
-    assert e.max_range_px() == 479
+    assert e.max_range_px == 479
     k, why = e.planned_ray_kernel()
-    assert k == "k_rays_skip" and "MAX_RANGE_PX" in why
+    assert k == "k_rays_sweep" and "global memory" in why
     # a configured kernel that cannot run with this map: 0 / None up front, MCL_ERR_UNSUPPORTED from the update
-    e2 = engine_mod.Engine(max_particles=1024, ray_kernel=engine_mod.RAYS_SWEEP)
+    e2 = engine_mod.Engine(max_particles=1024, ray_kernel=engine_mod.RAYS_CELL)
     e2.set_map(fine.data, fine.resolution, fine.origin_x, fine.origin_y)
     e2.set_beam_angles(ang)
-    assert e2.planned_ray_kernel()[0] is None
+    k2, why2 = e2.planned_ray_kernel()
+    assert k2 is None and "MAX_RANGE_PX" in why2
     e.close(); e2.close()

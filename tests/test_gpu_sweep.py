@@ -167,10 +167,10 @@ def test_work_list_overflow_falls_back_on_every_update(orc, engine_mod, spielber
         assert np.array_equal(out["auto"][k], out["skip"][k])
 
 
-def test_range_beyond_the_windowed_kernels_takes_k_rays_skip(orc, engine_mod, spielberg):
-    """k_rays_sweep's windows are 256 cells wide, k_rays_cell's 280: a range of more than 243 px leaves neither enough
-    play (mcl_rays_sweep.h sweep_window_fits; mcl_set_map's qside).  AUTO then stays on k_rays_skip at any size, an
-    explicit MCL_RAYS_SWEEP is refused; the log-weights equal the oracle's."""
+def test_range_beyond_the_lds_windows_takes_the_global_fields(orc, engine_mod, spielberg):
+    """k_rays_sweep's LDS windows are 256 cells wide, k_rays_cell's 280: a range of more than 243 px leaves neither enough
+    play (mcl_rays_sweep.h sweep_window_fits; mcl_set_map's qside).  AUTO then runs k_rays_sweep on the wedge fields in global
+    memory (k_rays_sweep<.., GLOBAL>), an explicit MCL_RAYS_CELL is refused; the log-weights equal the oracle's."""
     res = 0.0485                                                     # 12 m / 0.0485 = 247 px
     om = orc.OracleMap(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
     assert 243 < om.max_range_px <= 255
@@ -181,14 +181,18 @@ def test_range_beyond_the_windowed_kernels_takes_k_rays_skip(orc, engine_mod, sp
     e = engine_mod.Engine(max_particles=n, seed=1)
     e.set_map(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
     e.set_beam_angles(ang)
+    k, why = e.planned_ray_kernel()
+    assert k == "k_rays_sweep" and "global memory" in why
     e.set_particles(p, np.full(n, 1.0 / n))
     e.sensor_update(obs)
-    assert e.ray_kernel_name() == "k_rays_skip"
+    assert e.ray_kernel_name() == "k_rays_sweep"
     assert np.array_equal(e.log_weights(), oracle_logw(orc, om, p, ang, obs))
+    assert e.counters()["off_window_particles"] == 0
     e.close()
-    e = engine_mod.Engine(max_particles=n, seed=1, ray_kernel=engine_mod.RAYS_SWEEP)
+    e = engine_mod.Engine(max_particles=n, seed=1, ray_kernel=engine_mod.RAYS_CELL)
     e.set_map(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
     e.set_beam_angles(ang)
+    assert e.planned_ray_kernel()[0] is None
     e.set_particles(p, np.full(n, 1.0 / n))
     with pytest.raises(engine_mod.EngineError):
         e.sensor_update(obs)
@@ -313,7 +317,7 @@ def test_global_cloud_takes_the_windowed_far_pass(orc, engine_mod, sibal1, sibal
 def test_2p5_cm_cells_range_of_479_px(orc, engine_mod, sibal1):
     """cpp:195 puts no bound on MAX_RANGE_PX = int(max_range / resolution): a 0.025 m map at 12 m is 479 px (the float32
     resolution is a hair above 0.025).  The step
-    indices then need 16 bits and no LDS window holds a particle's reach, so AUTO runs k_rays_skip's global-field path
+    indices then need 16 bits and no LDS window holds a particle's reach, so AUTO -- at this small size -- runs k_rays_skip's global-field path
     (and MARCH the literal march): ray steps, log-weights and the children of a full update equal the oracle's."""
     grid = np.kron(sibal1.data, np.ones((2, 2), np.int8)).astype(np.int8)          # the same rooms at half the cell size
     res = 0.025
@@ -352,8 +356,9 @@ def test_2p5_cm_cells_range_of_479_px(orc, engine_mod, sibal1):
         logw2, _, _ = orc.eng_log_weights(om, parts, ang, orc.obs_index(obs, om), L)
         assert np.array_equal(e.log_weights(), logw2)
         e.close()
-    # the windowed kernels cannot take this map: asking for one is refused
-    e = engine_mod.Engine(max_particles=n, ray_kernel=engine_mod.RAYS_SWEEP)
+    # the LDS-windowed kernels cannot take this map: asking for one is refused (MCL_RAYS_SWEEP runs on the global wedge fields:
+    # tests/test_gpu_sweep_global.py)
+    e = engine_mod.Engine(max_particles=n, ray_kernel=engine_mod.RAYS_CELL)
     e.set_map(grid, res, sibal1.origin_x, sibal1.origin_y)
     e.set_beam_angles(ang)
     e.set_particles(p, np.full(n, 1.0 / n))
