@@ -65,6 +65,7 @@ struct mcl_engine {
     float *d_angle = nullptr;
     double2 *d_beam_cs = nullptr;
     double2 *d_beam_csx = nullptr;      // k_rays_sweep's copy with virtual beams either side (set_beam_angles)
+    double2 *d_beam_csxg = nullptr;     // the same for the global-field form: a virtual beam repeats the first / last REAL beam
     int beam_pad = 0, beam_margin = 0;
     int32_t *d_obs_idx = nullptr;
     float *d_obs = nullptr;
@@ -84,7 +85,7 @@ struct mcl_engine {
     // k_rays_sweep on the wedge fields in GLOBAL memory (ranges a 256-cell LDS window cannot hold; MCL_SWEEP_GLOBAL=1 forces it)
     uint8_t *d_distg = nullptr;         // kWedges fields with a two-cell stop ring: (Hp + 4) x distg_pitch bytes each
     int distg_pitch = 0, g_cb = 0;      // row pitch; cell bits of a window-relative position (10 .. 12)
-    size_t distg_stride = 0;
+    size_t distg_stride = 0, distg_pad = 0;   // bytes per field; stop-filled bytes before the first / after the last field
     bool sweep_global = false;          // this map takes the global-field variant (decided at mcl_set_map)
     bool env_sweep_global = false;
     int env_sw_split16 = -1;            // MCL_SW_SPLIT16=0/1 forces RayArgs::split16 (default: by size)
@@ -535,7 +536,7 @@ void unpack_result(mcl_engine *h)
 // ray's reach, or -- on the global wedge fields -- the span of the cell field minus the reach on both sides
 int sweep_play(const mcl_engine *h)
 {
-    if (h->sweep_global) return 2 * ((1 << (h->g_cb - 1)) - (h->P + 3) - 2);
+    if (h->sweep_global) return 1 << 20;             // every lane has its own origin there: no window a run could outgrow
     return mcl::kSwSide - (h->P + 2) - 3;
 }
 
@@ -584,10 +585,10 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
     if (rk == MCL_RAYS_QUAD) { w = windows_ok && h->quad_layout_ok ? "configured: MCL_RAYS_QUAD" : (no_windows ? no_windows : "k_rays_quad's LDS layout check failed"); return windows_ok && h->quad_layout_ok ? 3 : 0; }
     if (rk == MCL_RAYS_CELL) { w = windows_ok && h->cell_layout_ok ? "configured: MCL_RAYS_CELL" : (no_windows ? no_windows : "k_rays_cell's LDS layout check failed"); return windows_ok && h->cell_layout_ok ? 4 : 0; }
     // its windows are 256 cells wide (mcl_rays_sweep.h) and addressed from a raw LDS offset checked at mcl_create
-    // ... or, for ranges beyond that (MAX_RANGE_PX up to kSweepGlobalMaxP), probes the same wedge fields in global memory
+    // ... or, for ranges beyond that (MAX_RANGE_PX up to 2037), probes the same wedge fields in global memory
     const char *no_sweep = h->quad_ok ? nullptr : no_windows;
     if (!no_sweep) {
-        if (h->sweep_global) { if (!h->d_distg) no_sweep = "MAX_RANGE_PX > 1981: beyond the 12-bit cell field of k_rays_sweep's global-field variant"; }
+        if (h->sweep_global) { if (!h->d_distg) no_sweep = "MAX_RANGE_PX > 2037: beyond the 11-bit cell field of k_rays_sweep's global-field form"; }
         else if (!mcl::sweep_window_fits(h->P)) no_sweep = "MAX_RANGE_PX > 243: a 256-cell window of k_rays_sweep cannot hold a ray plus 8 cells of play";
         else if (!h->sweep_layout_ok) no_sweep = "k_rays_sweep's LDS layout check failed at mcl_create";
     }
@@ -847,8 +848,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             if (rc_plan) return rc_plan;
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
-            a.beam_csx = h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
-            a.distg = h->d_distg; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch; a.g_cb = h->g_cb;
+            a.beam_csx = h->sweep_global ? h->d_beam_csxg : h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
+            a.distg = h->d_distg + h->distg_pad; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch; a.g_cb = h->g_cb;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
                 HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
@@ -871,7 +872,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (dbgpath) { HIPCHK(h, hipMalloc(&d_dbg, (size_t)qg.x * 32)); HIPCHK(h, hipMemset(d_dbg, 0, (size_t)qg.x * 32)); a.dbg = d_dbg; }
         // k_rays_far is bound by global-memory latency: 4 workgroups per CU worth of blocks (2 resident at a time)
         dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
-        const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU
+        const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU (2 .. 16 per segment: no difference, round 4)
         HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
             if (sweep_glob) hipLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, a);
@@ -1209,7 +1210,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_maxpart); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_distg); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_cut_start); dfree(h->d_cut_end); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_beam_csxg); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1241,13 +1242,14 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     // budget S - (P+2) - 3 is at least 48 cells, otherwise k_rays_skip's full-LDS nibble window is used
     { const int S = h->env_qside > 0 ? h->env_qside : 280; h->qside = (S - (P + 2) - 3 >= 32) ? S : 0; }
     // k_rays_sweep: the 256-cell LDS windows hold ranges up to 243 px; beyond that (or with MCL_SWEEP_GLOBAL=1) the same walk
-    // probes the wedge fields in global memory, positions in a cell field of g_cb bits that leaves at least 64 cells either side
-    // of a ray's reach (10 bits up to 445 px, 11 up to 957, 12 up to 1981)
+    // probes the wedge fields in global memory, positions relative to an origin of the lane's own in a cell field of g_cb bits that
+    // holds a ray's reach (2^cb >= range + 11: 10 bits up to 1013 px, 11 up to 2037; 22 / 21 fractional bits -- a direction
+    // component of up to 2^22 fits v_mad_i32_i24)
     h->sweep_global = h->env_sweep_global || !mcl::sweep_window_fits(P);
     h->g_cb = 0;
     if (h->sweep_global)
-        for (int cb = 10; cb <= 12 && !h->g_cb; ++cb)
-            if ((1 << (cb - 1)) - (P + 3) >= 64) h->g_cb = cb;
+        for (int cb = 10; cb <= 11 && !h->g_cb; ++cb)
+            if ((1 << cb) >= P + 11) h->g_cb = cb;
     const bool want_wedges = h->qside > 0 || (h->sweep_global && h->g_cb != 0);     // wedge + quadrant fields (k_rays_far reads the latter)
     build_sensor_table(h->cfg, P, h->table);
     const int tw = P + 1;
@@ -1308,12 +1310,18 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
         if (rc_w != MCL_OK) return fail(h, rc_w, "building the wedge fields failed");
         if (h->sweep_global && h->g_cb != 0) {
             // the copies k_rays_sweep<.., GLOBAL> probes: every field with a two-cell ring of stop bytes (k_ring_field)
+            // Memory safety does not rest on the rays being valid: a position can be at most 2^cb rows / columns away from the lane's
+            // own (in-grid) cell, so with (2^cb + 2) rows of stop bytes before the first and after the last field every address
+            // the kernel can form lies inside this allocation (and a ray that strays there reads "stop" and ends).
             h->distg_pitch = (h->Wp + 4 + 63) & ~63;
             h->distg_stride = (size_t)(h->Hp + 4) * (size_t)h->distg_pitch;
-            HIPCHK(h, hipMalloc(&h->d_distg, h->distg_stride * mcl::kWedges));
+            h->distg_pad = (size_t)((1 << h->g_cb) + 2) * (size_t)h->distg_pitch;
+            const size_t galloc = h->distg_stride * mcl::kWedges + 2 * h->distg_pad;
+            HIPCHK(h, hipMalloc(&h->d_distg, galloc));
+            HIPCHK(h, hipMemsetAsync(h->d_distg, 0xFF, galloc, h->stream));
             for (int k = 0; k < mcl::kWedges; ++k)
                 hipLaunchKernelGGL(mcl::k_ring_field, dim3((h->distg_pitch + 255) / 256, h->Hp + 4), dim3(256), 0, h->stream, h->d_distw + (size_t)k * fsz,
-                                   h->Wp, h->Hp, h->Wps, h->distg_pitch, h->d_distg + (size_t)k * h->distg_stride);
+                                   h->Wp, h->Hp, h->Wps, h->distg_pitch, h->d_distg + h->distg_pad + (size_t)k * h->distg_stride);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
@@ -1392,16 +1400,22 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
         }
     }
     const int ncsx = n_beams + 2 * h->beam_margin + 8;
-    std::vector<double2> csx(ncsx);
+    // The LDS form continues the scan's angular grid beyond its ends (a virtual ray then looks like its neighbours' real ones).
+    // Such a ray may leave the lane's wedge by a beam or so, where the wedge's skip field does not hold for it: harmless in an
+    // LDS window (it can only read the window), NOT in the global-field form, where a ray that jumps a wall near the map border
+    // would leave the field -- there a virtual beam repeats the first / last real beam (inside the wedge by construction).
+    std::vector<double2> csx(ncsx), csxg(ncsx);
     for (int i = 0; i < ncsx; ++i) {
         const int j = i - h->beam_margin;
+        const double ac = (double)angles[j < 0 ? 0 : (j < n_beams ? j : n_beams - 1)];
         double a;
         if (j >= 0 && j < n_beams) a = (double)angles[j];
         else if (h->beam_margin > 0) a = (double)angles[0] + (double)j * inc;
-        else a = (double)angles[j < 0 ? 0 : n_beams - 1];
+        else a = ac;
         csx[i] = make_double2(std::cos(a), std::sin(a));
+        csxg[i] = make_double2(std::cos(ac), std::sin(ac));
     }
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_obs_idx); dfree(h->d_obs);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_beam_csxg); dfree(h->d_obs_idx); dfree(h->d_obs);
     if (h->h_obs) { (void)hipHostFree(h->h_obs); h->h_obs = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_obs, (size_t)n_beams * sizeof(float)));
     HIPCHK(h, hipHostMalloc(&h->h_obs, (size_t)n_beams * sizeof(float)));
@@ -1412,6 +1426,8 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
     HIPCHK(h, hipMemcpy(h->d_beam_cs, cs.data(), (size_t)ncs * sizeof(double2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMalloc(&h->d_beam_csx, (size_t)ncsx * sizeof(double2)));
     HIPCHK(h, hipMemcpy(h->d_beam_csx, csx.data(), (size_t)ncsx * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&h->d_beam_csxg, (size_t)ncsx * sizeof(double2)));
+    HIPCHK(h, hipMemcpy(h->d_beam_csxg, csxg.data(), (size_t)ncsx * sizeof(double2), hipMemcpyHostToDevice));
     h->lt_capacity = 0; dfree(h->d_Lt); h->ltd_capacity = 0; dfree(h->d_Ltd); h->ltd_ready = false;
     h->B = n_beams;
     return MCL_OK;

@@ -375,19 +375,23 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           "v55", "v56", "v57")
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
-// holds (MAX_RANGE_PX up to 2000; cpp:195 puts no bound on it).  Positions are [cell:cb][fraction:fb] relative to the run's
-// window origin, cb + fb = 32 (cb = 11 up to 1000 px of range, else 12), NOT mirrored: direction components are signed and fit
-// v_mad_i32_i24 (|X| <= 2^fb <= 2^21).  The cell's byte comes from a copy of the wedge field with a two-cell ring of stop bytes
+// holds (MAX_RANGE_PX up to 2041; cpp:195 puts no bound on it).  Positions are [cell:cb][fraction:fb] relative to an origin of the
+// LANE's own (its particle's cell at index 8, or 2^cb - 9 along an axis the wedge's rays run down), cb + fb = 32 with 2^cb >= range + 11
+// (cb = 10 up to 1013 px of range, 11 up to 2037): there is no window a particle could miss.  Every ray it traces must be INSIDE its
+// wedge -- a ray the wedge's skip field does not hold for could jump a wall next to the map border and leave the field -- which is why
+// this form's virtual beams repeat the scan's first / last real beam (mcl_set_beam_angles) instead of continuing its angular grid.  Nothing is mirrored: direction
+// components are signed and fit v_mad_i32_i24 (|X| <= 2^fb <= 2^23).  The cell's byte comes from a copy of the wedge field with a two-cell ring of stop bytes
 // around the padded grid (RayArgs::distg), so that no address a ray can reach lies outside the array: a jump from inside the grid
-// lands inside it or on the ring (the skip field counts the outside as stop), and a stop ends the walk.  A trip is 9 VALU
-// (5 four-cycle + 4 two-cycle) + one global byte load; its latency (L1 / L2 hits: the fields around the cloud stay resident) is
+// lands inside it or on the ring (the skip field counts the outside as stop), and a stop ends the walk.  A trip is 10 VALU
+// (5 four-cycle + 5 two-cycle) + one global byte load; its latency (L1 / L2 hits: the fields around the cloud stay resident) is
 // covered by the other seven waves of the SIMD where the LDS round trip was before.
-#define MCL_SWG_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, XX, XY, FB, PITCH, MASK, BASE) \
+#define MCL_SWG_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, XX, XY, FB, PITCH, MASK, BASE, LB) \
     "v_mad_i32_i24 " TX ", " BYIN ", " XX ", " TXIN "\n\t"                                                \
     "v_mad_i32_i24 " TY ", " BYIN ", " XY ", " TYIN "\n\t"                                                \
     "v_lshrrev_b32 " T0 ", " FB ", " TY "\n\t"                                                            \
     "v_lshrrev_b32 " T1 ", " FB ", " TX "\n\t"                                                            \
     "v_mad_u32_u24 " AD ", " T0 ", " PITCH ", " T1 "\n\t"                                                 \
+    "v_add_u32 " AD ", " AD ", " LB "\n\t"                                                                \
     "global_load_sbyte " BY ", " AD ", " BASE "\n\t"                                                      \
     "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                              \
     "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                              \
@@ -414,10 +418,10 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
         "s_mov_b32 %[cd], %[cdinit]\n\t"                                                                                       \
-        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]") \
+        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]") \
         "s_cbranch_execz 2f\n"                                                                                                 \
         "1:\n\t"                                                                                                               \
-        MCL_SWG_TRIP("v57", "v56", "v49", "v54", "v55", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]") \
+        MCL_SWG_TRIP("v57", "v56", "v49", "v54", "v55", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]") \
         "s_cbranch_execz 2f\n\t"                                                                                               \
         "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
         "s_cbranch_scc0 1b\n\t"                                                                                                \
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
         : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e),       \
           [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
-          [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit),                                       \
+          [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit), [lb] "v"(lane_base),                  \
           [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff)                               \
         : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
           "v55", "v56", "v57")
@@ -517,19 +521,15 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const bool negy = sxp != syp;
     const int mlo = 3;
     int wx0, wy0;
-    // GLOBAL: the cell bytes come from gbase[row * pitch + column] with (row, column) relative to the window origin; lanes without
-    // rays probe the in-grid cell (dcx, dcy), item_ok = that cell exists inside the cell field (else the run's box lies off the
-    // map by more than half the span: no particle of it can be traced here, all go to k_rays_far)
+    // GLOBAL: no window.  Every LANE has its own origin: its particle's cell sits at index 8 (or S - 9 along an axis the wedge's
+    // rays run down), so a ray's cells stay inside [0, S) whatever the run's extent, and the cell byte is
+    // gbase[lane_base + row * pitch + column] with lane_base = the lane origin's offset in the ringed field (32-bit wrap-around
+    // arithmetic: the sum is a valid offset whenever the cell is in the ringed field, which every reachable cell is)
     const uint8_t *gbase = nullptr;
-    int dcx = 2, dcy = 2;
-    bool item_ok = true;
+    const bool qsx = (q == 0 || q == 3), qsy = (q == 0 || q == 1);      // the wedge's rays run up (true) or down the axis
     if (GLOBAL) {
-        wx0 = ctr.x - (S >> 1);
-        wy0 = ctr.y - (S >> 1);
-        gbase = a.distg + (size_t)kbin * a.distg_stride + ((ptrdiff_t)(wy0 + 2) * (ptrdiff_t)a.distg_pitch + (ptrdiff_t)(wx0 + 2));
-        dcx = min(max(ctr.x, 0), a.Wp - 1) - wx0;
-        dcy = min(max(ctr.y, 0), a.Hp - 1) - wy0;
-        item_ok = dcx >= 1 && dcx <= S - 2 && dcy >= 1 && dcy <= S - 2;
+        wx0 = 0; wy0 = 0;
+        gbase = a.distg + (size_t)kbin * a.distg_stride;
         if (gw > 0) __syncthreads();                                       // every wave is done with the previous pass's chunk counter
         if (threadIdx.x == 0) chunk_sh = 0u;
         __syncthreads();
@@ -614,14 +614,26 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         }
         int n1 = jb > ja ? jb - ja : 0, n2 = a.B > ja2 ? a.B - ja2 : 0;
         if (!have) { n1 = 0; n2 = 0; }
-        const double wpx = pci.z - (double)(wx0 - 1);
-        const double wpy = pci.w - (double)(wy0 - 1);
-        // GLOBAL: a ray may run either way along both axes, and the particle's own cell must exist in the (ringed) field
-        const double fwd = (double)(a.P + (GLOBAL ? 3 : 2)), bwd = GLOBAL ? fwd : 2.0;
-        const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
-        const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
-        const bool ingrid = !GLOBAL || (item_ok && pci.z >= -1.0 && pci.z < (double)(a.Wp - 1) && pci.w >= -1.0 && pci.w < (double)(a.Hp - 1));
-        const bool inwin = inx && iny && ingrid;
+        double wpx, wpy;
+        bool inwin;
+        uint32_t lane_base = 0u;
+        if (GLOBAL) {
+            // the particle's own padded cell must exist in the field (NaN fails the comparisons); its position relative to the
+            // lane's origin keeps the fraction of the pixel coordinate
+            inwin = pci.z >= -1.0 && pci.z < (double)(a.Wp - 1) && pci.w >= -1.0 && pci.w < (double)(a.Hp - 1);
+            const int ocx = inwin ? (int)floor(pci.z) + 1 : 0, ocy = inwin ? (int)floor(pci.w) + 1 : 0;
+            const int r0x = qsx ? 8 : S - 9, r0y = qsy ? 8 : S - 9;
+            wpx = inwin ? pci.z - (double)(ocx - 1 - r0x) : (double)r0x + 0.5;
+            wpy = inwin ? pci.w - (double)(ocy - 1 - r0y) : (double)r0y + 0.5;
+            lane_base = (uint32_t)((ocy - r0y + 2) * a.distg_pitch + (ocx - r0x + 2));
+        } else {
+            wpx = pci.z - (double)(wx0 - 1);
+            wpy = pci.w - (double)(wy0 - 1);
+            const double fwd = (double)(a.P + 2), bwd = 2.0;
+            const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
+            const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
+            inwin = inx && iny;
+        }
         uint32_t i = 0xFFFFFFFFu;                                  // particle index, loaded by the rare paths that need it
         if (!inwin && n1 + n2 > 0) {                           // not in this window (or NaN): k_rays_far does this pair
             // flags, lists and sums are slot-indexed; the first flag of a slot also lists it for k_rays_far
@@ -636,12 +648,15 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // makes reads that cell, whose byte is never 0, and leaves the loop at once; its table column is the zero column B
         const bool live = total > 0;
         // position in the mirrored window (the rays of the wedge run towards +x, +y there)
-        const double lpx = live ? (sxp ? wpx : (double)S - wpx) : (double)dcx + 0.5, lpy = live ? (syp ? wpy : (double)S - wpy) : (double)dcy + 0.5;
+        // (GLOBAL: a lane without rays probes padded cell (0, 0) from index (8, 8) of an origin of its own)
+        if (GLOBAL && !live) lane_base = (uint32_t)((0 - 8 + 2) * a.distg_pitch + (0 - 8 + 2));
+        const double dpos = GLOBAL ? 8.5 : 2.5;
+        const double lpx = live ? (sxp ? wpx : (double)S - wpx) : dpos, lpy = live ? (syp ? wpy : (double)S - wpy) : dpos;
         const double p0x = lpx + kMagic, p0y = lpy + kMagic;
         const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
         const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
         int d0;
-        if (GLOBAL) d0 = live ? (int)gbase[(ptrdiff_t)cy0 * (ptrdiff_t)a.distg_pitch + cx0] : 1;      // (a live lane is in the window and in the grid)
+        if (GLOBAL) d0 = (int)gbase[(size_t)(uint32_t)((uint32_t)cy0 * gpitch + (uint32_t)cx0 + lane_base)];      // the own cell (a dead lane: cell (0, 0))
         else d0 = ldsb[((cy0 & (kSwSide - 1)) << 8) | (cx0 & (kSwSide - 1))];
         const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
         // no stop within range: look at sample P only (it is free: the skip says so), which ends the walk with "no hit"
@@ -740,10 +755,10 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     asm volatile(
                         "s_mov_b64 %[sv], exec\n\t"
                         "s_mov_b32 %[cd], %[cdinit]\n\t"
-                        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]")
+                        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]")
                         "s_cbranch_execz 2f\n"
                         "1:\n\t"
-                        MCL_SWG_TRIP("%[rem]", "%[g]", "%[by]", "%[tx]", "%[ty]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]")
+                        MCL_SWG_TRIP("%[rem]", "%[g]", "%[by]", "%[tx]", "%[ty]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]")
                         "s_cbranch_execz 2f\n\t"
                         "s_sub_u32 %[cd], %[cd], 1\n\t"
                         "s_cbranch_scc0 1b\n"
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
                           [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
                         : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
-                          [mask] "s"(fmask), [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit)
+                          [mask] "s"(fmask), [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit), [lb] "v"(lane_base)
                         : "memory", "vcc", "scc");
                     expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
                 } else if (!COUNT) {
@@ -794,7 +809,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         }
                         const uint32_t gm = (Tx & fmask) < (Ty & fmask) ? (Tx & fmask) : (Ty & fmask);
                         g = g < gm ? g : gm;
-                        if (GLOBAL) by = (uint32_t)(int)(int8_t)gbase[(size_t)(Ty >> fbits) * gpitch + (Tx >> fbits)];
+                        if (GLOBAL) by = (uint32_t)(int)(int8_t)gbase[(size_t)(uint32_t)((Ty >> fbits) * gpitch + (Tx >> fbits) + lane_base)];
                         else by = (uint32_t)(int)(int8_t)ldsb[((Ty >> kSwFx) << 8) | (Tx >> kSwFx)];
                         uint32_t nr;
                         const bool over = __builtin_usub_overflow((uint32_t)rem, by, &nr);

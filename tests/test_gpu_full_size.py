@@ -151,3 +151,37 @@ def test_nine_million_particles_plan_in_two_passes(orc, engine_mod, spielberg):
     T = orc.sensor_table(om.max_range_px)
     logw, _, _ = orc.eng_log_weights(om, p[:, pick], ang, orc.obs_index(obs, om), orc.eng_log_table(T))
     assert np.array_equal(out["sweep"][pick], logw)
+
+
+def test_fixed_point_cdf_vs_discrete_distribution_at_4m(orc, engine_mod, sibal1):
+    """The resampling step's one spec deviation MEASURED at the headline size: 4 194 304 children drawn by the engine
+    from the exact integer CDF of weights quantised to 2^-36 of the maximum, against std::discrete_distribution's floating-point
+    partial sums (cpp:658-663, orc_ref_resample_indices) under the same injected uniforms, for the weights an update with many beams
+    leaves (a few per cent of the particles carry everything).  The two can only disagree where a draw falls within ~N * 2^-36
+    (relative) of a CDF step: the count is asserted (and printed for the record), and every disagreement picks a neighbour in CDF
+    order (nothing but particles of negligible weight in between)."""
+    n = 4194304
+    rng = np.random.default_rng(78)
+    ang = orc.beam_angles(angle_step=54)
+    p = np.vstack([rng.uniform(-2, 2, n), rng.uniform(-1, 1, n), rng.uniform(-np.pi, np.pi, n)])
+    w = np.exp(-np.abs(rng.normal(0.0, 40.0, n)))
+    w /= w.sum()
+    u = rng.random(n)
+    e = make_engine(engine_mod, sibal1, ang, n)
+    e.set_particles(p, w)
+    e.update((0.0, 0.0, 0.0), np.full(ang.size, 3.0, np.float32), uniforms=u)
+    got = e.resample_indices()
+    e.close()
+    want = orc.resample_indices(w, u)
+    bad = np.nonzero(got != want)[0]
+    k53 = np.minimum((u * 9007199254740992.0).astype(np.uint64), np.uint64(9007199254740991))
+    assert np.array_equal(got, orc.eng_resample_indices(orc.eng_quantize_weights(w), 0, k53=k53))     # the engine's own spec: exactly
+    print(f"fixed-point CDF vs std::discrete_distribution at {n}: {bad.size} children differ ({bad.size / n:.2e} of the set)")
+    # measured on MI355X / this oracle (round 4): 3 of 4 194 304
+    assert bad.size <= 64, f"{bad.size} of {n} children differ from std::discrete_distribution"
+    q = orc.eng_quantize_weights(w)
+    for m in bad:
+        # the two picks are neighbours in CDF order up to particles of negligible weight: what lies strictly between them sums to
+        # at most 2^-26 of the LARGEST weight (the floating-point partial sums of cpp:658-663 cannot resolve such a step either)
+        lo, hi = sorted((int(got[m]), int(want[m])))
+        assert int(q[lo + 1:hi].sum()) <= 1024, (m, lo, hi, q[lo:hi + 1])

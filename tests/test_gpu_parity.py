@@ -465,6 +465,14 @@ def test_update_scan_downsamples_like_lidarcb(orc, engine_mod, spielberg):
         outs.append((e.get_particles(), e.get_weights(), e.log_weights()))
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+    # ... and against the ORACLE: lidarCB keeps ranges[i * ANGLE_STEP] (cpp:316-320); the log-weights of the particles the raw-scan
+    # update produced equal orc_eng_log_weights on them with that downsampled scan (NaN / +inf / beyond-range readings included)
+    om = orc.OracleMap(spielberg.data, spielberg.resolution, spielberg.origin_x, spielberg.origin_y)
+    ang18 = orc.beam_angles(angle_step=18)
+    down = np.array([raw[i * 18] for i in range(ang18.size)], np.float32)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    logw, _, _ = orc.eng_log_weights(om, outs[1][0], ang18, orc.obs_index(down, om), L)
+    assert np.array_equal(outs[1][2], logw)
     e = make_engine(engine_mod, spielberg, orc.beam_angles(angle_step=18), n)
     e.set_particles(p, np.full(n, 1.0 / n))
     with pytest.raises(engine_mod.EngineError):

@@ -4,11 +4,11 @@ MCL_SWEEP_GLOBAL=1 (read at mcl_create) forces for any map.  Same reference rows
 evaluation), same oracle, same bar: ray steps and log-weights bit for bit.
 
 Part 1 re-runs the oracle comparisons of tests/test_gpu_sweep.py with the variant forced on the reference's own maps (ranges
-of 57 .. 239 px: ten-bit cell field): tracking and scattered clouds, wedge edges, every wedge-group size, non-finite and
+of 57 .. 239 px): tracking and scattered clouds, wedge edges, every wedge-group size, non-finite and
 off-map particles, forced level 2 / level 3, fix-up overflow, beam counts that are multiples of 256, scans that wrap, the sort's
 orderings, several updates.
-Part 2 is the long-range case proper: a 0.025 m map at 12 m (479 px, eleven-bit cell field, 16-bit step indices) and a
-1000-px range (twelve bits), through AUTO at size and through MCL_RAYS_SWEEP with step output."""
+Part 2 is the long-range case proper: a 0.025 m map at 12 m (479 px, 16-bit step indices) and a 1000-px range (both in a ten-bit
+cell field around an origin of the lane's own), through AUTO at size and through MCL_RAYS_SWEEP with step output."""
 import os
 
 import numpy as np
@@ -41,7 +41,7 @@ test_long_range_map_single_unit_runs_and_sparse_cloud = S.test_long_range_map_si
 
 
 def test_scattered_particles_none_off_window(orc, engine_mod, sibal1, sibal1_oracle):
-    """The scattered cloud of test_scattered_particles_and_off_window_pairs: the cell field spans 1024 cells, so only the
+    """The scattered cloud of test_scattered_particles_and_off_window_pairs: every lane has an origin of its own, so only the
     particles OUTSIDE the padded grid are left to k_rays_far (the LDS windows lose a good part of this cloud)."""
     om = sibal1_oracle
     ang = orc.beam_angles(angle_step=5)
@@ -106,7 +106,7 @@ def fine_sibal1(sibal1):
 @pytest.mark.lds_windows
 @pytest.mark.parametrize("res,want_P", [(0.025, 479), (0.012, 999)])
 def test_long_ranges_steps_logw_and_a_full_update(orc, engine_mod, sibal1, res, want_P):
-    """0.025 m cells at 12 m = 479 px (eleven cell bits) and 0.012 m = 999 px (twelve): MCL_RAYS_SWEEP with step output --
+    """0.025 m cells at 12 m = 479 px and 0.012 m = 999 px: MCL_RAYS_SWEEP with step output --
     16-bit step indices, log-weights and the children of a full update equal the oracle's; particles in walls, outside the
     map and non-finite included."""
     grid = fine_sibal1(sibal1)

@@ -3,7 +3,8 @@
 
 Every case draws a map, a maximum range, a beam set (count, span up to a full turn, even or jittered spacing), a particle
 count around the thresholds of the kernels' paths and a cloud (tracking, uniform over the free cells, a few far-apart
-clusters, a mixture with stragglers and non-finite rows), lets the engine choose its kernels (RAYS_AUTO), and compares the
+clusters, a mixture with stragglers and non-finite rows), lets the engine choose its kernels (RAYS_AUTO; a quarter of the
+cases with MCL_SWEEP_GLOBAL=1, ranges of up to 30 m = 600 px take the global-field form anyway), and compares the
 log-weights of sampled particles after sensor_update and after one full update with the oracle's, bit for bit.
 
 usage: fuzz_ray_stage.py [cases, default 40] [seed, default 1]
@@ -34,7 +35,9 @@ bad = 0
 for case in range(ncases):
     mname = rng.choice(list(MAPS))
     m = MAPS[mname]
-    max_range = float(rng.choice([12.0, 12.0, 8.0, 5.0, 14.0 if mname == "spielberg" else 12.0]))
+    # (14 - 30 m: 241 .. 600 px on these maps -- beyond the 256-cell LDS windows, k_rays_sweep's global-field form)
+    max_range = float(rng.choice([12.0, 12.0, 8.0, 5.0, 14.0, 20.0, 30.0]))
+    os.environ["MCL_SWEEP_GLOBAL"] = "1" if rng.random() < 0.25 else "0"          # read at mcl_create: the global-field form on any range
     B = int(rng.choice([61, 181, 271, 361, 541, 721, 1000, 1081, 1440]))
     span = float(rng.choice([1.5 * np.pi, 1.5 * np.pi, np.pi, 0.5 * np.pi, 1.9 * np.pi, 2.0 * np.pi * (B - 1) / B]))
     a0 = float(rng.choice([-0.5 * span, -0.5 * span, -0.75 * np.pi, 0.3]))
@@ -97,8 +100,9 @@ for case in range(ncases):
     finally:
         e.close()
     bad += (not ok1) + (not ok2)
-    print(f"case {case:3d} {mname:9s} range {max_range:4.1f} B {B:4d} span {span:5.2f} a0 {a0:5.2f} {spacing:6s} n {n:6d} {kind:8s} "
-          f"{kern:12s} off {c['off_window_particles']:6d} lvl2 {c['level2_rays']:7d} {'OK' if ok1 else 'MISMATCH(sensor)'} {'OK' if ok2 else 'MISMATCH(update)'} "
+    kern += "/g" if (os.environ["MCL_SWEEP_GLOBAL"] == "1" or om.max_range_px > 243) and kern == "k_rays_sweep" else ""
+    print(f"case {case:3d} {mname:9s} range {max_range:4.1f} ({om.max_range_px:3d} px) B {B:4d} span {span:5.2f} a0 {a0:5.2f} {spacing:6s} n {n:6d} {kind:8s} "
+          f"{kern:14s} off {c['off_window_particles']:6d} lvl2 {c['level2_rays']:7d} {'OK' if ok1 else 'MISMATCH(sensor)'} {'OK' if ok2 else 'MISMATCH(update)'} "
           f"{time.time() - t0:.1f}s", flush=True)
 print("mismatching comparisons:", bad)
 sys.exit(1 if bad else 0)

@@ -38,10 +38,14 @@ cp "$OUT/prof/t_kernel_stats.csv" "$PROF/${TAG}_kernel_stats.csv"
 python3 tools/roofline_inputs.py "$TAG" "$PROF/${TAG}_pmc_sq.csv" "$PROF/${TAG}_pmc_sq2.csv" "$PROF/${TAG}_pmc_fetch.csv" \
     "$PROF/${TAG}_pmc_write.csv" "$PROF/${TAG}_valu_rates.txt" 4194304 1081 "$PROF" > "$OUT/roofline_inputs.log"
 cp "$PROF/${TAG}_roofline_inputs.json" "profiles/${TAG}_roofline_inputs.json"
+# per-kernel achieved bandwidth of the streaming kernels (algorithmic bytes / steady-state duration) + their VALU issue time
+python3 tools/kernel_bandwidth.py "$PROF/${TAG}_kernel_trace_summary.json" 4194304 "$PROF/${TAG}_kernel_bandwidth.md" "$PROF/${TAG}_pmc_sq.csv" > /dev/null
 python bench.py > "$OUT/b_4m.json"
 python bench.py --no-cpu-baseline --particles-per-gpu 262144 > "$OUT/b_256k.json"
 python bench.py --no-cpu-baseline --map levine > "$OUT/b_levine.json"
 python bench.py --no-cpu-baseline --regime global > "$OUT/b_global.json"
+python bench.py --no-cpu-baseline --regime global --map levine --steps 5 > "$OUT/b_global_levine.json"
 python bench.py --no-cpu-baseline --resample systematic > "$OUT/b_sys.json"
-for n in 4m 256k levine global sys; do tail -n 1 "$OUT/b_$n.json" > "$PROF/${TAG}_bench_$n.json"; done
+python bench.py --no-cpu-baseline --map fine025 --steps 10 > "$OUT/b_fine025.json"
+for n in 4m 256k levine global global_levine sys fine025; do tail -n 1 "$OUT/b_$n.json" > "$PROF/${TAG}_bench_$n.json"; done
 echo "$PROF/${TAG}_* refreshed"

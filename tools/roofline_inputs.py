@@ -24,7 +24,8 @@ KERNEL = "k_rays_sweep"
 def counters(path):
     v = defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if KERNEL in r["Kernel_Name"] and "<true>" not in r["Kernel_Name"]:      # (<true> = the probe-counting build of bench.py's untimed update)
+        # (<true, ..> = the probe-counting build of bench.py's untimed update; <.., true> = the global-field form of long-range maps)
+        if KERNEL in r["Kernel_Name"] and "sweep<true" not in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]:
             v[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return v
 
