@@ -184,6 +184,18 @@ struct mcl_engine {
     uint32_t *d_cut_start = nullptr, *d_cut_end = nullptr;   // kSwMaxCuts each: where the buckets of a sparse set start / end in the radix-sorted order (zero between sorts)
     bool env_no_bucket_cuts = false;    // MCL_NO_BUCKET_CUTS: units on the plain grid of 1024 slots, sparse sets ordered by whole tiles (rounds 2-3 before the cuts)
     int *d_tilemap = nullptr, *d_tilemark = nullptr;   // kSortMaxTiles each: tile of the map -> compact id; marks of the occupied tiles (zero between sorts)
+    // The ordering layout (bounding box, occupied tiles) of an update's children is made on the second stream right after the
+    // resampling kernel and used by the NEXT update, whose resampling kernel then writes the sort keys itself: d_bbox / d_tilemap are
+    // the layout in use, *_nx the one being made; swapped at the end of an update.  layout_valid: d_bbox describes the previous
+    // update's children of this configuration (cleared by graph_reset: map, beams, particles set from outside).
+    int *d_bbox_nx = nullptr, *d_tilemap_nx = nullptr, *d_tilemark_nx = nullptr;
+    hipEvent_t ev_children = nullptr, ev_layout = nullptr;
+    bool layout_valid = false, layout_pending = false;
+    int64_t layout_n = 0;
+    bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
+    bool keys_done = false;             // ... and its resampling kernel wrote the (key, index) pairs
+    bool env_no_stale_layout = false;   // MCL_NO_STALE_LAYOUT: every update makes its own layout first (rounds 1-3)
+    mcl::PrepClear prep_passed{};       // what the resampling kernel was given to clear (prep_folded)
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
     size_t slice_mean_capacity = 0;
     bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
@@ -748,14 +760,15 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             clr.logw_acc = h->d_logw_acc; clr.far_flags = reinterpret_cast<uint32_t *>(h->d_far);
             clr.fix_count = h->d_fix_count; clr.fix_words = nseg * 8; clr.fix_over = h->d_fix_over; clr.exact_count = h->d_result + 14;
             if (sweep) clr.far_count = h->d_result + 15;
-            if (cell) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
+            const bool stale_layout = cell && h->layout_stale_used;      // d_bbox / d_tilemap hold the layout to order by: not remade
+            if (cell && !stale_layout) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
             // the window play k_sweep_plan works with (0: no windowed kernel; -1: no cuts at all, MCL_NO_BUCKET_CUTS)
             clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? sweep_play(h) : 0);
             if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
                 clr.logw_acc = nullptr; clr.far_flags = nullptr;
                 // ... and, from the second update of a configuration on, the few words that are not per particle as well
-                const mcl::PrepClear &pc0 = h->prep_cache;
-                const bool done = h->prep_folded && h->prep_cache_valid && clr.fix_count == pc0.fix_count && clr.fix_words == pc0.fix_words &&
+                const mcl::PrepClear &pc0 = h->prep_passed;
+                const bool done = h->prep_folded && clr.fix_count == pc0.fix_count && clr.fix_words == pc0.fix_words &&
                                   clr.fix_over == pc0.fix_over && clr.exact_count == pc0.exact_count && clr.far_count == pc0.far_count &&
                                   clr.bbox == pc0.bbox && clr.bbox_play == pc0.bbox_play && !clr.hist && !pc0.hist;
                 if (!done) hipLaunchKernelGGL(mcl::k_prep_small, dim3(1), dim3(256), 0, h->stream, clr);
@@ -774,10 +787,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             // occupied tiles of the map are numbered compactly when the map has at most kSortMaxTiles of them (bbox[5] says so)
             const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
             const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
-            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0,
-                               h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox, tiles_ok ? h->d_tilemark : (int *)nullptr, ntx_abs);
-            if (tiles_ok)
-                hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, h->d_tilemark, h->d_tilemap, ntx_abs * nty_abs);
+            const bool stale_layout = h->layout_stale_used;
+            if (!stale_layout) {
+                hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0,
+                                   h->stream, h->d_pc, n, bstride, h->Wp, h->Hp, h->d_bbox, tiles_ok ? h->d_tilemark : (int *)nullptr, ntx_abs);
+                if (tiles_ok)
+                    hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, h->d_tilemark, h->d_tilemap, ntx_abs * nty_abs);
+            }
             // Two ways to the same kind of order (which lanes share a wave; never results).  Counting sort with per-XCD
             // histograms: one returning L2 atomic per particle (~1 per clock and XCD) + a scatter.  From 3M particles a radix
             // sort of (key, index) pairs is quicker -- keys only, rocPRIM's device sort (a plain library sort), then a gather:
@@ -796,8 +812,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                     HIPCHK(h, hipMalloc(&h->d_sort_tmp, tb));
                     h->sort_tmp_bytes = tb;
                 }
-                hipLaunchKernelGGL(mcl::k_sort_keys, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_skey, h->d_srank,
-                                   h->d_tilemap, ntx_abs);
+                if (!(stale_layout && h->keys_done))       // (else the resampling kernel wrote the pairs)
+                    hipLaunchKernelGGL(mcl::k_sort_keys, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_skey, h->d_srank,
+                                       h->d_tilemap, ntx_abs);
                 tb = h->sort_tmp_bytes;
                 HIPCHK(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tb, h->d_skey, h->d_skey2, h->d_srank, h->d_sval2, (size_t)n, 0, mcl::kSortKeyLog2, h->stream));
                 hipLaunchKernelGGL(mcl::k_sort_gather, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_sval2, h->d_pcs, h->d_ths, h->d_perm,
@@ -926,6 +943,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     if (!windows && !h->capturing && !direct_table) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
     h->last_mode = mode;
     h->prep_folded = false;
+    h->layout_stale_used = false; h->keys_done = false;
     if (!h->capturing) h->pc_ready = false;
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
@@ -972,6 +990,7 @@ void graph_reset(mcl_engine *h)
         if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); h->graph_exec[k] = nullptr; }
     h->graph_warm = false;
     h->prep_cache_valid = false; h->prep_folded = false;
+    h->layout_valid = false; h->layout_stale_used = false; h->keys_done = false;
     h->pc_ready = false;                    // whatever changed (map, beams, particles, a buffer): the ray stage makes its own constants
 }
 
@@ -1089,6 +1108,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     if (const char *e = getenv("MCL_SW_SPLIT16")) h->env_sw_split16 = atoi(e) != 0;
     h->env_no_obs_overlap = getenv("MCL_NO_OBS_OVERLAP") != nullptr;
     h->env_no_prep_fold = getenv("MCL_NO_PREP_FOLD") != nullptr;
+    h->env_no_stale_layout = getenv("MCL_NO_STALE_LAYOUT") != nullptr;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
     auto bail = [&](const char *what) {
@@ -1148,6 +1168,12 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMemset(h->d_hist, 0, (size_t)mcl::kSortBuckets * 4));          // kept all-zero between sorts (k_hist_clear)
     CRT(hipMemset(h->d_tile_used, 0, (size_t)(mcl::kSortKeySpace / mcl::kHistTile) * 4));
     CRT(hipMalloc(&h->d_bbox, 8 * sizeof(int)));
+    CRT(hipMalloc(&h->d_bbox_nx, 8 * sizeof(int)));
+    CRT(hipMalloc(&h->d_tilemap_nx, (size_t)mcl::kSortMaxTiles * sizeof(int)));
+    CRT(hipMalloc(&h->d_tilemark_nx, (size_t)mcl::kSortMaxTiles * sizeof(int)));
+    CRT(hipMemset(h->d_tilemark_nx, 0, (size_t)mcl::kSortMaxTiles * sizeof(int)));
+    CRT(hipEventCreateWithFlags(&h->ev_children, hipEventDisableTiming));
+    CRT(hipEventCreateWithFlags(&h->ev_layout, hipEventDisableTiming));
     CRT(hipMalloc(&h->d_cut_start, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
     CRT(hipMalloc(&h->d_cut_end, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
     CRT(hipMemset(h->d_cut_start, 0, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
@@ -1215,6 +1241,9 @@ void mcl_destroy(mcl_engine_t *h)
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->ev_obs) (void)hipEventDestroy(h->ev_obs);
+    if (h->ev_children) (void)hipEventDestroy(h->ev_children);
+    if (h->ev_layout) (void)hipEventDestroy(h->ev_layout);
+    dfree(h->d_bbox_nx); dfree(h->d_tilemap_nx); dfree(h->d_tilemark_nx);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1623,6 +1652,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         return fail(h, MCL_ERR_UNSUPPORTED, "resample_neff_permille needs weight_mode LOG");
     if (!resample_and_move) HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));   // else: the resampling kernel
     h->pc_ready = false;
+    h->layout_stale_used = false; h->keys_done = false;      // (set below when this update orders by the previous update's layout)
     // A small update (k_rays_skip, the whole tail in one workgroup) is three launches and no copy: resampling + motion +
     // per-particle constants + table rows of the scan | rays against the static table | weights, sums, CDF and the result
     // block written straight to pinned host memory.  Every buffer exists once a regular update has run (graph_warm).
@@ -1699,8 +1729,24 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
                 a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
                 if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
                 h->pc_ready = true;
+                // The ordering of the ray stage works from the layout (bounding box, occupied tiles) of the PREVIOUS update's children
+                // when there is one: the set moves by a cell or so per update and the order only decides which rays share a wave.
+                // Radix ordering: this kernel then writes the (key, index) pairs too and the sort starts right after it.
+                const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
+                const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
+                if (rmode >= 4 && h->layout_valid && h->layout_n == n && !h->env_no_stale_layout) {
+                    h->layout_stale_used = true;
+                    const bool radix = h->env_sort_radix >= 0 ? h->env_sort_radix != 0 : n >= 3000000;
+                    if (radix && h->d_skey2) {
+                        a.key_out = h->d_skey; a.val_out = h->d_srank; a.key_bbox = h->d_bbox; a.key_tilemap = tiles_ok ? h->d_tilemap : nullptr;
+                        a.key_ntx = ntx_abs; a.key_Wp = h->Wp; a.key_Hp = h->Hp;
+                        h->keys_done = true;
+                    }
+                }
                 if (rmode >= 4 && h->prep_cache_valid && h->prep_cache_n == n && !h->env_no_prep_fold) {
                     a.prep = h->prep_cache; a.prep_on = 1;      // launch_rays checks that this is what it would have cleared
+                    if (h->layout_stale_used) a.prep.bbox = nullptr;     // the layout in d_bbox is in use: not reset
+                    h->prep_passed = a.prep;
                     h->prep_folded = true;
                 }
             }
@@ -1709,6 +1755,23 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         if (!a.tile_excl && a.do_resample && n <= mcl::kTinyTailMax) { a.cdf_lds_entries = (int)n; cdf_lds = (size_t)n * sizeof(uint64_t); }
         hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, a);
         HIPCHK(h, hipGetLastError());
+        if (a.pc_out && choose_ray_mode(h, n, false) >= 4 && !h->env_no_stale_layout) {
+            // the layout of THESE children, for the next update: on the second stream, beside the sort and the ray stage
+            const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
+            const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
+            const int bstride = n >= (1 << 20) ? 16 : 1;
+            const int play = h->env_no_bucket_cuts ? -1 : (choose_ray_mode(h, n, false) == 5 ? sweep_play(h) : 0);
+            HIPCHK(h, hipEventRecord(h->ev_children, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_children, 0));
+            hipLaunchKernelGGL(mcl::k_bbox_init, dim3(1), dim3(64), 0, h->stream2, h->d_bbox_nx, play);
+            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0, h->stream2, h->d_pc, n,
+                               bstride, h->Wp, h->Hp, h->d_bbox_nx, tiles_ok ? h->d_tilemark_nx : (int *)nullptr, ntx_abs);
+            if (tiles_ok)
+                hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream2, h->d_bbox_nx, h->d_tilemark_nx, h->d_tilemap_nx, ntx_abs * nty_abs);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipEventRecord(h->ev_layout, h->stream2));
+            h->layout_pending = true;
+        }
         h->cur = nx;                       // cpp:689 as a pointer swap
         h->resampled_last = !keep;
         h->pack_valid[nx] = a.cpack != nullptr;
@@ -1844,6 +1907,11 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         if (rc) return rc;
     }
     if (h->carry_pending) { h->carry_idx ^= 1; h->carry_valid = true; h->carry_pending = false; }   // this update's logw - max
+    if (h->layout_pending) {               // the layout of this update's children (made beside the ray stage) is the next update's
+        HIPCHK(h, hipEventSynchronize(h->ev_layout));
+        std::swap(h->d_bbox, h->d_bbox_nx); std::swap(h->d_tilemap, h->d_tilemap_nx);
+        h->layout_valid = true; h->layout_n = n; h->layout_pending = false;
+    }
     h->graph_warm = true;                  // every buffer this configuration needs exists now
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;

@@ -214,6 +214,15 @@ struct PrepClear {
     uint32_t hist_n;
 };
 
+#ifndef MCL_SORT_SUB
+#define MCL_SORT_SUB 1
+#endif
+constexpr int kSortSub = MCL_SORT_SUB;               // sort cells per grid cell and axis (the ordering kernels below)
+// (defined with the ordering kernels below; the resampling kernel makes the sort keys of its children itself when it is given a layout)
+__device__ __forceinline__ int cell_of(double g, int hi);
+__device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const int *__restrict__ tilemap, int ntx_abs, int cx, int cy, double th,
+                                         int64_t n, double fx = 0.0, double fy = 0.0);
+
 __device__ __forceinline__ void prep_small_clear(const PrepClear &clr, int i, int nthreads)
 {
     if (clr.fix_count) for (int k = i; k < clr.fix_words; k += nthreads) clr.fix_count[k] = 0ull;
@@ -272,6 +281,12 @@ struct ResampleArgs {
     const double4 *crec;              // ... and its record
     const unsigned char *cchunks;     // gathered lists (cidx / crec null): entry p lives in chunk p / ccap
     int64_t cchunk_bytes, ccap;
+    // the ordering of the ray stage: (key, index) of every child from the layout (bounding box, occupied tiles) of the PREVIOUS update's
+    // children -- the set moves by a cell or so per update, and a key only decides which rays share a wave -- so that the radix
+    // sort can start right after this kernel (k_cell_bbox / k_tile_compact / k_sort_keys off the critical path)
+    uint32_t *key_out, *val_out;      // null: keys are made by k_sort_keys / k_sort_hist
+    const int *key_bbox, *key_tilemap;
+    int key_ntx, key_Wp, key_Hp;
     PrepClear prep;                   // prep_on: the first workgroup also clears the few words of the ray stage that are not per
     int prep_on;                      //   particle (what k_prep_small would do in a launch of its own)
     const float *obs_src;             // this update's ranges (pinned host memory, read once by the first workgroup), or null
@@ -480,7 +495,17 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
     }
     a.cx[m] = x; a.cy[m] = y; a.cth[m] = th;
     if (a.cpack) a.cpack[m] = make_double4(x, y, th, 0.0);
-    if (a.pc_out) a.pc_out[m] = particle_constants(x, y, th, a.ox, a.oy, a.res);
+    if (a.pc_out) {
+        const double4 c = particle_constants(x, y, th, a.ox, a.oy, a.res);
+        a.pc_out[m] = c;
+        if (a.key_out) {
+            // the same key k_sort_keys would make (same function, same arguments), from the layout handed in
+            a.key_out[m] = sort_key(a.key_bbox, a.key_tilemap, a.key_ntx, cell_of(c.z * kSortSub, a.key_Wp * kSortSub - 1),
+                                    cell_of(c.w * kSortSub, a.key_Hp * kSortSub - 1), th, a.n_children, c.z * kSortSub - floor(c.z * kSortSub),
+                                    c.w * kSortSub - floor(c.w * kSortSub));
+            a.val_out[m] = (uint32_t)m;
+        }
+    }
     if (a.clr_logw_acc) a.clr_logw_acc[m] = 0.0;
     if (a.clr_far_flags) a.clr_far_flags[m] = 0u;
 }
@@ -1523,13 +1548,9 @@ __global__ __launch_bounds__(256) void k_wedge_field(const int32_t *__restrict__
 // is an exact sum.
 constexpr int kSortKeyLog2 = 22;
 constexpr uint32_t kSortKeySpace = 1u << kSortKeyLog2;
-#ifndef MCL_SORT_SUB
-#define MCL_SORT_SUB 1
-#endif
 #ifndef MCL_SORT_MAX_SUB
 #define MCL_SORT_MAX_SUB 1
 #endif
-constexpr int kSortSub = MCL_SORT_SUB;               // sort cells per grid cell and axis
 constexpr int kSortXcds = 8;                        // copies of the histogram (XCC_ID & 7)
 constexpr uint32_t kSortBuckets = kSortKeySpace * kSortXcds;
 constexpr int kHistTile = 4096;                     // entries per workgroup of the bucket scan
@@ -1544,6 +1565,13 @@ __device__ __forceinline__ int cell_of(double g, int hi)
 // bbox[0..3] = min cx, min cy, max cx, max cy over every `stride`-th particle (initialised to +big / -big by the
 // host).  A sample is enough: sort_key clamps cells into the box, so a particle outside it merely lands in an
 // edge bucket (the order is a performance matter only).
+// bbox as PrepClear leaves it: empty box, no tiles numbered, [6] = the window play sort_layout works with
+__global__ void k_bbox_init(int *__restrict__ bbox, int play)
+{
+    const int i = threadIdx.x;
+    if (i < 7) bbox[i] = i < 2 ? 0x7fffffff : (i < 4 ? (int)0x80000000 : (i == 6 ? play : 0));
+}
+
 __global__ __launch_bounds__(256) void k_cell_bbox(const double4 *__restrict__ pc, int64_t n, int stride, int Wp, int Hp, int *__restrict__ bbox,
                                                   int *__restrict__ tilemark = nullptr, int ntx_abs = 0)
 {
@@ -1684,7 +1712,7 @@ __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, 
 }
 
 __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const int *__restrict__ tilemap, int ntx_abs, int cx, int cy, double th,
-                                         int64_t n, double fx = 0.0, double fy = 0.0)
+                                         int64_t n, double fx, double fy)
 {
     cx = cx < bbox[0] ? bbox[0] : (cx > bbox[2] ? bbox[2] : cx);
     cy = cy < bbox[1] ? bbox[1] : (cy > bbox[3] ? bbox[3] : cy);
