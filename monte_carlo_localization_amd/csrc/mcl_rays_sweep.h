@@ -893,7 +893,16 @@ __global__ __launch_bounds__(256) void k_combine_logw(int64_t n, const uint32_t 
         if (threadIdx.x == 0) *over = over_sh;
     }
     double m = -INFINITY;
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+    // four slots per trip: their (coalesced) loads are all requested before the first scattered store goes out
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; s + 3 * stride < n; s += 4 * stride) {
+        const double v0 = acc[s], v1 = acc[s + stride], v2 = acc[s + 2 * stride], v3 = acc[s + 3 * stride];
+        const uint32_t i0 = perm[s], i1 = perm[s + stride], i2 = perm[s + 2 * stride], i3 = perm[s + 3 * stride];
+        logw[i0] = v0; logw[i1] = v1; logw[i2] = v2; logw[i3] = v3;
+        m = fmax(fmax(m, v0), fmax(fmax(v1, v2), v3));
+    }
+    for (; s < n; s += stride) {
         const double v = acc[s];
         logw[perm[s]] = v;
         m = fmax(m, v);
