@@ -2485,6 +2485,7 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     } else {
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
     }
+    h->layout_stale_used = false; h->keys_done = false;      // (the staged flow makes its ordering layout per update)
     rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, force_skip);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
