@@ -487,6 +487,9 @@ def main():
         }
         if use_dist:
             line["exchange_bytes_per_update_per_gpu"] = sf.exchange_bytes
+            # stream synchronisations of one steady-state update on this rank (dist.py: 1 = device-ordered, the small exchanges
+            # stay in device memory; MCL_DIST_SYNC=1: a wait per exchanged value)
+            line["host_waits_per_update"] = sf.host_waits
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
         if parity and (parity["logw_mismatches"] or parity.get("idx_mismatches", 0)):

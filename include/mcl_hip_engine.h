@@ -314,6 +314,32 @@ int mcl_stage_weights(mcl_engine_t *h, double global_max_logw);
 /* Stage 3: install the GLOBAL sums (sum w, wx, wy, wsin, wcos) so that get_weights /
  * expected_pose report globally normalised values. */
 int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5]);
+/* ---- the same stages ORDERED ON THE DEVICE: one host wait per update ----------------------------------------------------
+ * The calls above return when their stage has finished (the host reads a value between them).  The *_async forms only enqueue
+ * on the engine's stream; the values the stages exchange stay in device memory the caller owns (its collective library's
+ * buffers), and the caller's stream and the engine's are ordered by events:
+ *   mcl_external_wait_stream(h, s): work enqueued on s after the call waits for everything enqueued on the engine so far;
+ *   mcl_stream_wait_external(h, s): the engine's later work waits for everything enqueued on s so far (s: a hipStream_t).
+ * One update of a sharded set, lists known from the previous update's sums:
+ *   mcl_export_compact_async -> [s waits] all-gather of the chunks on s -> [engine waits] mcl_stage_resample_compact_async ->
+ *   mcl_stage_rays_async (local max log-weight -> *d_local_max) -> [s waits] all-reduce MAX on s -> [engine waits]
+ *   mcl_stage_weights_async (reads *d_global_max; writes this shard's part of the SUM vector, 5 + 3 * n_shards + 1 doubles:
+ *   [sum w, sum w x, sum w y, sum w sin, sum w cos | per shard: list length + 1 (0: no list), low / high 32 bits of its
+ *   fixed-point weight total | 1.0 if this shard's ray stage overflowed its fix-up lists], the other shards' slots zeroed)
+ *   -> [s waits] all-reduce SUM on s, copy to the host, THE host wait -> mcl_stage_complete(global sums, &redo): waits for the
+ *   engine's stream (already drained), takes over the read-backs the synchronous calls do one by one.  *redo = 1 (the last
+ *   element of the summed vector is non-zero on every rank then): this shard's log-weights are incomplete -- run
+ *   mcl_stage_rays, the MAX exchange, mcl_stage_weights, the SUM exchange and mcl_stage_finish once more (all ranks).
+ * Results are those of the synchronous calls bit for bit (same kernels, same order). */
+int mcl_stream_wait_external(mcl_engine_t *h, void *stream);
+int mcl_external_wait_stream(mcl_engine_t *h, void *stream);
+int mcl_export_compact_async(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries);
+int mcl_stage_resample_compact_async(mcl_engine_t *h, const void *d_chunks, int32_t n_shards, int64_t chunk_entries, const int64_t *counts,
+                                     const uint64_t *totals, int64_t n_per_shard, int32_t self_shard, int64_t child_first,
+                                     int64_t n_children_total, const double action[3]);
+int mcl_stage_rays_async(mcl_engine_t *h, const float *obs, int32_t n_beams, double *d_local_max);
+int mcl_stage_weights_async(mcl_engine_t *h, const double *d_global_max, double *d_vec, int32_t n_shards, int32_t self_shard);
+int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *redo);
 /* Inclusive scan of q (uint64) on the engine's stream: cdf[i] = offset + q[0] + ... + q[i]. */
 int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset);
 

@@ -190,6 +190,8 @@ struct mcl_engine {
     // update's children of this configuration (cleared by graph_reset: map, beams, particles set from outside).
     int *d_bbox_nx = nullptr, *d_tilemap_nx = nullptr, *d_tilemark_nx = nullptr;
     hipEvent_t ev_children = nullptr, ev_layout = nullptr;
+    hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;   // ordering against a caller's stream (mcl_stream_wait_external / mcl_external_wait_stream)
+    bool stage_async_rays = false, stage_async_weights = false;
     bool layout_valid = false, layout_pending = false;
     int64_t layout_n = 0;
     bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
@@ -1174,6 +1176,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipMemset(h->d_tilemark_nx, 0, (size_t)mcl::kSortMaxTiles * sizeof(int)));
     CRT(hipEventCreateWithFlags(&h->ev_children, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->ev_layout, hipEventDisableTiming));
+    CRT(hipEventCreateWithFlags(&h->ev_ext_in, hipEventDisableTiming));
+    CRT(hipEventCreateWithFlags(&h->ev_ext_out, hipEventDisableTiming));
     CRT(hipMalloc(&h->d_cut_start, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
     CRT(hipMalloc(&h->d_cut_end, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
     CRT(hipMemset(h->d_cut_start, 0, (size_t)mcl::kSwMaxCuts * sizeof(uint32_t)));
@@ -1243,6 +1247,8 @@ void mcl_destroy(mcl_engine_t *h)
     if (h->ev_obs) (void)hipEventDestroy(h->ev_obs);
     if (h->ev_children) (void)hipEventDestroy(h->ev_children);
     if (h->ev_layout) (void)hipEventDestroy(h->ev_layout);
+    if (h->ev_ext_in) (void)hipEventDestroy(h->ev_ext_in);
+    if (h->ev_ext_out) (void)hipEventDestroy(h->ev_ext_out);
     dfree(h->d_bbox_nx); dfree(h->d_tilemap_nx); dfree(h->d_tilemark_nx);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1621,6 +1627,71 @@ int mcl_particle_mean(mcl_engine_t *h, double out[3])
     return MCL_OK;
 }
 
+
+// What the resampling kernel does for the ray stage that follows it in the same update (mcl_update and the staged flow alike):
+// the per-particle constants come out of it (k_rays_skip: one launch less per small update; k_rays_cell / k_rays_sweep: also the
+// per-particle scratch their stage wants zeroed, a pass over the children less), and from the second update of a configuration on
+// the (key, index) pairs of the ordering and the few words launch_rays would clear.
+static void resample_ray_extras(mcl_engine *h, int64_t n, mcl::ResampleArgs &a)
+{
+    const int rmode = choose_ray_mode(h, n, false);
+    if (!(rmode == 2 || rmode >= 4)) return;
+    a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
+    if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
+    h->pc_ready = true;
+    // The ordering of the ray stage works from the layout (bounding box, occupied tiles) of the PREVIOUS update's children
+    // when there is one: the set moves by a cell or so per update and the order only decides which rays share a wave.
+    // Radix ordering: this kernel then writes the (key, index) pairs too and the sort starts right after it.
+    const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
+    const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
+    if (rmode >= 4 && h->layout_valid && h->layout_n == n && !h->env_no_stale_layout) {
+        h->layout_stale_used = true;
+        const bool radix = h->env_sort_radix >= 0 ? h->env_sort_radix != 0 : n >= 3000000;
+        if (radix && h->d_skey2) {
+            a.key_out = h->d_skey; a.val_out = h->d_srank; a.key_bbox = h->d_bbox; a.key_tilemap = tiles_ok ? h->d_tilemap : nullptr;
+            a.key_ntx = ntx_abs; a.key_Wp = h->Wp; a.key_Hp = h->Hp;
+            h->keys_done = true;
+        }
+    }
+    if (rmode >= 4 && h->prep_cache_valid && h->prep_cache_n == n && !h->env_no_prep_fold) {
+        a.prep = h->prep_cache; a.prep_on = 1;      // launch_rays checks that this is what it would have cleared
+        if (h->layout_stale_used) a.prep.bbox = nullptr;     // the layout in d_bbox is in use: not reset
+        h->prep_passed = a.prep;
+        h->prep_folded = true;
+    }
+}
+
+// After the resampling kernel: the layout of THESE children, for the next update, on the second stream beside the sort and the ray stage.
+static int next_layout_launch(mcl_engine *h, int64_t n)
+{
+    if (choose_ray_mode(h, n, false) < 4 || h->env_no_stale_layout) return MCL_OK;
+    const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
+    const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
+    const int bstride = n >= (1 << 20) ? 16 : 1;
+    const int play = h->env_no_bucket_cuts ? -1 : (choose_ray_mode(h, n, false) == 5 ? sweep_play(h) : 0);
+    HIPCHK(h, hipEventRecord(h->ev_children, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_children, 0));
+    hipLaunchKernelGGL(mcl::k_bbox_init, dim3(1), dim3(64), 0, h->stream2, h->d_bbox_nx, play);
+    hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0, h->stream2, h->d_pc, n,
+                       bstride, h->Wp, h->Hp, h->d_bbox_nx, tiles_ok ? h->d_tilemark_nx : (int *)nullptr, ntx_abs);
+    if (tiles_ok)
+        hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream2, h->d_bbox_nx, h->d_tilemark_nx, h->d_tilemap_nx, ntx_abs * nty_abs);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_layout, h->stream2));
+    h->layout_pending = true;
+    return MCL_OK;
+}
+
+// End of an update: the layout made beside its ray stage becomes the one the next update orders by.
+static int layout_adopt(mcl_engine *h, int64_t n)
+{
+    if (!h->layout_pending) return MCL_OK;
+    HIPCHK(h, hipEventSynchronize(h->ev_layout));
+    std::swap(h->d_bbox, h->d_bbox_nx); std::swap(h->d_tilemap, h->d_tilemap_nx);
+    h->layout_valid = true; h->layout_n = n; h->layout_pending = false;
+    return MCL_OK;
+}
+
 static int do_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, const double *normals,
                      const double *uniforms, bool resample_and_move, int obs_stride = 1)
 {
@@ -1721,57 +1792,12 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
             stage_observation(h, obs, obs_stride);
             a.obs_src = h->h_obs; a.obs_idx_out = h->d_obs_idx; a.obs_B = h->B; a.obs_P = h->P; a.res = h->res;
         }
-        {
-            // the ray stage's per-particle constants come out of this kernel (k_rays_skip: one launch less per small update;
-            // k_rays_cell / k_rays_sweep: also the per-particle scratch their stage wants zeroed, a pass over the children less)
-            const int rmode = choose_ray_mode(h, n, false);
-            if (rmode == 2 || rmode >= 4) {
-                a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
-                if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
-                h->pc_ready = true;
-                // The ordering of the ray stage works from the layout (bounding box, occupied tiles) of the PREVIOUS update's children
-                // when there is one: the set moves by a cell or so per update and the order only decides which rays share a wave.
-                // Radix ordering: this kernel then writes the (key, index) pairs too and the sort starts right after it.
-                const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
-                const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
-                if (rmode >= 4 && h->layout_valid && h->layout_n == n && !h->env_no_stale_layout) {
-                    h->layout_stale_used = true;
-                    const bool radix = h->env_sort_radix >= 0 ? h->env_sort_radix != 0 : n >= 3000000;
-                    if (radix && h->d_skey2) {
-                        a.key_out = h->d_skey; a.val_out = h->d_srank; a.key_bbox = h->d_bbox; a.key_tilemap = tiles_ok ? h->d_tilemap : nullptr;
-                        a.key_ntx = ntx_abs; a.key_Wp = h->Wp; a.key_Hp = h->Hp;
-                        h->keys_done = true;
-                    }
-                }
-                if (rmode >= 4 && h->prep_cache_valid && h->prep_cache_n == n && !h->env_no_prep_fold) {
-                    a.prep = h->prep_cache; a.prep_on = 1;      // launch_rays checks that this is what it would have cleared
-                    if (h->layout_stale_used) a.prep.bbox = nullptr;     // the layout in d_bbox is in use: not reset
-                    h->prep_passed = a.prep;
-                    h->prep_folded = true;
-                }
-            }
-        }
+        resample_ray_extras(h, n, a);
         size_t cdf_lds = 0;
         if (!a.tile_excl && a.do_resample && n <= mcl::kTinyTailMax) { a.cdf_lds_entries = (int)n; cdf_lds = (size_t)n * sizeof(uint64_t); }
         hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, a);
         HIPCHK(h, hipGetLastError());
-        if (a.pc_out && choose_ray_mode(h, n, false) >= 4 && !h->env_no_stale_layout) {
-            // the layout of THESE children, for the next update: on the second stream, beside the sort and the ray stage
-            const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
-            const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
-            const int bstride = n >= (1 << 20) ? 16 : 1;
-            const int play = h->env_no_bucket_cuts ? -1 : (choose_ray_mode(h, n, false) == 5 ? sweep_play(h) : 0);
-            HIPCHK(h, hipEventRecord(h->ev_children, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_children, 0));
-            hipLaunchKernelGGL(mcl::k_bbox_init, dim3(1), dim3(64), 0, h->stream2, h->d_bbox_nx, play);
-            hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0, h->stream2, h->d_pc, n,
-                               bstride, h->Wp, h->Hp, h->d_bbox_nx, tiles_ok ? h->d_tilemark_nx : (int *)nullptr, ntx_abs);
-            if (tiles_ok)
-                hipLaunchKernelGGL(mcl::k_tile_compact, dim3(1), dim3(1024), 0, h->stream2, h->d_bbox_nx, h->d_tilemark_nx, h->d_tilemap_nx, ntx_abs * nty_abs);
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipEventRecord(h->ev_layout, h->stream2));
-            h->layout_pending = true;
-        }
+        if (a.pc_out) { const int rc_l = next_layout_launch(h, n); if (rc_l) return rc_l; }
         h->cur = nx;                       // cpp:689 as a pointer swap
         h->resampled_last = !keep;
         h->pack_valid[nx] = a.cpack != nullptr;
@@ -1907,11 +1933,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         if (rc) return rc;
     }
     if (h->carry_pending) { h->carry_idx ^= 1; h->carry_valid = true; h->carry_pending = false; }   // this update's logw - max
-    if (h->layout_pending) {               // the layout of this update's children (made beside the ray stage) is the next update's
-        HIPCHK(h, hipEventSynchronize(h->ev_layout));
-        std::swap(h->d_bbox, h->d_bbox_nx); std::swap(h->d_tilemap, h->d_tilemap_nx);
-        h->layout_valid = true; h->layout_n = n; h->layout_pending = false;
-    }
+    { const int rc_l = layout_adopt(h, n); if (rc_l) return rc_l; }
     h->graph_warm = true;                  // every buffer this configuration needs exists now
     h->have_logw = true;
     h->have_steps = h->cfg.keep_ray_steps != 0;
@@ -2321,18 +2343,13 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     if (action) motion_scalars(action, a.dt, a.v, a.w);
     a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
     a.do_resample = 1; a.do_motion = 1;
-    if (!index_only) {
-        // as in mcl_update: the ray stage's per-particle constants (and its zeroed per-particle scratch) come out of this
-        // kernel, a pass over the children less in mcl_stage_rays
-        const int rmode = choose_ray_mode(h, n, false);
-        if (rmode == 2 || rmode >= 4) {
-            a.pc_out = h->d_pc; a.ox = h->ox; a.oy = h->oy; a.res = h->res;
-            if (rmode >= 4) { a.clr_logw_acc = h->d_logw_acc; a.clr_far_flags = reinterpret_cast<uint32_t *>(h->d_far); }
-        }
-    }
+    h->layout_stale_used = false; h->keys_done = false; h->pc_ready = false;
+    // as in mcl_update: the ray stage's per-particle constants, its zeroed scratch and (by the previous update's layout) the sort
+    // keys come out of this kernel; the layout of these children is made on the second stream for the next update
+    if (!index_only) resample_ray_extras(h, n, a);
     hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
-    h->pc_ready = a.pc_out != nullptr;
+    if (a.pc_out) { const int rc_l = next_layout_launch(h, n); if (rc_l) return rc_l; }
     if (index_only) {
         HIPCHK(h, hipMemcpyAsync(src.idx_only_out, h->d_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
         h->have_idx = true;
@@ -2469,7 +2486,7 @@ int mcl_stage_resample_compact(mcl_engine_t *h, const void *d_chunks, int32_t n_
     return MCL_OK;
 }
 
-static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams, bool force_skip)
+static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams, bool force_skip, double *d_max_out = nullptr)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
@@ -2485,17 +2502,29 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     } else {
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
     }
-    h->layout_stale_used = false; h->keys_done = false;      // (the staged flow makes its ordering layout per update)
+    if (!h->pc_ready) { h->layout_stale_used = false; h->keys_done = false; }     // no staged resampling before this call: nothing prepared
     rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, force_skip);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     if (!h->max_partials_ready)
         hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_maxpart);
-    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_maxpart, mcl::kRedBlocks, h->d_scalars);
+    hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_maxpart, mcl::kRedBlocks, h->d_scalars, d_max_out);
     h->max_partials_ready = false;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
     return MCL_OK;
+}
+
+// the host-side notes of a finished ray stage (its stream has been waited for)
+static void stage_rays_note(mcl_engine_t *h)
+{
+    h->have_logw = true;
+    h->have_steps = h->cfg.keep_ray_steps != 0;
+    h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
+    h->timings[1] = 0.0;
+    h->timings[2] = 0.0;
+    h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
+    h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
 }
 
 static int stage_rays_finish(mcl_engine_t *h, const float *obs, int32_t n_beams)
@@ -2511,13 +2540,7 @@ static int stage_rays_finish(mcl_engine_t *h, const float *obs, int32_t n_beams)
         int rc = stage_rays_launch(h, obs, n_beams, true);
         if (rc) return rc;
     }
-    h->have_logw = true;
-    h->have_steps = h->cfg.keep_ray_steps != 0;
-    h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
-    h->timings[1] = 0.0;
-    h->timings[2] = 0.0;
-    h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
-    h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
+    stage_rays_note(h);
     return MCL_OK;
 }
 
@@ -2546,16 +2569,22 @@ int mcl_set_reserved_cus(mcl_engine_t *h, int32_t n_cus)
     return MCL_OK;
 }
 
-static int stage_weights_launch(mcl_engine_t *h, double global_max_logw)
+// d_global_max: the global maximum in device memory (the device-ordered flow: the log-weights need not have been seen by the
+// host yet), else the host's value is staged
+static int stage_weights_launch(mcl_engine_t *h, double global_max_logw, const double *d_global_max = nullptr)
 {
     if (!h) return MCL_ERR_INVALID_ARG;
-    if (!h->have_logw) return MCL_ERR_NOT_READY;
+    if (!h->have_logw && !d_global_max) return MCL_ERR_NOT_READY;
     if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
         return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->h_result[kResultStage] = 0;
-    std::memcpy(&h->h_result[kResultStage], &global_max_logw, sizeof(double));   // pinned: stays valid until the copy has run
-    HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[kResultStage], sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (d_global_max) {
+        hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, h->stream, d_global_max, h->d_scalars);
+    } else {
+        h->h_result[kResultStage] = 0;
+        std::memcpy(&h->h_result[kResultStage], &global_max_logw, sizeof(double));   // pinned: stays valid until the copy has run
+        HIPCHK(h, hipMemcpyAsync(h->d_scalars, &h->h_result[kResultStage], sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     int rc = weight_stats(h, true, h->d_scalars, true);        // (the scan below finishes the sums)
     if (rc) return rc;
     h->carry_pending = false;
@@ -2573,7 +2602,7 @@ static int stage_weights_finish(mcl_engine_t *h)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     unpack_result(h);
     h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
-    return MCL_OK;
+    return layout_adopt(h, h->N);
 }
 
 int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
@@ -2586,6 +2615,83 @@ int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
 int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5])
 {
     if (!h || !global_sums) return MCL_ERR_INVALID_ARG;
+    for (int i = 0; i < 5; ++i) h->global_sums[i] = global_sums[i];
+    return MCL_OK;
+}
+
+// ---- the staged flow ordered on the device: nothing below waits for the stream except mcl_stage_complete ----------------
+int mcl_stream_wait_external(mcl_engine_t *h, void *stream)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipEventRecord(h->ev_ext_in, static_cast<hipStream_t>(stream)));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ext_in, 0));
+    return MCL_OK;
+}
+
+int mcl_external_wait_stream(mcl_engine_t *h, void *stream)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipEventRecord(h->ev_ext_out, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_ext_out, 0));
+    return MCL_OK;
+}
+
+int mcl_export_compact_async(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return export_compact_launch(h, d_chunk, chunk_entries, h->cfg.device, h->stream);
+}
+
+int mcl_stage_resample_compact_async(mcl_engine_t *h, const void *d_chunks, int32_t n_shards, int64_t chunk_entries, const int64_t *counts,
+                                     const uint64_t *totals, int64_t n_per_shard, int32_t self_shard, int64_t child_first,
+                                     int64_t n_children_total, const double action[3])
+{
+    return stage_resample_compact_launch(h, d_chunks, n_shards, chunk_entries, counts, totals, n_per_shard, self_shard, child_first,
+                                         n_children_total, action, nullptr);
+}
+
+int mcl_stage_rays_async(mcl_engine_t *h, const float *obs, int32_t n_beams, double *d_local_max)
+{
+    if (!h || !d_local_max) return MCL_ERR_INVALID_ARG;
+    const int rc = stage_rays_launch(h, obs, n_beams, false, d_local_max);
+    if (rc) return rc;
+    h->stage_async_rays = true;
+    return MCL_OK;
+}
+
+int mcl_stage_weights_async(mcl_engine_t *h, const double *d_global_max, double *d_vec, int32_t n_shards, int32_t self_shard)
+{
+    if (!h || !d_global_max || !d_vec || n_shards <= 0 || n_shards > mcl::kMaxShards || self_shard < 0 || self_shard >= n_shards)
+        return MCL_ERR_INVALID_ARG;
+    if (!h->stage_async_rays) return fail(h, MCL_ERR_NOT_READY, "mcl_stage_rays_async first");
+    const int rc = stage_weights_launch(h, 0.0, d_global_max);       // ends with the copy of the result block to pinned memory
+    if (rc) return rc;
+    hipLaunchKernelGGL(mcl::k_stage_pack, dim3(1), dim3(64), 0, h->stream, h->d_result, d_vec, n_shards, self_shard, h->compact_pending ? 1 : 0,
+                       (unsigned long long)h->compact_cap);
+    HIPCHK(h, hipGetLastError());
+    h->stage_async_weights = true;
+    return MCL_OK;
+}
+
+int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *redo)
+{
+    if (!h || !global_sums || !redo) return MCL_ERR_INVALID_ARG;
+    if (!h->stage_async_rays || !h->stage_async_weights) return fail(h, MCL_ERR_NOT_READY, "mcl_stage_rays_async and mcl_stage_weights_async first");
+    h->stage_async_rays = h->stage_async_weights = false;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unpack_result(h);
+    stage_rays_note(h);
+    h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
+    const int rc = layout_adopt(h, h->N);
+    if (rc) return rc;
+    // more undecided rays than the fix-up lists hold (debug_force_exact at large sizes, a pathological map): the log-weights of
+    // this update are incomplete.  The caller runs the ray stage again through mcl_stage_rays (which falls back to the
+    // self-contained kernel) and the two exchanges after it; the children are untouched
+    *redo = (h->last_quad && h->h_fix_count != 0) ? 1 : 0;
     for (int i = 0; i < 5; ++i) h->global_sums[i] = global_sums[i];
     return MCL_OK;
 }
@@ -2623,10 +2729,11 @@ int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int6
 struct mcl_group {
     std::vector<mcl_engine *> eng;
     std::vector<uint64_t *> d_qall, d_cdfall;      // per device: all shards' weights and their global CDF
-    std::vector<unsigned long long *> d_remote;    // per device: children whose parent was fetched from a peer (last update)
+    std::vector<unsigned long long *> d_remote;    // per device, 4 words: children whose parent was fetched from a peer (last update) |
+                                                   // this shard's max log-weight | the maximum over the shards (doubles)
     std::vector<unsigned char *> d_chunks;         // per device: every shard's compact parent list (grown on demand)
     std::vector<size_t> chunks_capacity;
-    std::vector<hipEvent_t> ev_ready, ev_children; // per device, see mcl_group_update
+    std::vector<hipEvent_t> ev_ready, ev_children, ev_rays; // per device, see mcl_group_update
     bool compact_last = false;
     int64_t n_per = 0, n_total = 0;
     uint64_t q_total = 0;
@@ -2672,6 +2779,7 @@ void mcl_group_destroy(mcl_group_t *g)
         if (d < g->d_chunks.size() && g->d_chunks[d]) (void)hipFree(g->d_chunks[d]);
         if (d < g->ev_ready.size() && g->ev_ready[d]) (void)hipEventDestroy(g->ev_ready[d]);
         if (d < g->ev_children.size() && g->ev_children[d]) (void)hipEventDestroy(g->ev_children[d]);
+        if (d < g->ev_rays.size() && g->ev_rays[d]) (void)hipEventDestroy(g->ev_rays[d]);
         mcl_destroy(g->eng[d]);
     }
     delete g;
@@ -2698,12 +2806,13 @@ int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_
     }
     g->d_qall.assign(n_devices, nullptr); g->d_cdfall.assign(n_devices, nullptr); g->d_remote.assign(n_devices, nullptr);
     g->d_chunks.assign(n_devices, nullptr); g->chunks_capacity.assign(n_devices, 0);
-    g->ev_ready.assign(n_devices, nullptr); g->ev_children.assign(n_devices, nullptr);
+    g->ev_ready.assign(n_devices, nullptr); g->ev_children.assign(n_devices, nullptr); g->ev_rays.assign(n_devices, nullptr);
     const size_t cap_total = (size_t)cfg->max_particles * n_devices;
     for (int d = 0; d < n_devices; ++d) {
         if (hipSetDevice(devices[d]) != hipSuccess || hipMalloc(&g->d_qall[d], cap_total * 8) != hipSuccess ||
-            hipMalloc(&g->d_cdfall[d], cap_total * 8) != hipSuccess || hipMalloc(&g->d_remote[d], 8) != hipSuccess ||
+            hipMalloc(&g->d_cdfall[d], cap_total * 8) != hipSuccess || hipMalloc(&g->d_remote[d], 32) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_ready[d], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_rays[d], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_children[d], hipEventDisableTiming) != hipSuccess) {
             g_create_error = "group buffers: hipMalloc failed";
             mcl_group_destroy(g);
@@ -2887,40 +2996,62 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
         if (rc) return gfail(g, rc, e->err);
         GHIP(g, hipEventRecord(g->ev_children[d], e->stream));
     }
-    // phase 2: rays + likelihood on every device, then the global maximum
-    for (int d = 0; d < G; ++d) {
-        const int rc = stage_rays_launch(g->eng[d], obs, n_beams, false);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
-    double gmax = -INFINITY;
-    for (int d = 0; d < G; ++d) {
-        const int rc = stage_rays_finish(g->eng[d], obs, n_beams);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-        gmax = std::max(gmax, g->eng[d]->h_scalars[0]);
-    }
+    // phase 2: rays + likelihood on every device; the global maximum is taken ON the devices (every device reads the peers'
+    // local maxima once their ray stages have finished: events, no host wait)
     // phase 3: weights against the global maximum, sums.  The weights (and the compact list) of a shard are rewritten here:
-    // every device must have drawn its children first
-    for (int d = 0; d < G; ++d) {
-        GHIP(g, hipSetDevice(g->eng[d]->cfg.device));
-        for (int o = 0; o < G; ++o)
-            if (o != d) GHIP(g, hipStreamWaitEvent(g->eng[d]->stream, g->ev_children[o], 0));
-        const int rc = stage_weights_launch(g->eng[d], gmax);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
+    // every device must have drawn its children first.  The host waits once, for the sums.
     double gs[5] = {0, 0, 0, 0, 0};
     uint64_t qt = 0;
     unsigned long long remote = 0;
     uint64_t listed = 0;
-    for (int d = 0; d < G; ++d) {
-        mcl_engine *e = g->eng[d];
-        const int rc = stage_weights_finish(e);
-        if (rc) return gfail(g, rc, e->err);
-        for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];      // unpack_result left the LOCAL sums there
-        qt += e->q_total;
-        unsigned long long r = 0;
-        GHIP(g, hipMemcpy(&r, g->d_remote[d], 8, hipMemcpyDeviceToHost));
-        remote += r;
-        if (compact) listed += (uint64_t)counts[d];
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool redo = pass == 1;          // only after a fix-up list overflow: the synchronous ray stage falls back by itself
+        for (int d = 0; d < G; ++d) {
+            mcl_engine *e = g->eng[d];
+            double *lmax = reinterpret_cast<double *>(g->d_remote[d] + 1);
+            int rc = stage_rays_launch(e, obs, n_beams, false, lmax);
+            if (!rc && redo) {
+                rc = stage_rays_finish(e, obs, n_beams);             // (waits; relaunches with k_rays_skip after an overflow)
+                if (!rc && !e->last_quad)                             // the fallback ran: its maximum replaces the first launch's
+                    hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, e->stream, e->d_scalars, lmax);
+            }
+            if (rc) return gfail(g, rc, e->err);
+            GHIP(g, hipEventRecord(g->ev_rays[d], e->stream));
+        }
+        for (int d = 0; d < G; ++d) {
+            mcl_engine *e = g->eng[d];
+            GHIP(g, hipSetDevice(e->cfg.device));
+            mcl::GroupMaxArgs ma{};
+            for (int o = 0; o < G; ++o) {
+                if (o != d) {
+                    GHIP(g, hipStreamWaitEvent(e->stream, g->ev_rays[o], 0));
+                    GHIP(g, hipStreamWaitEvent(e->stream, g->ev_children[o], 0));
+                }
+                ma.src[o] = reinterpret_cast<const double *>(g->d_remote[o] + 1);
+            }
+            ma.n = G; ma.out = reinterpret_cast<double *>(g->d_remote[d] + 2);
+            hipLaunchKernelGGL(mcl::k_group_max, dim3(1), dim3(1), 0, e->stream, ma);
+            const int rc = stage_weights_launch(e, 0.0, ma.out);
+            if (rc) return gfail(g, rc, e->err);
+        }
+        for (int k = 0; k < 5; ++k) gs[k] = 0.0;
+        qt = 0; remote = 0; listed = 0;
+        bool overflow = false;
+        for (int d = 0; d < G; ++d) {
+            mcl_engine *e = g->eng[d];
+            int rc = stage_weights_finish(e);                         // THE host wait of this device's update
+            if (rc) return gfail(g, rc, e->err);
+            stage_rays_note(e);
+            overflow = overflow || (e->last_quad && e->h_fix_count != 0);
+            for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];      // unpack_result left the LOCAL sums there
+            qt += e->q_total;
+            unsigned long long r = 0;
+            GHIP(g, hipMemcpy(&r, g->d_remote[d], 8, hipMemcpyDeviceToHost));
+            remote += r;
+            if (compact) listed += (uint64_t)counts[d];
+        }
+        if (!overflow) break;
+        if (redo) return gfail(g, MCL_ERR_HIP, "the ray stage's work lists overflowed twice (internal)");
     }
     for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
     g->q_total = qt;

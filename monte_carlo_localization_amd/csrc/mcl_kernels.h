@@ -2577,7 +2577,9 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_max(const double *__rest
         part[blockIdx.x] = m;
     }
 }
-__global__ __launch_bounds__(kRedThreads) void k_final_max(const double *__restrict__ part, int nb, double *__restrict__ out)
+// (out2: a second place for the same value -- the caller's exchange buffer in the device-ordered staged flow -- or null)
+__global__ __launch_bounds__(kRedThreads) void k_final_max(const double *__restrict__ part, int nb, double *__restrict__ out,
+                                                           double *__restrict__ out2)
 {
     __shared__ double sm[kRedThreads / 64];
     double m = -INFINITY;
@@ -2588,6 +2590,39 @@ __global__ __launch_bounds__(kRedThreads) void k_final_max(const double *__restr
     if (threadIdx.x == 0) {
         for (int k = 1; k < kRedThreads / 64; ++k) m = fmax(m, sm[k]);
         out[0] = m;
+        if (out2) out2[0] = m;
+    }
+}
+
+__global__ void k_copy_double(const double *__restrict__ src, double *__restrict__ dst) { dst[0] = src[0]; }
+
+// mcl_group_update: the maximum over the shards' maxima, read where they live (peer pointers)
+struct GroupMaxArgs { const double *src[kMaxShards]; int n; double *out; };
+__global__ void k_group_max(GroupMaxArgs a)
+{
+    double m = -INFINITY;
+    for (int i = 0; i < a.n; ++i) m = fmax(m, a.src[i][0]);
+    a.out[0] = m;
+}
+
+// Device-ordered staged flow (mcl_stage_weights_async): this shard's contribution to the one SUM exchange of an update, written
+// where the collective reads it.  vec = [sum w, sum w x, sum w y, sum w sin, sum w cos | per shard: list length + 1 (0: no list),
+// low and high half of the fixed-point weight total | 1 when the ray stage's fix-up lists overflowed]; every other shard's
+// slots are zeroed here, so that the SUM over the shards fills them in.  res = the engine's result block.
+__global__ void k_stage_pack(const unsigned long long *__restrict__ res, double *__restrict__ vec, int n_shards, int self, int listed,
+                             unsigned long long list_cap)
+{
+    const int len = 5 + 3 * n_shards + 1;
+    const double *sc = reinterpret_cast<const double *>(res);
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        double v = 0.0;
+        if (i == 0) v = sc[1];
+        else if (i < 5) v = sc[2 + i];
+        else if (i == 5 + 3 * self) v = (listed && res[16] <= list_cap) ? (double)(res[16] + 1ull) : 0.0;
+        else if (i == 6 + 3 * self) v = (double)(res[2] & 0xFFFFFFFFull);
+        else if (i == 7 + 3 * self) v = (double)(res[2] >> 32);
+        else if (i == len - 1) v = res[12] != 0ull ? 1.0 : 0.0;
+        vec[i] = v;
     }
 }
 

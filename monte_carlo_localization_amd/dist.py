@@ -77,10 +77,16 @@ class ShardedFilter:
         self.use_lists = os.environ.get("MCL_DIST_NO_LISTS") != "1" and hasattr(shard, "export_compact")
         # the two small all-reduces of an update go through tensors made once (a fresh device tensor per update is an
         # allocation and a blocking copy each way: 0.1 ms of the update at 4M particles)
-        self.red_dev = torch.zeros(5 + 3 * self.world, dtype=torch.float64, device=device)
-        self.red_host = torch.zeros(5 + 3 * self.world, dtype=torch.float64)
+        # ([0]: the MAX exchange, [1:]: the SUM exchange with one more element, the ray stage's overflow flag)
+        self.red_dev = torch.zeros(1 + 5 + 3 * self.world + 1, dtype=torch.float64, device=device)
+        self.red_host = torch.zeros(1 + 5 + 3 * self.world + 1, dtype=torch.float64)
         if device.type == "cuda":
             self.red_host = self.red_host.pin_memory()
+        # device-ordered update (one host wait per update, the exchanged scalars never leave the device): needs the engine's
+        # *_async stages; MCL_DIST_SYNC=1 keeps the stage-by-stage flow (A/B measurements, the CPU stand-in of the tests)
+        self.device_ordered = (device.type == "cuda" and hasattr(shard, "stage_complete") and self.use_lists
+                               and os.environ.get("MCL_DIST_SYNC") != "1")
+        self.host_waits = 0                                               # of the last update (tests)
 
     def _all_reduce_small(self, values, op):
         """values (a short float64 sequence) -> their reduction over the ranks, as a numpy array."""
@@ -96,6 +102,7 @@ class ShardedFilter:
     def _sync(self):
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
+            self.host_waits += 1
 
     def reset(self):
         """Call after the shard's particle state was replaced from outside (set_particles / init_*)."""
@@ -126,6 +133,59 @@ class ShardedFilter:
         self._sync()
         work = dist.all_gather_into_tensor(self.chunk_all[:nbytes * self.world], self.chunk_local[:nbytes], group=self.group, async_op=async_op)
         return (work if async_op else None), entries
+
+    def _start_list_gather_ordered(self, async_op):
+        """_start_list_gather without a host wait: the export runs on the engine's stream, the collective's stream waits for it."""
+        entries = max(64, (int(self.counts.max()) + 63) // 64 * 64)
+        nbytes = 44 * entries
+        if self.chunk_local is None or self.chunk_local.numel() < nbytes:
+            self.chunk_local = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.chunk_all = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+        ts = torch.cuda.current_stream(self.device).cuda_stream
+        self.shard.stream_wait_external(ts)          # (the buffers may be fresh, or still read by the previous update's collective)
+        if int(self.counts[self.rank]) > 0:
+            self.shard.export_compact_async(self.chunk_local.data_ptr(), entries)
+        self.shard.external_wait_stream(ts)
+        work = dist.all_gather_into_tensor(self.chunk_all[:nbytes * self.world], self.chunk_local[:nbytes], group=self.group, async_op=async_op)
+        return (work if async_op else None), entries
+
+    def _update_ordered(self, action, obs):
+        """One update with the lists known (every update but the first): everything is enqueued, the two small exchanges read
+        and write device memory, the host waits once -- for the summed vector."""
+        s, world = self.shard, self.world
+        ts = torch.cuda.current_stream(self.device).cuda_stream
+        if self.pending_list is not None:
+            work, entries = self.pending_list                             # issued at the end of the previous update
+            self.pending_list = None
+            if work is not None:
+                work.wait()                                               # (the current stream waits, not the host)
+        else:
+            _, entries = self._start_list_gather_ordered(False)
+        listed = int(self.counts.sum())
+        self.exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (world - 1),
+                                   list_payload_bytes=44 * (listed - int(self.counts[self.rank])), weights_received=0,
+                                   requests_sent=0, records_received=0, distinct_remote_parents=0)
+        s.stream_wait_external(ts)
+        s.stage_resample_compact_async(self.chunk_all.data_ptr(), world, entries, self.counts, self.totals, self.n, self.rank,
+                                       self.rank * self.n, self.n_total, action)
+        k = 5 + 3 * world + 1
+        s.stage_rays_async(obs, self.red_dev.data_ptr())                 # local max log-weight -> red_dev[0]
+        s.external_wait_stream(ts)
+        dist.all_reduce(self.red_dev[:1], op=dist.ReduceOp.MAX, group=self.group)
+        s.stream_wait_external(ts)
+        vec = self.red_dev[1:1 + k]
+        s.stage_weights_async(self.red_dev.data_ptr(), vec.data_ptr(), world, self.rank)
+        s.external_wait_stream(ts)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+        self.red_host[:1 + k].copy_(self.red_dev[:1 + k], non_blocking=True)
+        self._sync()                                                      # THE host wait of the update
+        gs = self.red_host[1:1 + k].numpy().copy()
+        s.stage_complete(gs[:5])
+        if gs[-1] != 0.0:
+            # some shard's fix-up lists overflowed (debug_force_exact at size, a pathological map): every rank runs the ray stage
+            # and the two exchanges once more, stage by stage (the synchronous ray stage falls back to the self-contained kernel)
+            return None
+        return gs[:-1]
 
     def _distinct(self):
         """self.parent (global indices) -> (distinct parents ascending = grouped by owner, position of every child's parent
@@ -208,14 +268,41 @@ class ShardedFilter:
 
     def update(self, action, obs):
         s = self.shard
+        self.host_waits = 0
+        gs = None
         # (1) exchange for resampling + the children
-        if self._lists_usable():
+        if self.device_ordered and self._lists_usable():
+            gs = self._update_ordered(action, obs)                       # the whole update; None: once more from the ray stage on
+        elif self._lists_usable():
             self._resample_from_lists(action)
         else:
             if self.pending_list is not None and self.pending_list[0] is not None:
                 self.pending_list[0].wait()
             self.pending_list = None
             self._resample_dense(action)
+        if gs is None:
+            gs = self._stages_after_children(obs)
+        per = gs[5:].reshape(self.world, 3)
+        self.counts = per[:, 0].astype(np.int64) - 1
+        self.totals = np.array([(int(a) + (int(b) << 32)) & 0xFFFFFFFFFFFFFFFF for a, b in per[:, 1:]], dtype=np.uint64)   # exact: halves < 2^32
+        self.q_total = int(sum(int(t) for t in self.totals)) & 0xFFFFFFFFFFFFFFFF
+        gs = gs[:5]
+        s.stage_finish(gs)
+        if self.overlap:
+            # this update's weights are final: start the exchange of the next update now, beside the host work between updates
+            if self._lists_usable():
+                self.pending_list = (self._start_list_gather_ordered if self.device_ordered else self._start_list_gather)(True)
+            else:
+                s.export_state(0, 0, 0, self.loc_q.data_ptr())
+                self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
+        k = 1.0 / gs[0] if gs[0] > 0 else 1.0
+        self.pose = np.array([gs[1] * k, gs[2] * k, np.arctan2(gs[3] * k, gs[4] * k)])
+        return self.pose
+
+    def _stages_after_children(self, obs):
+        """Ray stage, MAX exchange, weights, SUM exchange -- stage by stage, the host reading each value (first update, dense
+        exchange, the CPU stand-in, the redo after an overflow).  Returns the summed vector."""
+        s = self.shard
         s.stage_rays(obs)
         # (2) global max log-weight
         read = getattr(s, "host_scalars", s.scalars)                      # the stage calls already read SCALARS back
@@ -228,23 +315,7 @@ class ShardedFilter:
         vec = np.zeros(5 + 3 * self.world)
         vec[:5] = (sc[1], sc[3], sc[4], sc[5], sc[6])
         vec[5 + 3 * self.rank: 8 + 3 * self.rank] = (float(n_list + 1), float(ql & 0xFFFFFFFF), float(ql >> 32))
-        gs = self._all_reduce_small(vec, dist.ReduceOp.SUM)
-        per = gs[5:].reshape(self.world, 3)
-        self.counts = per[:, 0].astype(np.int64) - 1
-        self.totals = np.array([(int(a) + (int(b) << 32)) & 0xFFFFFFFFFFFFFFFF for a, b in per[:, 1:]], dtype=np.uint64)   # exact: halves < 2^32
-        self.q_total = int(sum(int(t) for t in self.totals)) & 0xFFFFFFFFFFFFFFFF
-        gs = gs[:5]
-        s.stage_finish(gs)
-        if self.overlap:
-            # this update's weights are final: start the exchange of the next update now, beside the host work between updates
-            if self._lists_usable():
-                self.pending_list = self._start_list_gather(True)
-            else:
-                s.export_state(0, 0, 0, self.loc_q.data_ptr())
-                self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
-        k = 1.0 / gs[0] if gs[0] > 0 else 1.0
-        self.pose = np.array([gs[1] * k, gs[2] * k, np.arctan2(gs[3] * k, gs[4] * k)])
-        return self.pose
+        return self._all_reduce_small(vec, dist.ReduceOp.SUM)
 
     def set_particles(self, xyz_colmajor, weights):
         """Host-supplied particles for this shard (any non-negative weights): every shard quantises its weights against the

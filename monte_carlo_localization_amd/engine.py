@@ -35,6 +35,8 @@ EXPORTS = [
     "mcl_group_get_resample_indices", "mcl_group_get_stage_timings", "mcl_group_exchange_bytes",
     "mcl_set_debug_count_probes", "mcl_set_particles_shard", "mcl_get_compact_list", "mcl_compact_chunk_bytes", "mcl_export_compact",
     "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
+    "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
+    "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete",
 ]
 
 
@@ -456,6 +458,43 @@ class Engine:
     def stage_finish(self, sums5):
         s = _c(sums5, np.float64)
         self._chk(self.lib.mcl_stage_finish(self._h, _p(s)), "mcl_stage_finish")
+
+    # ---- the staged flow ordered on the device (include/mcl_hip_engine.h: "ORDERED ON THE DEVICE"): nothing here waits for the
+    # stream except stage_complete; `stream` is a raw hipStream_t (torch.cuda.current_stream().cuda_stream)
+    def stream_wait_external(self, stream):
+        self._chk(self.lib.mcl_stream_wait_external(self._h, C.c_void_p(stream)), "mcl_stream_wait_external")
+
+    def external_wait_stream(self, stream):
+        self._chk(self.lib.mcl_external_wait_stream(self._h, C.c_void_p(stream)), "mcl_external_wait_stream")
+
+    def export_compact_async(self, d_chunk, chunk_entries):
+        self._chk(self.lib.mcl_export_compact_async(self._h, C.c_void_p(d_chunk), C.c_int64(chunk_entries)), "mcl_export_compact_async")
+
+    def stage_resample_compact_async(self, d_chunks, n_shards, chunk_entries, counts, totals, n_per_shard, self_shard, child_first, n_children_total,
+                                     action):
+        a = _c(action, np.float64)
+        c = np.ascontiguousarray(np.asarray(counts, np.int64))
+        t = np.ascontiguousarray(np.asarray(totals, np.uint64))
+        assert c.size == n_shards and t.size == n_shards
+        self._chk(self.lib.mcl_stage_resample_compact_async(self._h, C.c_void_p(d_chunks), C.c_int32(n_shards), C.c_int64(chunk_entries), _p(c), _p(t),
+                                                            C.c_int64(n_per_shard), C.c_int32(self_shard), C.c_int64(child_first),
+                                                            C.c_int64(n_children_total), _p(a)), "mcl_stage_resample_compact_async")
+
+    def stage_rays_async(self, obs, d_local_max):
+        o = _c(obs, np.float32)
+        self._chk(self.lib.mcl_stage_rays_async(self._h, _p(o), C.c_int32(o.size), C.c_void_p(d_local_max)), "mcl_stage_rays_async")
+
+    def stage_weights_async(self, d_global_max, d_vec, n_shards, self_shard):
+        self._chk(self.lib.mcl_stage_weights_async(self._h, C.c_void_p(d_global_max), C.c_void_p(d_vec), C.c_int32(n_shards), C.c_int32(self_shard)),
+                  "mcl_stage_weights_async")
+
+    def stage_complete(self, sums5) -> bool:
+        """The one host wait of a device-ordered update.  True: the ray stage's fix-up lists overflowed, run the synchronous
+        stages once more (stage_rays .. stage_finish)."""
+        s = _c(sums5, np.float64)
+        redo = C.c_int32(0)
+        self._chk(self.lib.mcl_stage_complete(self._h, _p(s), C.byref(redo)), "mcl_stage_complete")
+        return bool(redo.value)
 
     def scan_weights(self, d_q, d_cdf, n, offset=0):
         self._chk(self.lib.mcl_scan_weights(self._h, C.c_void_p(d_q), C.c_void_p(d_cdf), C.c_int64(n),

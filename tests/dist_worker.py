@@ -50,7 +50,8 @@ def main():
         device = torch.device("cpu")
     else:
         from monte_carlo_localization_amd import engine
-        shard = engine.Engine(max_particles=n_local, device=dev_index, seed=2024, resample_mode=mode)
+        shard = engine.Engine(max_particles=n_local, device=dev_index, seed=2024, resample_mode=mode,
+                              debug_force_exact=int(os.environ.get("MCL_TEST_FORCE_EXACT", "0")))
         shard.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
         shard.set_beam_angles(ang)
         if device_init:
@@ -62,10 +63,11 @@ def main():
     sf = ShardedFilter(shard, n_local, device, overlap=overlap)
     if skewed:
         sf.set_particles(p[:, mine], w)                 # every shard quantises against the maximum of the whole set
-    poses, kinds = [], []
+    poses, kinds, waits = [], [], []
     for _ in range(steps):
         poses.append(sf.update((0.05, 0.0, 0.01), obs))
         kinds.append(sf.exchange_bytes["kind"])
+        waits.append(sf.host_waits)                     # stream synchronisations of this update (1: the device-ordered flow)
     if backend_kind == "oracle":
         parts, q, idx = shard.p, shard.q, shard.idx
     else:
@@ -76,9 +78,9 @@ def main():
     if digest:
         from conftest import block_digests
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=block_digests(parts), q=block_digests(q), idx=block_digests(idx),
-                 poses=np.array(poses), kinds=np.array(kinds))
+                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits))
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits))
     dist.barrier()
     dist.destroy_process_group()
 

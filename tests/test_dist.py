@@ -110,6 +110,65 @@ def test_two_ranks_dense_exchange_and_skewed_weights_hip_engine(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [False, True])
+def test_device_ordered_update_waits_once_and_equals_the_stage_by_stage_flow(tmp_path, overlap):
+    """The default flow on a GPU (dist.py `_update_ordered`, the mcl_stage_*_async calls): the two small exchanges read and
+    write device memory and the host waits ONCE per update; MCL_DIST_SYNC=1 is the stage-by-stage flow with a wait per value.
+    Same kernels in the same order: identical bits -- here with k_rays_sweep (131 072 particles x 361 beams per rank) and,
+    in the one-rank run, against a plain engine's mcl_update."""
+    do, ds, d1 = tmp_path / "ordered", tmp_path / "sync", tmp_path / "one"
+    do.mkdir(); ds.mkdir(); d1.mkdir()
+    n = 131072
+    two = run_world("engine", do, 2, n, 4, 0, overlap, MCL_TEST_BEAM_STEP="3")
+    ref = run_world("engine", ds, 2, n, 4, 0, overlap, MCL_TEST_BEAM_STEP="3", MCL_DIST_SYNC="1")
+    one = run_world("engine", d1, 1, 2 * n, 4, 0, False, MCL_TEST_BEAM_STEP="3")
+    for r in range(2):
+        for k in ("idx", "particles", "q", "poses"):
+            assert np.array_equal(two[r][k], ref[r][k]), (r, k)
+        assert list(two[r]["kinds"]) == ["dense", "lists", "lists", "lists"]
+        assert list(two[r]["waits"][1:]) == [1, 1, 1]                   # (the first update has no lists yet: stage by stage)
+        assert min(ref[r]["waits"][1:]) >= 4
+    check_equal(two, one, n)
+    assert list(one[0]["waits"][1:]) == [1, 1, 1]
+    # ... and the plain engine, same seed and particles: the sharded flow is the single engine's update bit for bit
+    import __graft_entry__ as g
+    g.build()
+    from conftest import GOLDEN
+    from monte_carlo_localization_amd import engine, maps
+    from oracle import oracle as orc
+    m = maps.load_npz(os.path.join(GOLDEN, "map_Spielberg_map.npz"))
+    rng = np.random.default_rng(123)
+    p = np.stack([rng.normal(0, 0.5, 2 * n), rng.normal(0, 0.5, 2 * n), rng.normal(0, 0.4, 2 * n)])
+    e = engine.Engine(max_particles=2 * n, seed=2024, resample_mode=0)
+    e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+    e.set_beam_angles(orc.beam_angles(angle_step=3))
+    e.set_particles(p, np.full(2 * n, 1.0 / (2 * n)))
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::3].copy()
+    for _ in range(4):
+        e.update((0.05, 0.0, 0.01), obs)
+    assert e.ray_kernel_name() == "k_rays_sweep"
+    assert np.array_equal(e.get_particles(), one[0]["particles"])
+    assert np.array_equal(e.resample_indices(), one[0]["idx"])
+    e.close()
+
+
+@pytest.mark.gpu
+def test_device_ordered_update_redoes_the_ray_stage_after_a_list_overflow(tmp_path):
+    """debug_force_exact=2 sends every ray to the fix-up lists, which overflow: the device-ordered update learns that from the
+    summed vector (its last element), and every rank runs the ray stage and the exchanges again stage by stage -- same result
+    as the stage-by-stage flow, whose ray stage falls back by itself."""
+    do, ds = tmp_path / "ordered", tmp_path / "sync"
+    do.mkdir(); ds.mkdir()
+    n = 65536
+    two = run_world("engine", do, 2, n, 3, 0, False, MCL_TEST_BEAM_STEP="3", MCL_TEST_FORCE_EXACT="2")
+    ref = run_world("engine", ds, 2, n, 3, 0, False, MCL_TEST_BEAM_STEP="3", MCL_TEST_FORCE_EXACT="2", MCL_DIST_SYNC="1")
+    for r in range(2):
+        for k in ("idx", "particles", "q", "poses"):
+            assert np.array_equal(two[r][k], ref[r][k]), (r, k)
+        assert min(two[r]["waits"][1:]) > 1                            # the redo ran
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_children,n_total,span", [(5000, 40000, 40000), (70000, 1 << 20, 3000), (4096, 4096, 4096), (1000, 33, 33)])
 def test_engine_distinct_parents_and_records_at(n_children, n_total, span):
     """mcl_stage_distinct_parents (bitmap + popcount prefix) against numpy.unique, and mcl_export_records_at against the
