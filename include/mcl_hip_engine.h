@@ -340,6 +340,30 @@ int mcl_stage_resample_compact_async(mcl_engine_t *h, const void *d_chunks, int3
 int mcl_stage_rays_async(mcl_engine_t *h, const float *obs, int32_t n_beams, double *d_local_max);
 int mcl_stage_weights_async(mcl_engine_t *h, const double *d_global_max, double *d_vec, int32_t n_shards, int32_t self_shard);
 int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *redo);
+/* ---- one process per GPU, the exchange in native code (RCCL on the engine's own stream) -----------------------------------
+ * The engine holds an RCCL communicator; mcl_comm_update is ONE sharded update: all-gather of the compact parent lists,
+ * resampling + motion from the merged lists, ray stage, all-reduce MAX of the max log-weight, weights + scan + list,
+ * all-reduce SUM of the sums -- the three collectives enqueued on the engine's stream between its kernels (no second stream,
+ * no event between streams, no host code between the stages), ONE host wait at the end.  Bit-identical to mcl_update of a
+ * single engine holding all shards (same kernels as the staged calls above).
+ *   mcl_comm_available: MCL_OK when an RCCL library can be used (the one already loaded in the process, e.g. a torch
+ *     process's, else librccl.so.1 of the ROCm installation; taken with dlopen -- the engine does not link RCCL);
+ *   mcl_comm_unique_id: on ONE rank; the host passes the 128 bytes to every rank (any channel: MPI, torch.distributed, a file);
+ *   mcl_comm_create: COLLECTIVE (every rank calls it, ncclCommInitRank inside); one rank per device;
+ *   mcl_comm_update: counts[r] / totals[r] = list length and fixed-point weight total of shard r as the PREVIOUS update's
+ *     summed vector gave them (mcl_stage_weights_async documents the vector; after the first update or a set / init call, when
+ *     some shard has no list yet, the host runs the stage calls and the dense exchange instead: MCL_ERR_NOT_READY here, nothing
+ *     touched); vec_out receives the summed vector of THIS update (5 + 3 * n_ranks + 1 doubles): [0..4] the global sums (also
+ *     installed, as mcl_stage_finish does), then per shard list length + 1 and the two halves of its weight total;
+ *   mcl_comm_stats: bytes the last list exchange delivered to this rank (padded chunks) / carried (entries), host waits. */
+int mcl_comm_available(const char **why);
+int mcl_comm_unique_id(unsigned char id[128]);
+int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank);
+int mcl_comm_destroy(mcl_engine_t *h);
+int mcl_comm_update(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals, int64_t n_per_shard, const double action[3],
+                    const float *obs, int32_t n_beams, double *vec_out);
+int mcl_comm_stats(const mcl_engine_t *h, uint64_t *list_bytes_received, uint64_t *list_payload_bytes, int32_t *host_waits);
+
 /* Inclusive scan of q (uint64) on the engine's stream: cdf[i] = offset + q[0] + ... + q[i]. */
 int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset);
 

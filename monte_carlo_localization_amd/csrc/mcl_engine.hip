@@ -8,7 +8,9 @@
 #include "../../include/mcl_hip_engine.h"
 
 #include <cstring>
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
@@ -38,6 +40,8 @@ constexpr int kResultWords = 17;
 constexpr int kResultStage = 40;             // h_result word that stages a host value on its way to the device
 constexpr int kResultStamp = 32;             // h_result word a small update's last kernel stamps (the host polls it)
 
+struct mcl_comm;
+static void comm_free(struct mcl_comm *c);
 struct mcl_engine {
     mcl_config_t cfg{};
     int num_cu = 256;
@@ -192,6 +196,7 @@ struct mcl_engine {
     hipEvent_t ev_children = nullptr, ev_layout = nullptr;
     hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;   // ordering against a caller's stream (mcl_stream_wait_external / mcl_external_wait_stream)
     bool stage_async_rays = false, stage_async_weights = false;
+    struct mcl_comm *comm = nullptr;    // RCCL communicator of a sharded set (mcl_comm_create), or null
     bool layout_valid = false, layout_pending = false;
     int64_t layout_n = 0;
     bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
@@ -237,6 +242,7 @@ int fail(mcl_engine *h, int code, const char *msg)
     if (h) h->err = msg;
     return code;
 }
+int fail(mcl_engine *h, int code, const std::string &msg) { return fail(h, code, msg.c_str()); }
 
 template <class T>
 void dfree(T *&p)
@@ -1232,6 +1238,7 @@ void mcl_destroy(mcl_engine_t *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) { comm_free(h->comm); h->comm = nullptr; }
     graph_reset(h);
     for (int b = 0; b < 2; ++b) { dfree(h->d_x[b]); dfree(h->d_y[b]); dfree(h->d_th[b]); }
     dfree(h->d_w); dfree(h->d_logw); dfree(h->d_tmp); dfree(h->d_logw_acc); dfree(h->d_carry[0]); dfree(h->d_carry[1]); dfree(h->d_q); dfree(h->d_cdf); dfree(h->d_blocktot); dfree(h->d_bm); dfree(h->d_bm_pop); dfree(h->d_bm_pref);
@@ -2693,6 +2700,230 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
     // self-contained kernel) and the two exchanges after it; the children are untouched
     *redo = (h->last_quad && h->h_fix_count != 0) ? 1 : 0;
     for (int i = 0; i < 5; ++i) h->global_sums[i] = global_sums[i];
+    return MCL_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// One process per GPU, the exchange in native code: the engine holds an RCCL communicator and one call runs a whole sharded
+// update -- the three collectives of an update (all-gather of the compact parent lists, all-reduce MAX of one double,
+// all-reduce SUM of 5 + 3 G + 1 doubles) are enqueued on the ENGINE'S OWN STREAM between its kernels: no second stream, no
+// event hop, no interpreter between the stages; the host waits once, for the summed vector.  RCCL is taken from the process
+// at run time (dlopen: the library a torch process already carries, else the ROCm one): the engine does not link it, and a
+// host without RCCL keeps every other entry point.  The rendezvous (128-byte id from rank 0 to every rank) is the host's.
+// ---------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+static RcclApi &rccl_api()
+{
+    static RcclApi api;
+    if (api.lib || !api.why.empty()) return api;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *nm : names) {
+        api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already has (a torch process: torch's)
+        if (api.lib) break;
+    }
+    for (const char *nm : names) {
+        if (api.lib) break;
+        api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!api.lib) { api.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return api; }
+    auto sym = [&](const char *n) { void *p = dlsym(api.lib, n); if (!p && api.why.empty()) api.why = std::string("RCCL symbol missing: ") + n; return p; };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!api.why.empty()) api.lib = nullptr;
+    return api;
+}
+
+struct mcl_comm {
+    ncclComm_t comm = nullptr;
+    int n_ranks = 0, rank = 0;
+    unsigned char *d_chunk_local = nullptr, *d_chunk_all = nullptr;     // the lists: this shard's chunk, every shard's
+    size_t chunk_capacity = 0;                                           // entries per chunk the buffers hold
+    double *d_red = nullptr;                                             // [0] MAX exchange | [1 ..] SUM exchange
+    double *h_red = nullptr;                                             // pinned copy of it
+    uint64_t bytes_received = 0, bytes_payload = 0;                      // of the last update's list exchange
+    int host_waits = 0;
+};
+
+static void comm_free(mcl_comm *c)
+{
+    if (!c) return;
+    if (c->comm && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(c->comm);
+    if (c->d_chunk_local) (void)hipFree(c->d_chunk_local);
+    if (c->d_chunk_all) (void)hipFree(c->d_chunk_all);
+    if (c->d_red) (void)hipFree(c->d_red);
+    if (c->h_red) (void)hipHostFree(c->h_red);
+    delete c;
+}
+
+#define NCCLCHK(h, call)                                                                                          \
+    do {                                                                                                          \
+        ncclResult_t r_ = (call);                                                                                 \
+        if (r_ != ncclSuccess) return fail(h, MCL_ERR_HIP, std::string(#call) + ": " + rccl_api().GetErrorString(r_)); \
+    } while (0)
+
+int mcl_comm_available(const char **why)
+{
+    RcclApi &api = rccl_api();
+    if (why) *why = api.lib ? "" : api.why.c_str();
+    return api.lib ? MCL_OK : MCL_ERR_UNSUPPORTED;
+}
+
+int mcl_comm_unique_id(unsigned char id[128])
+{
+    RcclApi &api = rccl_api();
+    if (!id) return MCL_ERR_INVALID_ARG;
+    if (!api.lib) return MCL_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId u;
+    if (api.GetUniqueId(&u) != ncclSuccess) return MCL_ERR_HIP;
+    std::memcpy(id, &u, 128);
+    return MCL_OK;
+}
+
+int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank)
+{
+    if (!h || !id || n_ranks <= 0 || n_ranks > mcl::kMaxShards || rank < 0 || rank >= n_ranks) return MCL_ERR_INVALID_ARG;
+    RcclApi &api = rccl_api();
+    if (!api.lib) return fail(h, MCL_ERR_UNSUPPORTED, api.why);
+    if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
+        return fail(h, MCL_ERR_UNSUPPORTED, "a sharded set needs weight_mode LOG and resample_neff_permille 0");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->comm) { comm_free(h->comm); h->comm = nullptr; }
+    mcl_comm *c = new mcl_comm();
+    c->n_ranks = n_ranks; c->rank = rank;
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    const ncclResult_t r = api.CommInitRank(&c->comm, n_ranks, u, rank);          // collective: every rank is in this call
+    if (r != ncclSuccess) { c->comm = nullptr; comm_free(c); return fail(h, MCL_ERR_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)); }
+    const size_t words = 1 + 5 + 3 * (size_t)n_ranks + 1;
+    if (hipMalloc(&c->d_red, words * 8) != hipSuccess || hipHostMalloc(&c->h_red, words * 8) != hipSuccess) {
+        comm_free(c);
+        return fail(h, MCL_ERR_HIP, "mcl_comm_create: allocation failed");
+    }
+    h->comm = c;
+    return MCL_OK;
+}
+
+int mcl_comm_destroy(mcl_engine_t *h)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    if (h->comm) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipStreamSynchronize(h->stream);
+        comm_free(h->comm);
+        h->comm = nullptr;
+    }
+    return MCL_OK;
+}
+
+// rays -> local max -> all-reduce MAX -> weights, scan, list -> this shard's part of the sums -> all-reduce SUM -> pinned host
+static int comm_rays_to_sums(mcl_engine_t *h, const float *obs, int32_t n_beams, bool sync_rays)
+{
+    mcl_comm *c = h->comm;
+    RcclApi &api = rccl_api();
+    const size_t k = 5 + 3 * (size_t)c->n_ranks + 1;
+    int rc = stage_rays_launch(h, obs, n_beams, false, c->d_red);
+    if (rc) return rc;
+    if (sync_rays) {                      // after an overflow: wait, let the synchronous stage fall back to the self-contained kernel
+        rc = stage_rays_finish(h, obs, n_beams);
+        if (rc) return rc;
+        c->host_waits += 1;
+        hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, h->stream, h->d_scalars, c->d_red);
+    }
+    NCCLCHK(h, api.AllReduce(c->d_red, c->d_red, 1, ncclDouble, ncclMax, c->comm, h->stream));
+    rc = stage_weights_launch(h, 0.0, c->d_red);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mcl::k_stage_pack, dim3(1), dim3(64), 0, h->stream, h->d_result, c->d_red + 1, c->n_ranks, c->rank, h->compact_pending ? 1 : 0,
+                       (unsigned long long)h->compact_cap);
+    HIPCHK(h, hipGetLastError());
+    NCCLCHK(h, api.AllReduce(c->d_red + 1, c->d_red + 1, k, ncclDouble, ncclSum, c->comm, h->stream));
+    HIPCHK(h, hipMemcpyAsync(c->h_red, c->d_red, (1 + k) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));                       // THE host wait of the update
+    c->host_waits += 1;
+    unpack_result(h);
+    stage_rays_note(h);
+    h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
+    return layout_adopt(h, h->N);
+}
+
+int mcl_comm_update(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals, int64_t n_per_shard, const double action[3],
+                    const float *obs, int32_t n_beams, double *vec_out)
+{
+    if (!h || !counts || !totals || !action || !obs || !vec_out || n_per_shard <= 0) return MCL_ERR_INVALID_ARG;
+    mcl_comm *c = h->comm;
+    if (!c) return fail(h, MCL_ERR_NOT_READY, "mcl_comm_create first");
+    if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
+    if (n_beams != h->B || h->N != n_per_shard) return fail(h, MCL_ERR_INVALID_ARG, "bad observation / shard size");
+    RcclApi &api = rccl_api();
+    const int G = c->n_ranks;
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t longest = 0, listed = 0;
+    uint64_t weight = 0;
+    for (int r = 0; r < G; ++r) {
+        if (counts[r] < 0) return fail(h, MCL_ERR_NOT_READY, "a shard has no compact list: this update takes the dense exchange (dist.py)");
+        longest = std::max(longest, counts[r]); listed += counts[r];
+        weight += counts[r] > 0 ? totals[r] : 0ull;
+    }
+    if (weight == 0) return fail(h, MCL_ERR_NOT_READY, "the lists carry no weight");
+    if (counts[c->rank] != h->compact_n) return fail(h, MCL_ERR_INVALID_ARG, "counts[rank] is not this engine's list length");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    c->host_waits = 0;
+    const int64_t entries = std::max<int64_t>(64, (longest + 63) & ~(int64_t)63);
+    if ((size_t)entries > c->chunk_capacity) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (c->d_chunk_local) (void)hipFree(c->d_chunk_local);
+        if (c->d_chunk_all) (void)hipFree(c->d_chunk_all);
+        c->d_chunk_local = c->d_chunk_all = nullptr; c->chunk_capacity = 0;
+        const size_t cap = (size_t)entries + (size_t)entries / 4;            // lists breathe from update to update
+        HIPCHK(h, hipMalloc(&c->d_chunk_local, cap * 44));
+        HIPCHK(h, hipMalloc(&c->d_chunk_all, cap * 44 * (size_t)G));
+        c->chunk_capacity = cap;
+    }
+    // (1) the lists: nothing of the engine's state has changed before the first collective has been accepted
+    int rc = export_compact_launch(h, c->d_chunk_local, entries, h->cfg.device, h->stream);
+    if (rc) return rc;
+    NCCLCHK(h, api.AllGather(c->d_chunk_local, c->d_chunk_all, (size_t)entries * 44, ncclChar, c->comm, h->stream));
+    c->bytes_received = (uint64_t)entries * 44u * (uint64_t)(G - 1);
+    c->bytes_payload = (uint64_t)(listed - counts[c->rank]) * 44u;
+    rc = stage_resample_compact_launch(h, c->d_chunk_all, G, entries, counts, totals, n_per_shard, c->rank, (int64_t)c->rank * n_per_shard,
+                                       n_per_shard * G, action, nullptr);
+    if (rc) return rc;
+    // (2) + (3)
+    rc = comm_rays_to_sums(h, obs, n_beams, false);
+    if (rc) return rc;
+    const size_t k = 5 + 3 * (size_t)G + 1;
+    if (c->h_red[1 + k - 1] != 0.0) {
+        // some shard's fix-up lists overflowed (debug_force_exact at size, a pathological map): every rank once more from the ray stage on
+        rc = comm_rays_to_sums(h, obs, n_beams, true);
+        if (rc) return rc;
+    }
+    for (size_t i = 0; i < k; ++i) vec_out[i] = c->h_red[1 + i];
+    for (int i = 0; i < 5; ++i) h->global_sums[i] = vec_out[i];
+    h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MCL_OK;
+}
+
+int mcl_comm_stats(const mcl_engine_t *h, uint64_t *list_bytes_received, uint64_t *list_payload_bytes, int32_t *host_waits)
+{
+    if (!h || !h->comm) return MCL_ERR_INVALID_ARG;
+    if (list_bytes_received) *list_bytes_received = h->comm->bytes_received;
+    if (list_payload_bytes) *list_payload_bytes = h->comm->bytes_payload;
+    if (host_waits) *host_waits = h->comm->host_waits;
     return MCL_OK;
 }
 

@@ -32,6 +32,7 @@ stand-in that lives under tests/.
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 import torch
@@ -87,6 +88,41 @@ class ShardedFilter:
         self.device_ordered = (device.type == "cuda" and hasattr(shard, "stage_complete") and self.use_lists
                                and os.environ.get("MCL_DIST_SYNC") != "1")
         self.host_waits = 0                                               # of the last update (tests)
+        # native exchange (one rank per DEVICE over RCCL): the engine holds its own RCCL communicator and runs the whole update
+        # in one call, the collectives on its own stream (include/mcl_hip_engine.h: mcl_comm_*).  torch.distributed then only
+        # carries the rendezvous and the first update's dense exchange.  Needs the nccl backend (a gloo rehearsal shares one
+        # device between the ranks, which RCCL refuses); MCL_DIST_NATIVE=0 keeps the torch collectives.
+        self.native = False
+        if (self.device_ordered and hasattr(shard, "comm_update") and os.environ.get("MCL_DIST_NATIVE") != "0"
+                and dist.get_backend(group) == "nccl"):
+            self.native = self._make_native_comm()
+
+    def _make_native_comm(self):
+        """Every rank ends with the same answer: the communicator exists everywhere, or nowhere (torch collectives then)."""
+        ok, why = self.shard.comm_available()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            if self.rank == 0:
+                print(f"[dist] no RCCL for the engine on some rank ({why or 'another rank'}): torch collectives", file=sys.stderr)
+            return False
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            uid.copy_(torch.from_numpy(np.frombuffer(self.shard.comm_unique_id(), dtype=np.uint8).copy()))
+        dist.broadcast(uid, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        try:
+            self.shard.comm_create(uid.cpu().numpy().tobytes(), self.world, self.rank)
+            made = 1
+        except Exception as ex:                        # noqa: BLE001 -- any failure here means "not on this rank"
+            print(f"[dist] rank {self.rank}: mcl_comm_create failed ({ex}): torch collectives", file=sys.stderr)
+            made = 0
+        flag.fill_(made)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            if made:
+                self.shard.comm_destroy()
+            return False
+        return True
 
     def _all_reduce_small(self, values, op):
         """values (a short float64 sequence) -> their reduction over the ranks, as a numpy array."""
@@ -271,7 +307,13 @@ class ShardedFilter:
         self.host_waits = 0
         gs = None
         # (1) exchange for resampling + the children
-        if self.device_ordered and self._lists_usable():
+        if self.native and self._lists_usable():
+            gs = s.comm_update(self.counts, self.totals, self.n, action, obs)[:-1]      # the whole update, one call
+            st = s.comm_stats()
+            self.host_waits = st["host_waits"]
+            self.exchange_bytes.update(kind="lists", list_bytes_received=st["list_bytes_received"], list_payload_bytes=st["list_payload_bytes"],
+                                       weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
+        elif self.device_ordered and self._lists_usable():
             gs = self._update_ordered(action, obs)                       # the whole update; None: once more from the ray stage on
         elif self._lists_usable():
             self._resample_from_lists(action)
@@ -291,7 +333,8 @@ class ShardedFilter:
         if self.overlap:
             # this update's weights are final: start the exchange of the next update now, beside the host work between updates
             if self._lists_usable():
-                self.pending_list = (self._start_list_gather_ordered if self.device_ordered else self._start_list_gather)(True)
+                if not self.native:                  # (the native update gathers on the engine's stream, first thing)
+                    self.pending_list = (self._start_list_gather_ordered if self.device_ordered else self._start_list_gather)(True)
             else:
                 s.export_state(0, 0, 0, self.loc_q.data_ptr())
                 self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)

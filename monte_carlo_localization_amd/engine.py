@@ -37,6 +37,7 @@ EXPORTS = [
     "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
     "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete",
+    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats",
 ]
 
 
@@ -495,6 +496,49 @@ class Engine:
         redo = C.c_int32(0)
         self._chk(self.lib.mcl_stage_complete(self._h, _p(s), C.byref(redo)), "mcl_stage_complete")
         return bool(redo.value)
+
+    # ---- the sharded update in native code: an RCCL communicator inside the engine (include/mcl_hip_engine.h: mcl_comm_*)
+    @staticmethod
+    def comm_available():
+        """(True, "") when the library finds an RCCL to use, else (False, why)."""
+        why = C.c_char_p()
+        rc = load_library().mcl_comm_available(C.byref(why))
+        return rc == MCL_OK, (why.value or b"").decode()
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        rc = load_library().mcl_comm_unique_id(buf)
+        if rc != MCL_OK:
+            raise EngineError(f"mcl_comm_unique_id rc={rc}")
+        return bytes(buf)
+
+    def comm_create(self, uid: bytes, n_ranks: int, rank: int):
+        """COLLECTIVE: every rank calls it with rank 0's id."""
+        assert len(uid) == 128
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        self._chk(self.lib.mcl_comm_create(self._h, buf, C.c_int32(n_ranks), C.c_int32(rank)), "mcl_comm_create")
+        self._comm_ranks = n_ranks
+
+    def comm_destroy(self):
+        self._chk(self.lib.mcl_comm_destroy(self._h), "mcl_comm_destroy")
+
+    def comm_update(self, counts, totals, n_per_shard, action, obs):
+        """One sharded update; returns the summed vector (5 + 3 * ranks + 1 doubles)."""
+        g = self._comm_ranks
+        c = np.ascontiguousarray(np.asarray(counts, np.int64))
+        t = np.ascontiguousarray(np.asarray(totals, np.uint64))
+        assert c.size == g and t.size == g
+        a = _c(action, np.float64)
+        o = _c(obs, np.float32)
+        vec = np.zeros(5 + 3 * g + 1)
+        self._chk(self.lib.mcl_comm_update(self._h, _p(c), _p(t), C.c_int64(n_per_shard), _p(a), _p(o), C.c_int32(o.size), _p(vec)), "mcl_comm_update")
+        return vec
+
+    def comm_stats(self):
+        r, p, w = C.c_uint64(), C.c_uint64(), C.c_int32()
+        self._chk(self.lib.mcl_comm_stats(self._h, C.byref(r), C.byref(p), C.byref(w)), "mcl_comm_stats")
+        return dict(list_bytes_received=r.value, list_payload_bytes=p.value, host_waits=w.value)
 
     def scan_weights(self, d_q, d_cdf, n, offset=0):
         self._chk(self.lib.mcl_scan_weights(self._h, C.c_void_p(d_q), C.c_void_p(d_cdf), C.c_int64(n),

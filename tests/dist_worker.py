@@ -78,9 +78,9 @@ def main():
     if digest:
         from conftest import block_digests
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=block_digests(parts), q=block_digests(q), idx=block_digests(idx),
-                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits))
+                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), native=np.array(int(getattr(sf, 'native', False))))
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), native=np.array(int(getattr(sf, 'native', False))))
     dist.barrier()
     dist.destroy_process_group()
 
