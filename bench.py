@@ -490,6 +490,9 @@ def main():
             # stream synchronisations of one steady-state update on this rank (dist.py: 1 = device-ordered, the small exchanges
             # stay in device memory; MCL_DIST_SYNC=1: a wait per exchanged value)
             line["host_waits_per_update"] = sf.host_waits
+            # who runs the collectives of an update: the engine itself (mcl_comm_*: RCCL on its own stream, one native call per
+            # update) or dist.py through torch.distributed (gloo rehearsals, MCL_DIST_NATIVE=0)
+            line["collectives"] = "engine (RCCL on the engine's stream)" if sf.native else f"torch.distributed ({args.backend})"
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
         if parity and (parity["logw_mismatches"] or parity.get("idx_mismatches", 0)):

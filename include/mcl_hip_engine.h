@@ -350,18 +350,22 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
  *     process's, else librccl.so.1 of the ROCm installation; taken with dlopen -- the engine does not link RCCL);
  *   mcl_comm_unique_id: on ONE rank; the host passes the 128 bytes to every rank (any channel: MPI, torch.distributed, a file);
  *   mcl_comm_create: COLLECTIVE (every rank calls it, ncclCommInitRank inside); one rank per device;
- *   mcl_comm_update: counts[r] / totals[r] = list length and fixed-point weight total of shard r as the PREVIOUS update's
- *     summed vector gave them (mcl_stage_weights_async documents the vector; after the first update or a set / init call, when
- *     some shard has no list yet, the host runs the stage calls and the dense exchange instead: MCL_ERR_NOT_READY here, nothing
- *     touched); vec_out receives the summed vector of THIS update (5 + 3 * n_ranks + 1 doubles): [0..4] the global sums (also
- *     installed, as mcl_stage_finish does), then per shard list length + 1 and the two halves of its weight total;
- *   mcl_comm_stats: bytes the last list exchange delivered to this rank (padded chunks) / carried (entries), host waits. */
+ *   mcl_comm_update: == ParticleFilter::MCL(action, observation) + expected_pose() (cpp:652-716) for the whole sharded set; the
+ *     shards' list lengths and weight totals come from the PREVIOUS update's summed vector (mcl_stage_weights_async documents
+ *     it), which the communicator keeps.  MCL_ERR_NOT_READY, nothing touched: they are not known or some shard has no list
+ *     (the first update, after a set / init call): the host runs the stage calls with the dense exchange for this update and
+ *     hands the result over with mcl_comm_set_lists (counts[r]: list length of shard r, -1 none; totals[r]: its fixed-point
+ *     weight total).  The global sums are installed as mcl_stage_finish does; mcl_comm_get_vector returns the summed vector
+ *     (5 + 3 * n_ranks + 1 doubles) of the last update;
+ *   mcl_comm_stats: bytes the last list exchange delivered to this rank (padded chunks) / carried (entries), host waits of the
+ *     last update. */
 int mcl_comm_available(const char **why);
 int mcl_comm_unique_id(unsigned char id[128]);
 int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank);
 int mcl_comm_destroy(mcl_engine_t *h);
-int mcl_comm_update(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals, int64_t n_per_shard, const double action[3],
-                    const float *obs, int32_t n_beams, double *vec_out);
+int mcl_comm_set_lists(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals);
+int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, double pose_out[3]);
+int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n);
 int mcl_comm_stats(const mcl_engine_t *h, uint64_t *list_bytes_received, uint64_t *list_payload_bytes, int32_t *host_waits);
 
 /* Inclusive scan of q (uint64) on the engine's stream: cdf[i] = offset + q[0] + ... + q[i]. */

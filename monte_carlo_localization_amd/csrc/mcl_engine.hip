@@ -197,11 +197,13 @@ struct mcl_engine {
     hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;   // ordering against a caller's stream (mcl_stream_wait_external / mcl_external_wait_stream)
     bool stage_async_rays = false, stage_async_weights = false;
     struct mcl_comm *comm = nullptr;    // RCCL communicator of a sharded set (mcl_comm_create), or null
+    unsigned long long list_epoch = 0;  // counts the rewrites of the compact list (a gathered copy of an older one is stale)
     bool layout_valid = false, layout_pending = false;
     int64_t layout_n = 0;
     bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
     bool keys_done = false;             // ... and its resampling kernel wrote the (key, index) pairs
     bool env_no_stale_layout = false;   // MCL_NO_STALE_LAYOUT: every update makes its own layout first (rounds 1-3)
+    bool env_comm_no_pregather = false; // MCL_COMM_NO_PREGATHER: mcl_comm_update gathers the lists when it starts, not when the previous one ends
     mcl::PrepClear prep_passed{};       // what the resampling kernel was given to clear (prep_folded)
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
     size_t slice_mean_capacity = 0;
@@ -488,7 +490,7 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
     hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf, h->d_leaders, co);
     HIPCHK(h, hipGetLastError());
     h->blocktot_for = d_cdf; h->blocktot_n = n;
-    if (d_cdf == h->d_cdf) { h->compact_n = -1; h->compact_pending = own; }
+    if (d_cdf == h->d_cdf) { h->compact_n = -1; h->compact_pending = own; h->list_epoch++; }
     return MCL_OK;
 }
 
@@ -1030,7 +1032,7 @@ int weights_and_cdf(mcl_engine *h, bool result_to_host = false)
         h->max_partials_ready = false;
         h->carry_pending = false;
         h->blocktot_for = nullptr;             // no spine / leaders for this CDF: the resampling search bisects it directly
-        h->compact_n = -1; h->compact_pending = false;
+        h->compact_n = -1; h->compact_pending = false; h->list_epoch++;
         return MCL_OK;
     }
     int rc = sensor_and_weights(h, nullptr, true);             // (the sums are finished by the scan's spine)
@@ -1117,6 +1119,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     h->env_no_obs_overlap = getenv("MCL_NO_OBS_OVERLAP") != nullptr;
     h->env_no_prep_fold = getenv("MCL_NO_PREP_FOLD") != nullptr;
     h->env_no_stale_layout = getenv("MCL_NO_STALE_LAYOUT") != nullptr;
+    h->env_comm_no_pregather = getenv("MCL_COMM_NO_PREGATHER") != nullptr;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
     auto bail = [&](const char *what) {
@@ -2757,6 +2760,16 @@ struct mcl_comm {
     double *h_red = nullptr;                                             // pinned copy of it
     uint64_t bytes_received = 0, bytes_payload = 0;                      // of the last update's list exchange
     int host_waits = 0;
+    // what the shards' lists look like (the previous update's summed vector, or mcl_comm_set_lists after a dense update)
+    bool lists_known = false;
+    int64_t counts[mcl::kMaxShards] = {};
+    uint64_t totals[mcl::kMaxShards] = {};
+    double vec[5 + 3 * mcl::kMaxShards + 1] = {};                        // the last summed vector
+    // the lists of the NEXT update, gathered right after this update's sums (beside whatever the host does between updates)
+    bool gathered = false;
+    unsigned long long gathered_epoch = 0;
+    int64_t gathered_entries = 0;
+    int64_t gathered_counts[mcl::kMaxShards] = {};
 };
 
 static void comm_free(mcl_comm *c)
@@ -2861,29 +2874,16 @@ static int comm_rays_to_sums(mcl_engine_t *h, const float *obs, int32_t n_beams,
     return layout_adopt(h, h->N);
 }
 
-int mcl_comm_update(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals, int64_t n_per_shard, const double action[3],
-                    const float *obs, int32_t n_beams, double *vec_out)
+// export of this shard's list + all-gather of the chunks, on the engine's stream
+static int comm_gather_lists(mcl_engine_t *h, const int64_t *counts)
 {
-    if (!h || !counts || !totals || !action || !obs || !vec_out || n_per_shard <= 0) return MCL_ERR_INVALID_ARG;
     mcl_comm *c = h->comm;
-    if (!c) return fail(h, MCL_ERR_NOT_READY, "mcl_comm_create first");
-    if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
-    if (n_beams != h->B || h->N != n_per_shard) return fail(h, MCL_ERR_INVALID_ARG, "bad observation / shard size");
     RcclApi &api = rccl_api();
     const int G = c->n_ranks;
-    const auto t0 = std::chrono::steady_clock::now();
     int64_t longest = 0, listed = 0;
-    uint64_t weight = 0;
-    for (int r = 0; r < G; ++r) {
-        if (counts[r] < 0) return fail(h, MCL_ERR_NOT_READY, "a shard has no compact list: this update takes the dense exchange (dist.py)");
-        longest = std::max(longest, counts[r]); listed += counts[r];
-        weight += counts[r] > 0 ? totals[r] : 0ull;
-    }
-    if (weight == 0) return fail(h, MCL_ERR_NOT_READY, "the lists carry no weight");
-    if (counts[c->rank] != h->compact_n) return fail(h, MCL_ERR_INVALID_ARG, "counts[rank] is not this engine's list length");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    c->host_waits = 0;
+    for (int r = 0; r < G; ++r) { longest = std::max(longest, counts[r]); listed += counts[r]; }
     const int64_t entries = std::max<int64_t>(64, (longest + 63) & ~(int64_t)63);
+    c->gathered = false;
     if ((size_t)entries > c->chunk_capacity) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (c->d_chunk_local) (void)hipFree(c->d_chunk_local);
@@ -2894,12 +2894,67 @@ int mcl_comm_update(mcl_engine_t *h, const int64_t *counts, const uint64_t *tota
         HIPCHK(h, hipMalloc(&c->d_chunk_all, cap * 44 * (size_t)G));
         c->chunk_capacity = cap;
     }
-    // (1) the lists: nothing of the engine's state has changed before the first collective has been accepted
-    int rc = export_compact_launch(h, c->d_chunk_local, entries, h->cfg.device, h->stream);
+    const int rc = export_compact_launch(h, c->d_chunk_local, entries, h->cfg.device, h->stream);
     if (rc) return rc;
     NCCLCHK(h, api.AllGather(c->d_chunk_local, c->d_chunk_all, (size_t)entries * 44, ncclChar, c->comm, h->stream));
     c->bytes_received = (uint64_t)entries * 44u * (uint64_t)(G - 1);
     c->bytes_payload = (uint64_t)(listed - counts[c->rank]) * 44u;
+    c->gathered = true; c->gathered_epoch = h->list_epoch; c->gathered_entries = entries;
+    for (int r = 0; r < G; ++r) c->gathered_counts[r] = counts[r];
+    return MCL_OK;
+}
+
+// the shards' list lengths and weight totals out of a summed vector
+static void comm_note_lists(mcl_comm *c, const double *vec)
+{
+    const int G = c->n_ranks;
+    for (int r = 0; r < G; ++r) {
+        c->counts[r] = (int64_t)vec[5 + 3 * r] - 1;
+        c->totals[r] = ((uint64_t)vec[6 + 3 * r] + ((uint64_t)vec[7 + 3 * r] << 32));      // exact: halves < 2^32
+    }
+    c->lists_known = true;
+}
+
+int mcl_comm_set_lists(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals)
+{
+    if (!h || !h->comm || !counts || !totals) return MCL_ERR_INVALID_ARG;
+    mcl_comm *c = h->comm;
+    for (int r = 0; r < c->n_ranks; ++r) { c->counts[r] = counts[r]; c->totals[r] = totals[r]; }
+    c->lists_known = true;
+    return MCL_OK;
+}
+
+int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, double pose_out[3])
+{
+    if (!h || !action || !obs || !pose_out) return MCL_ERR_INVALID_ARG;
+    mcl_comm *c = h->comm;
+    if (!c) return fail(h, MCL_ERR_NOT_READY, "mcl_comm_create first");
+    if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
+    if (n_beams != h->B) return fail(h, MCL_ERR_INVALID_ARG, "bad observation");
+    const int G = c->n_ranks;
+    const int64_t n_per_shard = h->N;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!c->lists_known) return fail(h, MCL_ERR_NOT_READY, "the shards' lists are not known: this update takes the dense exchange, then mcl_comm_set_lists");
+    const int64_t *counts = c->counts;
+    const uint64_t *totals = c->totals;
+    uint64_t weight = 0;
+    for (int r = 0; r < G; ++r) {
+        if (counts[r] < 0) return fail(h, MCL_ERR_NOT_READY, "a shard has no compact list: this update takes the dense exchange");
+        weight += counts[r] > 0 ? totals[r] : 0ull;
+    }
+    if (weight == 0) return fail(h, MCL_ERR_NOT_READY, "the lists carry no weight");
+    if (counts[c->rank] != h->compact_n) return fail(h, MCL_ERR_NOT_READY, "this engine's list is not the one the last exchange described");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    c->host_waits = 0;
+    // (1) the lists: already here when the previous update gathered them (same lists, same lengths), else now.  Nothing of
+    // the engine's state has changed before the first collective has been accepted
+    bool have = c->gathered && c->gathered_epoch == h->list_epoch;
+    for (int r = 0; r < G && have; ++r) have = c->gathered_counts[r] == counts[r];
+    int rc = have ? MCL_OK : comm_gather_lists(h, counts);
+    if (rc) return rc;
+    const int64_t entries = c->gathered_entries;
+    c->gathered = false;
+    c->lists_known = false;                // (known again once this update's vector is here)
     rc = stage_resample_compact_launch(h, c->d_chunk_all, G, entries, counts, totals, n_per_shard, c->rank, (int64_t)c->rank * n_per_shard,
                                        n_per_shard * G, action, nullptr);
     if (rc) return rc;
@@ -2912,9 +2967,30 @@ int mcl_comm_update(mcl_engine_t *h, const int64_t *counts, const uint64_t *tota
         rc = comm_rays_to_sums(h, obs, n_beams, true);
         if (rc) return rc;
     }
-    for (size_t i = 0; i < k; ++i) vec_out[i] = c->h_red[1 + i];
-    for (int i = 0; i < 5; ++i) h->global_sums[i] = vec_out[i];
+    for (size_t i = 0; i < k; ++i) c->vec[i] = c->h_red[1 + i];
+    for (int i = 0; i < 5; ++i) h->global_sums[i] = c->vec[i];
+    comm_note_lists(c, c->vec);
+    // the lists this update wrote are final: gather them for the next update now, beside the host's work between updates
+    // (every rank reads the same vector, so every rank takes the same decision)
+    {
+        bool all = true;
+        uint64_t wsum = 0;
+        for (int r = 0; r < G; ++r) { all = all && c->counts[r] >= 0; wsum |= c->counts[r] > 0 ? c->totals[r] : 0ull; }
+        if (all && wsum != 0 && !h->env_comm_no_pregather) {
+            rc = comm_gather_lists(h, c->counts);
+            if (rc) return rc;
+        }
+    }
+    const double sw = c->vec[0], kk = sw > 0.0 ? 1.0 / sw : 1.0;          // expected_pose (cpp:702-716) over the whole set
+    pose_out[0] = c->vec[1] * kk; pose_out[1] = c->vec[2] * kk; pose_out[2] = std::atan2(c->vec[3] * kk, c->vec[4] * kk);
     h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MCL_OK;
+}
+
+int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n)
+{
+    if (!h || !h->comm || !vec_out || n != 5 + 3 * h->comm->n_ranks + 1) return MCL_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i) vec_out[i] = h->comm->vec[i];
     return MCL_OK;
 }
 

@@ -66,7 +66,7 @@ class ShardedFilter:
         self.uniq_buf = torch.empty(n, dtype=i64, device=device)        # distinct parents of the local children (ascending)
         self.slot_buf = torch.empty(n, dtype=i32, device=device)        # every child's position among them
         self.pose = np.zeros(3)
-        self.exchange_bytes = dict(kind="none", weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0,
+        self._exchange_bytes = dict(kind="none", weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0,
                                    list_bytes_received=0, list_payload_bytes=0)
         # list exchange: every rank's list length (-1: none) and fixed-point total, known from the previous update's sums
         self.counts = None
@@ -87,15 +87,29 @@ class ShardedFilter:
         # *_async stages; MCL_DIST_SYNC=1 keeps the stage-by-stage flow (A/B measurements, the CPU stand-in of the tests)
         self.device_ordered = (device.type == "cuda" and hasattr(shard, "stage_complete") and self.use_lists
                                and os.environ.get("MCL_DIST_SYNC") != "1")
-        self.host_waits = 0                                               # of the last update (tests)
+        self._host_waits = 0                                               # of the last update (tests)
         # native exchange (one rank per DEVICE over RCCL): the engine holds its own RCCL communicator and runs the whole update
         # in one call, the collectives on its own stream (include/mcl_hip_engine.h: mcl_comm_*).  torch.distributed then only
         # carries the rendezvous and the first update's dense exchange.  Needs the nccl backend (a gloo rehearsal shares one
         # device between the ranks, which RCCL refuses); MCL_DIST_NATIVE=0 keeps the torch collectives.
         self.native = False
+        self.native_updates = 0                                           # consecutive updates the native call has run
         if (self.device_ordered and hasattr(shard, "comm_update") and os.environ.get("MCL_DIST_NATIVE") != "0"
                 and dist.get_backend(group) == "nccl"):
             self.native = self._make_native_comm()
+
+    @property
+    def host_waits(self):
+        """Stream synchronisations of the last update on this rank."""
+        return self.shard.comm_stats()["host_waits"] if self.native_updates > 0 else self._host_waits
+
+    @property
+    def exchange_bytes(self):
+        if self.native_updates > 0:
+            st = self.shard.comm_stats()
+            self._exchange_bytes.update(kind="lists", list_bytes_received=st["list_bytes_received"], list_payload_bytes=st["list_payload_bytes"],
+                                        weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
+        return self._exchange_bytes
 
     def _make_native_comm(self):
         """Every rank ends with the same answer: the communicator exists everywhere, or nowhere (torch collectives then)."""
@@ -138,7 +152,7 @@ class ShardedFilter:
     def _sync(self):
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
-            self.host_waits += 1
+            self._host_waits += 1
 
     def reset(self):
         """Call after the shard's particle state was replaced from outside (set_particles / init_*)."""
@@ -150,6 +164,9 @@ class ShardedFilter:
         self.pending_list = None
         self.q_total = None
         self.counts = self.totals = None
+        if self.native:
+            self.shard.comm_set_lists([-1] * self.world, [0] * self.world)      # no lists: the next update is a dense one on every rank
+            self.native_updates = 0
 
     # ---- list exchange
     def _lists_usable(self):
@@ -198,7 +215,7 @@ class ShardedFilter:
         else:
             _, entries = self._start_list_gather_ordered(False)
         listed = int(self.counts.sum())
-        self.exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (world - 1),
+        self._exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (world - 1),
                                    list_payload_bytes=44 * (listed - int(self.counts[self.rank])), weights_received=0,
                                    requests_sent=0, records_received=0, distinct_remote_parents=0)
         s.stream_wait_external(ts)
@@ -251,7 +268,7 @@ class ShardedFilter:
         local = (uniq - torch.div(uniq, n, rounding_mode="floor") * n).contiguous()
         if world == 1:
             self._records_at(local, table)
-            self.exchange_bytes.update(requests_sent=0, records_received=0, distinct_remote_parents=0)
+            self._exchange_bytes.update(requests_sent=0, records_received=0, distinct_remote_parents=0)
             return table, inv
         send_counts = torch.tensor(sc, dtype=torch.int64, device=self.device)
         recv_counts = torch.empty_like(send_counts)
@@ -264,7 +281,7 @@ class ShardedFilter:
         self._sync()
         dist.all_to_all_single(table, reply, output_split_sizes=sc, input_split_sizes=rcv, group=self.group)
         remote = k - sc[self.rank]
-        self.exchange_bytes.update(requests_sent=8 * remote, records_received=32 * remote, distinct_remote_parents=remote)
+        self._exchange_bytes.update(requests_sent=8 * remote, records_received=32 * remote, distinct_remote_parents=remote)
         return table, inv
 
     def _resample_from_lists(self, action):
@@ -279,7 +296,7 @@ class ShardedFilter:
         listed = int(self.counts.sum())
         # what crosses the links is the padded chunk of every other rank (the all-gather moves `entries` entries per rank: the
         # longest list rounded up to 64); the entries that carry data are reported beside it
-        self.exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (self.world - 1),
+        self._exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (self.world - 1),
                                    list_payload_bytes=44 * (listed - int(self.counts[self.rank])), weights_received=0,
                                    requests_sent=0, records_received=0, distinct_remote_parents=0)
         self.shard.stage_resample_compact(self.chunk_all.data_ptr(), self.world, entries, self.counts, self.totals, self.n, self.rank,
@@ -294,7 +311,7 @@ class ShardedFilter:
             self.pending_q.wait()                                        # issued at the end of the previous update
             self.pending_q = None
         self._sync()
-        self.exchange_bytes.update(kind="dense", weights_received=8 * self.n * (self.world - 1), list_bytes_received=0, list_payload_bytes=0)
+        self._exchange_bytes.update(kind="dense", weights_received=8 * self.n * (self.world - 1), list_bytes_received=0, list_payload_bytes=0)
         s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
         s.stage_resample_indices(self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, self.parent.data_ptr())
@@ -304,15 +321,18 @@ class ShardedFilter:
 
     def update(self, action, obs):
         s = self.shard
-        self.host_waits = 0
+        self._host_waits = 0
         gs = None
         # (1) exchange for resampling + the children
-        if self.native and self._lists_usable():
-            gs = s.comm_update(self.counts, self.totals, self.n, action, obs)[:-1]      # the whole update, one call
-            st = s.comm_stats()
-            self.host_waits = st["host_waits"]
-            self.exchange_bytes.update(kind="lists", list_bytes_received=st["list_bytes_received"], list_payload_bytes=st["list_payload_bytes"],
-                                       weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
+        if self.native:
+            pose = s.comm_update(action, obs)          # the whole update in one native call; None: no lists yet, nothing touched
+            if pose is not None:
+                self.pose = pose
+                self.native_updates += 1
+                self.q_total = self.counts = self.totals = None           # (the communicator keeps them now)
+                return pose
+            self.native_updates = 0
+            self._resample_dense(action)
         elif self.device_ordered and self._lists_usable():
             gs = self._update_ordered(action, obs)                       # the whole update; None: once more from the ray stage on
         elif self._lists_usable():
@@ -330,6 +350,8 @@ class ShardedFilter:
         self.q_total = int(sum(int(t) for t in self.totals)) & 0xFFFFFFFFFFFFFFFF
         gs = gs[:5]
         s.stage_finish(gs)
+        if self.native:
+            s.comm_set_lists(self.counts, self.totals)      # what the next (native) update's list exchange works from
         if self.overlap:
             # this update's weights are final: start the exchange of the next update now, beside the host work between updates
             if self._lists_usable():

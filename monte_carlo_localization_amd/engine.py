@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcl_hip_engine.so")
 
 MCL_OK = 0
+MCL_ERR_NOT_READY = -2
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 WEIGHT_LOG, WEIGHT_PRODUCT = 0, 1
 RAYS_AUTO, RAYS_MARCH, RAYS_SKIP, RAYS_QUAD, RAYS_CELL, RAYS_SWEEP = 0, 1, 2, 3, 4, 5
@@ -37,7 +38,7 @@ EXPORTS = [
     "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
     "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete",
-    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats",
+    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector",
 ]
 
 
@@ -523,16 +524,27 @@ class Engine:
     def comm_destroy(self):
         self._chk(self.lib.mcl_comm_destroy(self._h), "mcl_comm_destroy")
 
-    def comm_update(self, counts, totals, n_per_shard, action, obs):
-        """One sharded update; returns the summed vector (5 + 3 * ranks + 1 doubles)."""
-        g = self._comm_ranks
+    def comm_set_lists(self, counts, totals):
         c = np.ascontiguousarray(np.asarray(counts, np.int64))
         t = np.ascontiguousarray(np.asarray(totals, np.uint64))
-        assert c.size == g and t.size == g
+        assert c.size == self._comm_ranks and t.size == self._comm_ranks
+        self._chk(self.lib.mcl_comm_set_lists(self._h, _p(c), _p(t)), "mcl_comm_set_lists")
+
+    def comm_update(self, action, obs):
+        """One sharded update in one native call; the pose of the whole set, or None when this update needs the dense exchange
+        (no lists yet: nothing was touched)."""
         a = _c(action, np.float64)
         o = _c(obs, np.float32)
-        vec = np.zeros(5 + 3 * g + 1)
-        self._chk(self.lib.mcl_comm_update(self._h, _p(c), _p(t), C.c_int64(n_per_shard), _p(a), _p(o), C.c_int32(o.size), _p(vec)), "mcl_comm_update")
+        pose = np.zeros(3)
+        rc = self.lib.mcl_comm_update(self._h, _p(a), _p(o), C.c_int32(o.size), _p(pose))
+        if rc == MCL_ERR_NOT_READY:
+            return None
+        self._chk(rc, "mcl_comm_update")
+        return pose
+
+    def comm_vector(self):
+        vec = np.zeros(5 + 3 * self._comm_ranks + 1)
+        self._chk(self.lib.mcl_comm_get_vector(self._h, _p(vec), C.c_int32(vec.size)), "mcl_comm_get_vector")
         return vec
 
     def comm_stats(self):
