@@ -2521,7 +2521,8 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_maxpart, mcl::kRedBlocks, h->d_scalars, d_max_out);
     h->max_partials_ready = false;
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
+    if (!d_max_out)          // (the device-ordered flows read the result block once, after the weights)
+        HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
     return MCL_OK;
 }
 
@@ -2850,7 +2851,7 @@ static int comm_rays_to_sums(mcl_engine_t *h, const float *obs, int32_t n_beams,
     mcl_comm *c = h->comm;
     RcclApi &api = rccl_api();
     const size_t k = 5 + 3 * (size_t)c->n_ranks + 1;
-    int rc = stage_rays_launch(h, obs, n_beams, false, c->d_red);
+    int rc = stage_rays_launch(h, obs, n_beams, false, sync_rays ? nullptr : c->d_red);
     if (rc) return rc;
     if (sync_rays) {                      // after an overflow: wait, let the synchronous stage fall back to the self-contained kernel
         rc = stage_rays_finish(h, obs, n_beams);
@@ -3316,11 +3317,10 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
         for (int d = 0; d < G; ++d) {
             mcl_engine *e = g->eng[d];
             double *lmax = reinterpret_cast<double *>(g->d_remote[d] + 1);
-            int rc = stage_rays_launch(e, obs, n_beams, false, lmax);
+            int rc = stage_rays_launch(e, obs, n_beams, false, redo ? nullptr : lmax);
             if (!rc && redo) {
                 rc = stage_rays_finish(e, obs, n_beams);             // (waits; relaunches with k_rays_skip after an overflow)
-                if (!rc && !e->last_quad)                             // the fallback ran: its maximum replaces the first launch's
-                    hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, e->stream, e->d_scalars, lmax);
+                if (!rc) hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, e->stream, e->d_scalars, lmax);
             }
             if (rc) return gfail(g, rc, e->err);
             GHIP(g, hipEventRecord(g->ev_rays[d], e->stream));

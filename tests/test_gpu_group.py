@@ -94,6 +94,30 @@ def test_group_with_the_sweep_kernel_and_set_particles(orc, engine_mod, spielber
     grp.close(); one.close()
 
 
+def test_group_redoes_the_ray_stage_when_a_fix_up_list_overflows(orc, engine_mod, spielberg):
+    """debug_force_exact=2 sends every ray of k_rays_sweep to the fix-up lists, which overflow.  The group takes the maximum on
+    the devices and waits only for the sums: it learns of the overflow there and runs the ray stage (now with the self-contained
+    kernel) and the reductions once more -- same children and weights as one engine, whose update does the same by itself."""
+    from conftest import tracking_cloud
+    ang = orc.beam_angles(angle_step=3)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::3].astype(np.float32)
+    n = 131072
+    p = tracking_cloud(np.random.default_rng(5), n)
+    w = np.full(n, 1.0 / n)
+    one = make_engine(engine_mod, spielberg, ang, n, seed=13, debug_force_exact=2)
+    one.set_particles(p, w)
+    grp = make_group(engine_mod, spielberg, ang, n // 2, 2, seed=13, debug_force_exact=2)
+    grp.set_particles(p, w)
+    for k in range(3):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        assert np.array_equal(grp.resample_indices(), one.resample_indices()), f"update {k}"
+    assert one.ray_kernel_name() == "k_rays_skip"                      # the fallback ran
+    assert np.array_equal(grp.get_particles(), one.get_particles())
+    np.testing.assert_allclose(grp.get_weights(), one.get_weights(), rtol=1e-13, atol=0)
+    grp.close(); one.close()
+
+
 def test_group_set_particles_with_non_uniform_weights(orc, engine_mod, spielberg):
     """Host-supplied weights that differ between the shards (the second shard holds most of the mass): every shard is
     quantised against the maximum of the WHOLE set, so the global CDF -- and with it every child -- equals one engine's."""
