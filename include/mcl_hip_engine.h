@@ -350,15 +350,17 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
  *     process's, else librccl.so.1 of the ROCm installation; taken with dlopen -- the engine does not link RCCL);
  *   mcl_comm_unique_id: on ONE rank; the host passes the 128 bytes to every rank (any channel: MPI, torch.distributed, a file);
  *   mcl_comm_create: COLLECTIVE (every rank calls it, ncclCommInitRank inside); one rank per device;
- *   mcl_comm_update: == ParticleFilter::MCL(action, observation) + expected_pose() (cpp:652-716) for the whole sharded set; the
+ *   mcl_comm_update: == ParticleFilter::MCL(action, observation) + expected_pose() (cpp:652-716) for the whole sharded set.  The
  *     shards' list lengths and weight totals come from the PREVIOUS update's summed vector (mcl_stage_weights_async documents
- *     it), which the communicator keeps.  MCL_ERR_NOT_READY, nothing touched: they are not known or some shard has no list
- *     (the first update, after a set / init call): the host runs the stage calls with the dense exchange for this update and
- *     hands the result over with mcl_comm_set_lists (counts[r]: list length of shard r, -1 none; totals[r]: its fixed-point
- *     weight total).  The global sums are installed as mcl_stage_finish does; mcl_comm_get_vector returns the summed vector
- *     (5 + 3 * n_ranks + 1 doubles) of the last update;
- *   mcl_comm_stats: bytes the last list exchange delivered to this rank (padded chunks) / carried (entries), host waits of the
- *     last update. */
+ *     it), which the communicator keeps.  When they are not known (the first update after the particles were set or
+ *     initialised on every rank) or some shard has no list, the update takes the DENSE exchange instead, also on the engine's
+ *     stream: all-gather of every shard's fixed-point weights and packed records (8 + 32 B per particle), one global CDF, the
+ *     same draw (one more host wait, for the weight total).  Every rank decides from the same numbers, so every rank issues the
+ *     same collectives.  The global sums are installed as mcl_stage_finish does; mcl_comm_get_vector returns the summed vector
+ *     (5 + 3 * n_ranks + 1 doubles) of the last update.  mcl_comm_set_lists hands over list lengths (-1: none) and weight totals
+ *     found by other means (a host that ran an update through the stage calls);
+ *   mcl_comm_stats: bytes the last LIST exchange delivered to this rank (padded chunks) / carried (entries), host waits of the
+ *     last update; mcl_comm_last_exchange: whether the last update took the dense exchange, and the bytes it received. */
 int mcl_comm_available(const char **why);
 int mcl_comm_unique_id(unsigned char id[128]);
 int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank);
@@ -367,6 +369,7 @@ int mcl_comm_set_lists(mcl_engine_t *h, const int64_t *counts, const uint64_t *t
 int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, double pose_out[3]);
 int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n);
 int mcl_comm_stats(const mcl_engine_t *h, uint64_t *list_bytes_received, uint64_t *list_payload_bytes, int32_t *host_waits);
+int mcl_comm_last_exchange(const mcl_engine_t *h, int32_t *dense, uint64_t *weights_bytes, uint64_t *records_bytes);
 
 /* Inclusive scan of q (uint64) on the engine's stream: cdf[i] = offset + q[0] + ... + q[i]. */
 int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset);

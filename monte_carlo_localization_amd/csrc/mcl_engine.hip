@@ -42,6 +42,7 @@ constexpr int kResultStamp = 32;             // h_result word a small update's l
 
 struct mcl_comm;
 static void comm_free(struct mcl_comm *c);
+static void comm_forget(struct mcl_comm *c);
 struct mcl_engine {
     mcl_config_t cfg{};
     int num_cu = 256;
@@ -203,6 +204,7 @@ struct mcl_engine {
     bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
     bool keys_done = false;             // ... and its resampling kernel wrote the (key, index) pairs
     bool env_no_stale_layout = false;   // MCL_NO_STALE_LAYOUT: every update makes its own layout first (rounds 1-3)
+    bool env_comm_no_lists = false;     // MCL_COMM_NO_LISTS: mcl_comm_update takes the dense exchange on every update
     bool env_comm_no_pregather = false; // MCL_COMM_NO_PREGATHER: mcl_comm_update gathers the lists when it starts, not when the previous one ends
     mcl::PrepClear prep_passed{};       // what the resampling kernel was given to clear (prep_folded)
     double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
@@ -1120,6 +1122,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     h->env_no_prep_fold = getenv("MCL_NO_PREP_FOLD") != nullptr;
     h->env_no_stale_layout = getenv("MCL_NO_STALE_LAYOUT") != nullptr;
     h->env_comm_no_pregather = getenv("MCL_COMM_NO_PREGATHER") != nullptr;
+    h->env_comm_no_lists = getenv("MCL_COMM_NO_LISTS") != nullptr;
     h->num_cu = prop.multiProcessorCount;
     h->cap = cfg->max_particles;
     auto bail = [&](const char *what) {
@@ -1508,6 +1511,7 @@ static int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *
     h->far_fresh = true;
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
+    comm_forget(h->comm);                   // a sharded set: the other shards' lists are unknown again
     return MCL_OK;
 }
 
@@ -1537,6 +1541,7 @@ static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
     h->far_fresh = true;
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
+    comm_forget(h->comm);                   // a sharded set: the other shards' lists are unknown again
     h->init_idx++;
     return MCL_OK;
 }
@@ -2761,6 +2766,13 @@ struct mcl_comm {
     double *h_red = nullptr;                                             // pinned copy of it
     uint64_t bytes_received = 0, bytes_payload = 0;                      // of the last update's list exchange
     int host_waits = 0;
+    // dense exchange (an update without lists: the first after the particles were set): every shard's fixed-point weights,
+    // their global CDF and every shard's packed records; allocated when first needed
+    uint64_t *d_qall = nullptr, *d_cdfall = nullptr;
+    double4 *d_recall = nullptr;
+    size_t dense_capacity = 0;                                           // particles (all shards) the three arrays hold
+    bool last_dense = false;
+    uint64_t dense_weights_bytes = 0, dense_records_bytes = 0;
     // what the shards' lists look like (the previous update's summed vector, or mcl_comm_set_lists after a dense update)
     bool lists_known = false;
     int64_t counts[mcl::kMaxShards] = {};
@@ -2773,6 +2785,13 @@ struct mcl_comm {
     int64_t gathered_counts[mcl::kMaxShards] = {};
 };
 
+static void comm_forget(mcl_comm *c)
+{
+    if (!c) return;
+    c->lists_known = false;
+    c->gathered = false;
+}
+
 static void comm_free(mcl_comm *c)
 {
     if (!c) return;
@@ -2781,6 +2800,9 @@ static void comm_free(mcl_comm *c)
     if (c->d_chunk_all) (void)hipFree(c->d_chunk_all);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->d_qall) (void)hipFree(c->d_qall);
+    if (c->d_cdfall) (void)hipFree(c->d_cdfall);
+    if (c->d_recall) (void)hipFree(c->d_recall);
     delete c;
 }
 
@@ -2925,6 +2947,59 @@ int mcl_comm_set_lists(mcl_engine_t *h, const int64_t *counts, const uint64_t *t
     return MCL_OK;
 }
 
+// An update without lists (the first after the particles were set or initialised, or a shard whose list outgrew its arrays):
+// every shard's fixed-point weights and packed records are gathered whole (8 + 32 B per particle of the other shards), every
+// rank scans the same global CDF and draws its own children from it -- the same thresholds as every other path.
+static int comm_resample_dense(mcl_engine_t *h, const double action[3])
+{
+    mcl_comm *c = h->comm;
+    RcclApi &api = rccl_api();
+    const int G = c->n_ranks;
+    const int64_t n = h->N, nt = n * G;
+    if (nt >= MCL_MAX_TOTAL_PARTICLES) return fail(h, MCL_ERR_INVALID_ARG, "particle total must stay below 2^27");
+    if ((size_t)nt > c->dense_capacity) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (c->d_qall) (void)hipFree(c->d_qall);
+        if (c->d_cdfall) (void)hipFree(c->d_cdfall);
+        if (c->d_recall) (void)hipFree(c->d_recall);
+        c->d_qall = c->d_cdfall = nullptr; c->d_recall = nullptr; c->dense_capacity = 0;
+        HIPCHK(h, hipMalloc(&c->d_qall, (size_t)nt * 8));
+        HIPCHK(h, hipMalloc(&c->d_cdfall, (size_t)nt * 8));
+        HIPCHK(h, hipMalloc(&c->d_recall, (size_t)nt * sizeof(double4)));
+        c->dense_capacity = (size_t)nt;
+    }
+    if ((size_t)nt / mcl::kScanTile + 2 > h->blocktot_capacity) {          // spine scratch of the scan, sized for one shard so far
+        graph_reset(h);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        dfree(h->d_blocktot);
+        HIPCHK(h, hipMalloc(&h->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8));
+        h->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;
+    }
+    const int cur = h->cur;
+    if (!h->pack_valid[cur]) {
+        hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_x[cur], h->d_y[cur], h->d_th[cur], n,
+                           h->d_pack[cur]);
+        h->pack_valid[cur] = true;
+    }
+    NCCLCHK(h, api.AllGather(h->d_q, c->d_qall, (size_t)n, ncclUint64, c->comm, h->stream));
+    NCCLCHK(h, api.AllGather(h->d_pack[cur], c->d_recall, (size_t)n * sizeof(double4), ncclChar, c->comm, h->stream));
+    int rc = scan_weights(h, c->d_qall, c->d_cdfall, nt, 0, nullptr);
+    if (rc) return rc;
+    // the draw needs the global fixed-point total on the host (a launch argument): one more wait, in an update that has no lists
+    uint64_t q_total = 0;
+    HIPCHK(h, hipMemcpyAsync(&c->h_red[0], c->d_cdfall + (nt - 1), 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    c->host_waits += 1;
+    std::memcpy(&q_total, &c->h_red[0], 8);
+    if (q_total == 0) return fail(h, MCL_ERR_NOT_READY, "the particle set carries no weight");
+    ParentSource src;
+    src.records = c->d_recall;
+    c->last_dense = true;
+    c->dense_weights_bytes = (uint64_t)n * 8u * (uint64_t)(G - 1);
+    c->dense_records_bytes = (uint64_t)n * 32u * (uint64_t)(G - 1);
+    return stage_resample_launch(h, src, c->d_cdfall, nt, q_total, (int64_t)c->rank * n, nt, action);
+}
+
 int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, double pose_out[3])
 {
     if (!h || !action || !obs || !pose_out) return MCL_ERR_INVALID_ARG;
@@ -2935,29 +3010,38 @@ int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, i
     const int G = c->n_ranks;
     const int64_t n_per_shard = h->N;
     const auto t0 = std::chrono::steady_clock::now();
-    if (!c->lists_known) return fail(h, MCL_ERR_NOT_READY, "the shards' lists are not known: this update takes the dense exchange, then mcl_comm_set_lists");
-    const int64_t *counts = c->counts;
-    const uint64_t *totals = c->totals;
-    uint64_t weight = 0;
-    for (int r = 0; r < G; ++r) {
-        if (counts[r] < 0) return fail(h, MCL_ERR_NOT_READY, "a shard has no compact list: this update takes the dense exchange");
-        weight += counts[r] > 0 ? totals[r] : 0ull;
-    }
-    if (weight == 0) return fail(h, MCL_ERR_NOT_READY, "the lists carry no weight");
-    if (counts[c->rank] != h->compact_n) return fail(h, MCL_ERR_NOT_READY, "this engine's list is not the one the last exchange described");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     c->host_waits = 0;
-    // (1) the lists: already here when the previous update gathered them (same lists, same lengths), else now.  Nothing of
-    // the engine's state has changed before the first collective has been accepted
-    bool have = c->gathered && c->gathered_epoch == h->list_epoch;
-    for (int r = 0; r < G && have; ++r) have = c->gathered_counts[r] == counts[r];
-    int rc = have ? MCL_OK : comm_gather_lists(h, counts);
-    if (rc) return rc;
-    const int64_t entries = c->gathered_entries;
-    c->gathered = false;
-    c->lists_known = false;                // (known again once this update's vector is here)
-    rc = stage_resample_compact_launch(h, c->d_chunk_all, G, entries, counts, totals, n_per_shard, c->rank, (int64_t)c->rank * n_per_shard,
-                                       n_per_shard * G, action, nullptr);
+    c->last_dense = false;
+    const int64_t *counts = c->counts;
+    const uint64_t *totals = c->totals;
+    // Lists or not is decided from what EVERY rank knows alike (the previous update's summed vector): all ranks take the same branch.
+    bool lists = c->lists_known && !h->env_comm_no_lists;
+    uint64_t weight = 0;
+    for (int r = 0; r < G && lists; ++r) {
+        lists = counts[r] >= 0;
+        weight += counts[r] > 0 ? totals[r] : 0ull;
+    }
+    lists = lists && weight != 0;
+    if (lists && counts[c->rank] != h->compact_n)
+        return fail(h, MCL_ERR_NOT_READY, "this engine's list is not the one the last exchange described (state changed on one rank only?)");
+    int rc;
+    if (lists) {
+        // (1) the lists: already here when the previous update gathered them (same lists, same lengths), else now
+        bool have = c->gathered && c->gathered_epoch == h->list_epoch;
+        for (int r = 0; r < G && have; ++r) have = c->gathered_counts[r] == counts[r];
+        rc = have ? MCL_OK : comm_gather_lists(h, counts);
+        if (rc) return rc;
+        const int64_t entries = c->gathered_entries;
+        c->gathered = false;
+        c->lists_known = false;                // (known again once this update's vector is here)
+        rc = stage_resample_compact_launch(h, c->d_chunk_all, G, entries, counts, totals, n_per_shard, c->rank, (int64_t)c->rank * n_per_shard,
+                                           n_per_shard * G, action, nullptr);
+    } else {
+        c->gathered = false;
+        c->lists_known = false;
+        rc = comm_resample_dense(h, action);
+    }
     if (rc) return rc;
     // (2) + (3)
     rc = comm_rays_to_sums(h, obs, n_beams, false);
@@ -2992,6 +3076,15 @@ int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n)
 {
     if (!h || !h->comm || !vec_out || n != 5 + 3 * h->comm->n_ranks + 1) return MCL_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i) vec_out[i] = h->comm->vec[i];
+    return MCL_OK;
+}
+
+int mcl_comm_last_exchange(const mcl_engine_t *h, int32_t *dense, uint64_t *weights_bytes, uint64_t *records_bytes)
+{
+    if (!h || !h->comm) return MCL_ERR_INVALID_ARG;
+    if (dense) *dense = h->comm->last_dense ? 1 : 0;
+    if (weights_bytes) *weights_bytes = h->comm->last_dense ? h->comm->dense_weights_bytes : 0;
+    if (records_bytes) *records_bytes = h->comm->last_dense ? h->comm->dense_records_bytes : 0;
     return MCL_OK;
 }
 

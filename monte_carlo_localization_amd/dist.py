@@ -1,5 +1,15 @@
-"""Particle set sharded over the GPUs of one node: one process per GPU, one engine per process,
-torch.distributed (backend "nccl" == RCCL over xGMI) for the exchange steps of an update.
+"""Particle set sharded over the GPUs of one node: one process per GPU, one engine per process.
+
+Who runs the collectives of an update (three hosts over the same engine stages, bit-identical results):
+  * backend "nccl", one rank per device (the production case): the ENGINE -- it holds its own RCCL communicator
+    (mcl_comm_*, include/mcl_hip_engine.h) and `mcl_comm_update` is the whole update in one native call, the all-gather and the
+    two all-reduces enqueued on the engine's stream between its kernels, one host wait.  torch.distributed then only carries
+    the 128-byte rendezvous (`_make_native_comm`).
+  * any backend, a GPU, MCL_DIST_NATIVE=0 or gloo (rehearsals with several ranks on one device): torch's collectives, ordered
+    against the engine's stream by events (`_update_ordered`: mcl_stage_*_async, the reduced values stay in device memory,
+    one host wait); MCL_DIST_SYNC=1: stage by stage, the host reading every value (rounds 1-3).
+  * a CPU stand-in (tests): stage by stage over gloo.
+What the exchange is, in every case:
 
 The reference has no distributed code.  The update couples particles only through
   (1) resampling  — children of rank g are drawn from the GLOBAL weighted set.
@@ -107,8 +117,12 @@ class ShardedFilter:
     def exchange_bytes(self):
         if self.native_updates > 0:
             st = self.shard.comm_stats()
-            self._exchange_bytes.update(kind="lists", list_bytes_received=st["list_bytes_received"], list_payload_bytes=st["list_payload_bytes"],
-                                        weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
+            if st["dense"]:      # whole shards' weights and records (no request step: records_received counts every particle of the others)
+                self._exchange_bytes.update(kind="dense", list_bytes_received=0, list_payload_bytes=0, weights_received=st["weights_received"],
+                                            requests_sent=0, records_received=st["records_received"], distinct_remote_parents=0)
+            else:
+                self._exchange_bytes.update(kind="lists", list_bytes_received=st["list_bytes_received"], list_payload_bytes=st["list_payload_bytes"],
+                                            weights_received=0, requests_sent=0, records_received=0, distinct_remote_parents=0)
         return self._exchange_bytes
 
     def _make_native_comm(self):
@@ -325,7 +339,9 @@ class ShardedFilter:
         gs = None
         # (1) exchange for resampling + the children
         if self.native:
-            pose = s.comm_update(action, obs)          # the whole update in one native call; None: no lists yet, nothing touched
+            # the whole update in one native call -- lists, or the dense exchange when there are none (first update) -- on the
+            # engine's stream.  (None: the communicator declined without touching anything; dist.py's own dense exchange then.)
+            pose = s.comm_update(action, obs)
             if pose is not None:
                 self.pose = pose
                 self.native_updates += 1

@@ -38,7 +38,7 @@ EXPORTS = [
     "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
     "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete",
-    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector",
+    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector", "mcl_comm_last_exchange",
 ]
 
 
@@ -550,7 +550,10 @@ class Engine:
     def comm_stats(self):
         r, p, w = C.c_uint64(), C.c_uint64(), C.c_int32()
         self._chk(self.lib.mcl_comm_stats(self._h, C.byref(r), C.byref(p), C.byref(w)), "mcl_comm_stats")
-        return dict(list_bytes_received=r.value, list_payload_bytes=p.value, host_waits=w.value)
+        d, wb, rb = C.c_int32(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.mcl_comm_last_exchange(self._h, C.byref(d), C.byref(wb), C.byref(rb)), "mcl_comm_last_exchange")
+        return dict(list_bytes_received=r.value, list_payload_bytes=p.value, host_waits=w.value, dense=bool(d.value),
+                    weights_received=wb.value, records_received=rb.value)
 
     def scan_weights(self, d_q, d_cdf, n, offset=0):
         self._chk(self.lib.mcl_scan_weights(self._h, C.c_void_p(d_q), C.c_void_p(d_cdf), C.c_int64(n),

@@ -153,28 +153,31 @@ def test_device_ordered_update_waits_once_and_equals_the_stage_by_stage_flow(tmp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("force_exact", [0, 2])
-def test_native_rccl_update_one_rank_equals_the_torch_collectives(tmp_path, force_exact):
+@pytest.mark.parametrize("variant", ["lists", "overflow", "dense"])
+def test_native_rccl_update_one_rank_equals_the_torch_collectives(tmp_path, variant):
     """The engine's own RCCL communicator (mcl_comm_*: the whole sharded update in one native call, the collectives on the
     engine's stream) -- what `--backend nccl` runs with one rank per device.  One GPU here, so ONE rank: the communicator, the
-    three collectives and the single host wait are real, the transfers are not (tests/test_gpu_group.py holds the two-device
-    test).  Against the same rank over torch's collectives (MCL_DIST_NATIVE=0); force_exact=2 takes the overflow redo."""
+    collectives and the single host wait are real, the transfers are not (tests/test_gpu_group.py holds the two-device
+    test).  Against the same rank over torch's collectives (MCL_DIST_NATIVE=0).  "overflow": debug_force_exact=2, the redo after
+    a fix-up list overflow; "dense": the exchange of an update without lists (whole weights and records) on every update."""
     dn, dt = tmp_path / "native", tmp_path / "torch"
     dn.mkdir(); dt.mkdir()
     n = 131072
     extra = dict(MCL_TEST_BEAM_STEP="3", MCL_TEST_NCCL="1")
-    if force_exact:
-        extra["MCL_TEST_FORCE_EXACT"] = str(force_exact)
-    nat = run_world("engine", dn, 1, n, 4, 0, False, **extra)
-    ref = run_world("engine", dt, 1, n, 4, 0, False, MCL_DIST_NATIVE="0", **extra)
+    if variant == "overflow":
+        extra["MCL_TEST_FORCE_EXACT"] = "2"
+    nat = run_world("engine", dn, 1, n, 4, 0, False, **extra, **(dict(MCL_COMM_NO_LISTS="1") if variant == "dense" else {}))
+    ref = run_world("engine", dt, 1, n, 4, 0, False, MCL_DIST_NATIVE="0", **extra, **(dict(MCL_DIST_NO_LISTS="1") if variant == "dense" else {}))
     assert int(nat[0]["native"]) == 1 and int(ref[0]["native"]) == 0
     for k in ("idx", "particles", "q", "poses"):
         assert np.array_equal(nat[0][k], ref[0][k]), k
-    assert list(nat[0]["kinds"]) == ["dense", "lists", "lists", "lists"]
-    if force_exact:
+    assert list(nat[0]["kinds"]) == (["dense"] * 4 if variant == "dense" else ["dense", "lists", "lists", "lists"])
+    if variant == "overflow":
         assert min(nat[0]["waits"][1:]) > 1                              # the redo ran
+    elif variant == "lists":
+        assert list(nat[0]["waits"]) == [2, 1, 1, 1]                     # (a dense update waits once more, for the weight total)
     else:
-        assert list(nat[0]["waits"][1:]) == [1, 1, 1]
+        assert list(nat[0]["waits"]) == [2, 2, 2, 2]
 
 
 @pytest.mark.gpu
