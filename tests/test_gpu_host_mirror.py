@@ -72,3 +72,35 @@ def test_host_mirror_native_philox_runs(tmp_path, spielberg):
     assert r["beams"] == 1081 and abs(r["sum_w"] - 1.0) < 1e-10 and r["wmax"] > 0
     assert all(np.isfinite(v) for pose in r["poses"] for v in pose)
     assert abs(r["poses"][-1][0]) < 1.0 and abs(r["poses"][-1][1]) < 1.0
+
+
+def test_one_rank_in_plain_cpp_through_the_engines_rccl_communicator(tmp_path, engine_mod, spielberg):
+    """host/comm_demo: one rank of the one-process-per-GPU host in C++ against the C ABI -- no Python, no torch in the process, so
+    the RCCL the engine finds (dlopen) is the ROCm installation's.  Rendezvous over a file, 4 x mcl_comm_update (the first one
+    without lists: the dense exchange).  Poses and particles equal a plain engine's mcl_update (same seed: Philox keyed by the
+    global index).  One GPU here, so one rank; with more GPUs the same binary is started once per rank
+    (comm_demo ... <n_ranks> <rank> <id_file>)."""
+    import __graft_entry__ as g
+    g.build()
+    scan = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"]
+    mp, sp = write_inputs(tmp_path, spielberg, scan)
+    n, step, k, seed = 131072, 3, 4, 77
+    dump = tmp_path / "particles.bin"
+    out = subprocess.check_output([os.path.join(ROOT, "host", "comm_demo"), mp, sp, str(n), str(step), str(k), str(seed), "1", "0",
+                                   str(tmp_path / "rccl_id")], timeout=300, env=dict(os.environ, MCL_DEMO_DUMP=str(dump)))
+    r = json.loads(out.decode().strip().splitlines()[-1])        # (RCCL may print its version banner first)
+    assert r["ranks"] == 1 and r["beams"] == 361 and r["last_exchange"] == "lists" and r["host_waits"] == 1
+    angle_min, angle_inc = np.float32(-3.0 * np.pi / 4.0), np.float32((3.0 * np.pi / 2.0) / 1080.0)
+    ang = (angle_min + np.arange(0, 1081, step, dtype=np.float32) * angle_inc).astype(np.float32)
+    e = engine_mod.Engine(max_particles=n, seed=seed)
+    e.set_map(spielberg.data, spielberg.resolution, spielberg.origin_x, spielberg.origin_y)
+    e.set_beam_angles(ang)
+    e.init_particles_pose((0.0, 0.0, 0.0), n)
+    obs = scan[::step].astype(np.float32)
+    for it in range(k):
+        e.update((0.05, 0.0, 0.01), obs)
+        np.testing.assert_allclose(r["poses"][it], e.expected_pose(), rtol=0, atol=1e-12)
+    p = e.get_particles()
+    assert r["p0"] == [p[0, 0], p[1, 0], p[2, 0]]
+    assert np.array_equal(np.fromfile(dump, np.float64).reshape(3, n), p)        # every particle, bit for bit
+    e.close()
