@@ -364,6 +364,7 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
 int mcl_comm_available(const char **why);
 int mcl_comm_unique_id(unsigned char id[128]);
 int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank);
+int mcl_comm_selftest(mcl_engine_t *h);   /* COLLECTIVE: the three collectives of an update on known data; MCL_OK or what failed */
 int mcl_comm_destroy(mcl_engine_t *h);
 int mcl_comm_set_lists(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals);
 int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, double pose_out[3]);

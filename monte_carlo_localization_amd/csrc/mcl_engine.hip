@@ -2855,6 +2855,44 @@ int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_rank
     return MCL_OK;
 }
 
+// The three collectives of an update on known data, before any particle depends on them: all-reduce MAX of the rank, all-reduce
+// SUM of ones, all-gather of one 64-byte chunk per rank.  COLLECTIVE.  A host that finds a rank failing here keeps its other
+// exchange (dist.py: torch's collectives) instead of learning it in the first update.
+int mcl_comm_selftest(mcl_engine_t *h)
+{
+    if (!h) return MCL_ERR_INVALID_ARG;
+    mcl_comm *c = h->comm;
+    if (!c) return fail(h, MCL_ERR_NOT_READY, "mcl_comm_create first");
+    RcclApi &api = rccl_api();
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int G = c->n_ranks;
+    unsigned char *d_buf = nullptr;
+    HIPCHK(h, hipMalloc(&d_buf, 64 * (size_t)(G + 1)));
+    unsigned char mine[64];
+    for (int i = 0; i < 64; ++i) mine[i] = (unsigned char)(c->rank * 7 + i);
+    double two[2] = {(double)c->rank, 1.0};
+    auto run = [&]() -> int {
+        HIPCHK(h, hipMemcpyAsync(d_buf, mine, 64, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(c->d_red, two, 16, hipMemcpyHostToDevice, h->stream));
+        NCCLCHK(h, api.AllReduce(c->d_red, c->d_red, 1, ncclDouble, ncclMax, c->comm, h->stream));
+        NCCLCHK(h, api.AllReduce(c->d_red + 1, c->d_red + 1, 1, ncclDouble, ncclSum, c->comm, h->stream));
+        NCCLCHK(h, api.AllGather(d_buf, d_buf + 64, 64, ncclChar, c->comm, h->stream));
+        std::vector<unsigned char> all(64 * (size_t)G);
+        HIPCHK(h, hipMemcpyAsync(c->h_red, c->d_red, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(all.data(), d_buf + 64, all.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (c->h_red[0] != (double)(G - 1) || c->h_red[1] != (double)G) return fail(h, MCL_ERR_HIP, "mcl_comm_selftest: an all-reduce returned a wrong value");
+        for (int r = 0; r < G; ++r)
+            for (int i = 0; i < 64; ++i)
+                if (all[(size_t)r * 64 + i] != (unsigned char)(r * 7 + i)) return fail(h, MCL_ERR_HIP, "mcl_comm_selftest: the all-gather returned wrong bytes");
+        return MCL_OK;
+    };
+    const int rc = run();
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_buf);
+    return rc;
+}
+
 int mcl_comm_destroy(mcl_engine_t *h)
 {
     if (!h) return MCL_ERR_INVALID_ARG;

@@ -138,19 +138,28 @@ class ShardedFilter:
         if self.rank == 0:
             uid.copy_(torch.from_numpy(np.frombuffer(self.shard.comm_unique_id(), dtype=np.uint8).copy()))
         dist.broadcast(uid, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+
+        def agreed(step):
+            """Run `step` here; True when it succeeded on EVERY rank (the next collective step is only entered then)."""
+            try:
+                step()
+                ok_here = 1
+            except Exception as ex:                    # noqa: BLE001 -- any failure here means "not on this rank"
+                print(f"[dist] rank {self.rank}: {ex}: torch collectives", file=sys.stderr)
+                ok_here = 0
+            flag.fill_(ok_here)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item()) == 1
+
+        made = agreed(lambda: self.shard.comm_create(uid.cpu().numpy().tobytes(), self.world, self.rank))
+        # the collectives of an update on known data, before a particle depends on them
+        if made and agreed(self.shard.comm_selftest):
+            return True
         try:
-            self.shard.comm_create(uid.cpu().numpy().tobytes(), self.world, self.rank)
-            made = 1
-        except Exception as ex:                        # noqa: BLE001 -- any failure here means "not on this rank"
-            print(f"[dist] rank {self.rank}: mcl_comm_create failed ({ex}): torch collectives", file=sys.stderr)
-            made = 0
-        flag.fill_(made)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) != 1:
-            if made:
-                self.shard.comm_destroy()
-            return False
-        return True
+            self.shard.comm_destroy()
+        except Exception:                              # noqa: BLE001
+            pass
+        return False
 
     def _all_reduce_small(self, values, op):
         """values (a short float64 sequence) -> their reduction over the ranks, as a numpy array."""

@@ -38,7 +38,7 @@ EXPORTS = [
     "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
     "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete",
-    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector", "mcl_comm_last_exchange",
+    "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector", "mcl_comm_last_exchange", "mcl_comm_selftest",
 ]
 
 
@@ -520,6 +520,10 @@ class Engine:
         buf = (C.c_ubyte * 128).from_buffer_copy(uid)
         self._chk(self.lib.mcl_comm_create(self._h, buf, C.c_int32(n_ranks), C.c_int32(rank)), "mcl_comm_create")
         self._comm_ranks = n_ranks
+
+    def comm_selftest(self):
+        """COLLECTIVE: the three collectives of an update on known data."""
+        self._chk(self.lib.mcl_comm_selftest(self._h), "mcl_comm_selftest")
 
     def comm_destroy(self):
         self._chk(self.lib.mcl_comm_destroy(self._h), "mcl_comm_destroy")
