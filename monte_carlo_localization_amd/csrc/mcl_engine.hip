@@ -201,6 +201,7 @@ struct mcl_engine {
     unsigned long long list_epoch = 0;  // counts the rewrites of the compact list (a gathered copy of an older one is stale)
     bool layout_valid = false, layout_pending = false;
     int64_t layout_n = 0;
+    bool layout_wanted = false;         // the resampling kernel left children to make the next layout of (layout_mark -> next_layout_launch)
     bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
     bool keys_done = false;             // ... and its resampling kernel wrote the (key, index) pairs
     bool env_no_stale_layout = false;   // MCL_NO_STALE_LAYOUT: every update makes its own layout first (rounds 1-3)
@@ -1677,14 +1678,25 @@ static void resample_ray_extras(mcl_engine *h, int64_t n, mcl::ResampleArgs &a)
 }
 
 // After the resampling kernel: the layout of THESE children, for the next update, on the second stream beside the sort and the ray stage.
+// (in two steps: the event right behind the resampling kernel, the launches once the ray stage has been submitted -- the
+//  ordering kernels of the main stream are on the critical path of a small update, these are not)
+static int layout_mark(mcl_engine *h, int64_t n)
+{
+    h->layout_wanted = false;
+    if (choose_ray_mode(h, n, false) < 4 || h->env_no_stale_layout) return MCL_OK;
+    HIPCHK(h, hipEventRecord(h->ev_children, h->stream));
+    h->layout_wanted = true;
+    return MCL_OK;
+}
+
 static int next_layout_launch(mcl_engine *h, int64_t n)
 {
-    if (choose_ray_mode(h, n, false) < 4 || h->env_no_stale_layout) return MCL_OK;
+    if (!h->layout_wanted) return MCL_OK;
+    h->layout_wanted = false;
     const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
     const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
     const int bstride = n >= (1 << 20) ? 16 : 1;
     const int play = h->env_no_bucket_cuts ? -1 : (choose_ray_mode(h, n, false) == 5 ? sweep_play(h) : 0);
-    HIPCHK(h, hipEventRecord(h->ev_children, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_children, 0));
     hipLaunchKernelGGL(mcl::k_bbox_init, dim3(1), dim3(64), 0, h->stream2, h->d_bbox_nx, play);
     hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0, h->stream2, h->d_pc, n,
@@ -1745,19 +1757,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     const bool tiny = resample_and_move && h->cfg.graph_mode != 1 && h->graph_warm && n <= mcl::kTinyTailMax && !keep &&
                       choose_ray_mode(h, n, false) == 2 && h->cfg.weight_mode == MCL_WEIGHT_LOG && h->cfg.resample_neff_permille == 0;
     if (!tiny) HIPCHK(h, hipEventRecord(h->ev[EV_START], h->stream));
-    // The tables of this update's scan (table rows of the observed ranges, Lt, Ltd) depend on nothing the resampling and ordering
-    // kernels produce: with a windowed ray kernel they are built on a second stream beside those, and the ray stage waits for
-    // them (a copy and two or three small launches off the critical path of an update: ~15 us).
     bool obs_early = false;
-    if (resample_and_move && !tiny && !h->env_no_obs_overlap && choose_ray_mode(h, n, false) >= 3) {
-        std::swap(h->stream, h->stream2);
-        const int rc_obs = prepare_observation(h, obs, obs_stride);
-        hipError_t ee = rc_obs ? hipSuccess : hipEventRecord(h->ev_obs, h->stream);
-        std::swap(h->stream, h->stream2);
-        if (rc_obs) return rc_obs;
-        HIPCHK(h, ee);
-        obs_early = true;
-    }
     if (resample_and_move) {
         const int c = h->cur, nx = c ^ 1;
         mcl::ResampleArgs a{};
@@ -1812,7 +1812,20 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         if (!a.tile_excl && a.do_resample && n <= mcl::kTinyTailMax) { a.cdf_lds_entries = (int)n; cdf_lds = (size_t)n * sizeof(uint64_t); }
         hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, a);
         HIPCHK(h, hipGetLastError());
-        if (a.pc_out) { const int rc_l = next_layout_launch(h, n); if (rc_l) return rc_l; }
+        if (a.pc_out) { const int rc_l = layout_mark(h, n); if (rc_l) return rc_l; }
+        // The tables of this update's scan (table rows of the observed ranges, Lt, Ltd) depend on nothing the resampling and ordering
+        // kernels produce: with a windowed ray kernel they are built on a second stream beside those, and the ray stage waits for
+        // them (a copy and two or three small launches off the critical path of an update: ~15 us).  Enqueued AFTER the resampling
+        // kernel: that one is on the critical path, and a small update is bound by the order the host submits in.
+        if (!tiny && !h->env_no_obs_overlap && choose_ray_mode(h, n, false) >= 3) {
+            std::swap(h->stream, h->stream2);
+            const int rc_obs = prepare_observation(h, obs, obs_stride);
+            hipError_t ee = rc_obs ? hipSuccess : hipEventRecord(h->ev_obs, h->stream);
+            std::swap(h->stream, h->stream2);
+            if (rc_obs) return rc_obs;
+            HIPCHK(h, ee);
+            obs_early = true;
+        }
         h->cur = nx;                       // cpp:689 as a pointer swap
         h->resampled_last = !keep;
         h->pack_valid[nx] = a.cpack != nullptr;
@@ -1921,6 +1934,8 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     }
     HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
+    if (rc) return rc;
+    rc = next_layout_launch(h, n);          // (second stream; behind the ray stage in submission order, beside it on the device)
     if (rc) return rc;
     if (keep) {
         hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
@@ -2364,7 +2379,7 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     if (!index_only) resample_ray_extras(h, n, a);
     hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
-    if (a.pc_out) { const int rc_l = next_layout_launch(h, n); if (rc_l) return rc_l; }
+    if (a.pc_out) { const int rc_l = layout_mark(h, n); if (rc_l) return rc_l; }
     if (index_only) {
         HIPCHK(h, hipMemcpyAsync(src.idx_only_out, h->d_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
         h->have_idx = true;
@@ -2519,6 +2534,8 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     }
     if (!h->pc_ready) { h->layout_stale_used = false; h->keys_done = false; }     // no staged resampling before this call: nothing prepared
     rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, force_skip);
+    if (rc) return rc;
+    rc = next_layout_launch(h, n);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     if (!h->max_partials_ready)
