@@ -10,6 +10,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -201,6 +202,11 @@ struct mcl_engine {
     unsigned long long list_epoch = 0;  // counts the rewrites of the compact list (a gathered copy of an older one is stale)
     bool layout_valid = false, layout_pending = false;
     int64_t layout_n = 0;
+    // Stage events BOUND TO DISPATCHES: the stop event of hipExtLaunchKernelGGL costs nothing, a hipEventRecord between two kernels
+    // of a stream ~3 us of pipeline (tools/ubench/event_cost.hip; elapsed times across different launches are valid).  Set by the
+    // launch that bound the event, cleared by the code that would otherwise record it.
+    bool ev_resample_bound = false, ev_rays_bound = false, ev_sensor_bound = false, ev_query_skipped = false;
+    bool bind_sensor_event = false;     // the next scan of the engine's own weights binds EV_SENSOR to its last kernel
     bool layout_wanted = false;         // the resampling kernel left children to make the next layout of (layout_mark -> next_layout_launch)
     bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
     bool keys_done = false;             // ... and its resampling kernel wrote the (key, index) pairs
@@ -490,7 +496,13 @@ int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n,
         HIPCHK(h, hipMalloc(&h->d_leaders, nlead * 8));
         h->leaders_capacity = nlead;
     }
-    hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf, h->d_leaders, co);
+    if (h->bind_sensor_event && own && !h->capturing) {          // the update's last kernel: EV_SENSOR is its stop event
+        hipExtLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, nullptr, h->ev[EV_SENSOR], 0, d_q, n, h->d_blocktot, d_cdf,
+                              h->d_leaders, co);
+        h->ev_sensor_bound = true; h->bind_sensor_event = false;
+    } else {
+        hipLaunchKernelGGL(mcl::k_scan_final, dim3(nb), dim3(mcl::kScanThreads), 0, h->stream, d_q, n, h->d_blocktot, d_cdf, h->d_leaders, co);
+    }
     HIPCHK(h, hipGetLastError());
     h->blocktot_for = d_cdf; h->blocktot_n = n;
     if (d_cdf == h->d_cdf) { h->compact_n = -1; h->compact_pending = own; h->list_epoch++; }
@@ -580,8 +592,9 @@ int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
     }
     if (!h->d_nitems) HIPCHK(h, hipMalloc(&h->d_nitems, sizeof(int)));
     const int play = sweep_play(h);                                     // cells a window leaves for the particles of an item
-    hipLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), mcl::kPlanLds, h->stream, h->d_unit_sums, h->d_nunits, ngroups, nwg, (double)(play / 2 - 1),
-                       h->d_items, h->d_centres, h->d_nitems);
+    // (EV_K0 = the stop event of the kernel before the ray kernel, EV_K1 = the ray kernel's own: its duration, dispatch included, at no cost)
+    hipExtLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), mcl::kPlanLds, h->stream, nullptr, h->ev[EV_K0], 0, h->d_unit_sums, h->d_nunits, ngroups, nwg,
+                          (double)(play / 2 - 1), h->d_items, h->d_centres, h->d_nitems);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -903,23 +916,23 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // k_rays_far is bound by global-memory latency: 4 workgroups per CU worth of blocks (2 resident at a time)
         dim3 gfar((unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)h->num_cu, (n + 15) / 16)));
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU (2 .. 16 per segment: no difference, round 4)
-        HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
+        if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            if (sweep_glob) hipLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, a);
-            else if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, a);
+            if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
-            HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+            if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             if (sweep && a.far_windowed) { const int rcw = launch_far_windowed(h, a, n, true); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
         } else {
-            if (sweep_glob) hipLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, a);
-            else if (sweep) hipLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, a);
+            if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
-            HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
+            if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             if (sweep && a.far_windowed) { const int rcw = launch_far_windowed(h, a, n, false); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_fix<false>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
@@ -928,8 +941,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (sweep) {
             // the slot accumulators (k_rays_sweep's per-wedge sums + what the far / fix / exact kernels added) -> d_logw in particle
             // order, the per-workgroup maxima, and the overflow flag of the fix-up lists (k_fix_overflow's job for the other kernels)
-            hipLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, n, h->d_perm, h->d_logw_acc, h->d_logw, h->d_maxpart,
-                               h->d_fix_count, nseg, segcap, h->d_fix_over);
+            hipExtLaunchKernelGGL(mcl::k_combine_logw, dim3(mcl::kRedBlocks), dim3(256), 0, h->stream, nullptr, h->ev[EV_RAYS], 0, n, h->d_perm, h->d_logw_acc,
+                                  h->d_logw, h->d_maxpart, h->d_fix_count, nseg, segcap, h->d_fix_over);
+            h->ev_rays_bound = true;               // (the stage's last kernel: EV_RAYS is its stop event)
             h->max_partials_ready = true;
         } else {
             hipLaunchKernelGGL(mcl::k_fix_overflow, dim3(1), dim3(256), 0, h->stream, h->d_fix_count, nseg, segcap, h->d_fix_over);
@@ -1686,6 +1700,8 @@ static int layout_mark(mcl_engine *h, int64_t n)
     if (choose_ray_mode(h, n, false) < 4 || h->env_no_stale_layout) return MCL_OK;
     HIPCHK(h, hipEventRecord(h->ev_children, h->stream));
     h->layout_wanted = true;
+    // (launched right here the layout kernels share the device with the sort: measured 0.04-0.06 ms per update slower at 1M and
+    //  4M particles than behind the ray stage, where they run in the shadow of the persistent kernel's tail)
     return MCL_OK;
 }
 
@@ -1810,7 +1826,13 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         resample_ray_extras(h, n, a);
         size_t cdf_lds = 0;
         if (!a.tile_excl && a.do_resample && n <= mcl::kTinyTailMax) { a.cdf_lds_entries = (int)n; cdf_lds = (size_t)n * sizeof(uint64_t); }
-        hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, a);
+        h->ev_resample_bound = false;
+        if (!tiny && !h->capturing) {
+            hipExtLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, nullptr, h->ev[EV_RESAMPLE], 0, a);
+            h->ev_resample_bound = true;
+        } else {
+            hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), cdf_lds, h->stream, a);
+        }
         HIPCHK(h, hipGetLastError());
         if (a.pc_out) { const int rc_l = layout_mark(h, n); if (rc_l) return rc_l; }
         // The tables of this update's scan (table rows of the observed ranges, Lt, Ltd) depend on nothing the resampling and ordering
@@ -1864,7 +1886,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         h->ray_ms_is_graph_tail = true;
         return MCL_OK;
     }
-    HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
+    if (!(resample_and_move && h->ev_resample_bound)) HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
     // Small updates are launch-bound (about twenty launches for ~0.06 ms of kernels): once a regular update has run with
     // these sizes on the k_rays_skip path, everything after the resampling kernel is replayed as one hipGraph per
     // particle buffer (observation upload, table build, rays, weights, CDF, result read-back: all arguments are fixed).
@@ -1932,7 +1954,10 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         rc = prepare_observation(h, obs, obs_stride);
         if (rc) return rc;
     }
-    HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
+    // (the tables were made beside the ordering: no query-preparation stage on this stream, nothing to time)
+    h->ev_query_skipped = obs_early;
+    if (!obs_early) HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
+    h->ev_rays_bound = false;
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
     if (rc) return rc;
     rc = next_layout_launch(h, n);          // (second stream; behind the ray stage in submission order, beside it on the device)
@@ -1941,10 +1966,12 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
         hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
         h->max_partials_ready = false;
     }
-    HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    if (keep || !h->ev_rays_bound) HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    h->bind_sensor_event = true; h->ev_sensor_bound = false;
     rc = weights_and_cdf(h);
+    h->bind_sensor_event = false;
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
+    if (!h->ev_sensor_bound) HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
     rc = fetch_scalars(h);                 // one D2H copy (scalars, counters, overflow flag); synchronises the stream
     if (rc) return rc;
     if (h->last_quad && h->h_fix_count != 0) {
@@ -1970,8 +1997,8 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     if (resample_and_move) h->update_idx++;
     h->timings[0] = elapsed(h->ev[EV_START], h->ev[EV_RESAMPLE]);
     h->timings[1] = 0.0;                   // motion is fused into the resample/gather kernel
-    h->timings[2] = elapsed(h->ev[EV_RESAMPLE], h->ev[EV_QUERY]);
-    h->timings[3] = elapsed(h->ev[EV_QUERY], h->ev[EV_RAYS]);
+    h->timings[2] = h->ev_query_skipped ? 0.0 : elapsed(h->ev[EV_RESAMPLE], h->ev[EV_QUERY]);
+    h->timings[3] = elapsed(h->ev[h->ev_query_skipped ? EV_RESAMPLE : EV_QUERY], h->ev[EV_RAYS]);
     h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
     h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     h->ray_ms = elapsed(h->ev[EV_K0], h->ev[EV_K1]);
@@ -2377,7 +2404,8 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     // as in mcl_update: the ray stage's per-particle constants, its zeroed scratch and (by the previous update's layout) the sort
     // keys come out of this kernel; the layout of these children is made on the second stream for the next update
     if (!index_only) resample_ray_extras(h, n, a);
-    hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+    if (!index_only) hipExtLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, nullptr, h->ev[EV_RESAMPLE], 0, a);
+    else hipLaunchKernelGGL(mcl::k_resample_motion, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
     if (a.pc_out) { const int rc_l = layout_mark(h, n); if (rc_l) return rc_l; }
     if (index_only) {
@@ -2390,7 +2418,6 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     h->compact_used = src.gcdf != nullptr;
     h->have_idx = true;
     h->have_logw = false;
-    HIPCHK(h, hipEventRecord(h->ev[EV_RESAMPLE], h->stream));
     h->update_idx++;
     return MCL_OK;
 }
@@ -2533,11 +2560,12 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
         HIPCHK(h, hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), h->stream));
     }
     if (!h->pc_ready) { h->layout_stale_used = false; h->keys_done = false; }     // no staged resampling before this call: nothing prepared
+    h->ev_rays_bound = false;
     rc = launch_rays(h, h->d_x[c], h->d_y[c], h->d_th[c], n, force_skip);
     if (rc) return rc;
     rc = next_layout_launch(h, n);
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    if (!h->ev_rays_bound) HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     if (!h->max_partials_ready)
         hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_maxpart);
     hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_maxpart, mcl::kRedBlocks, h->d_scalars, d_max_out);
@@ -2622,9 +2650,11 @@ static int stage_weights_launch(mcl_engine_t *h, double global_max_logw, const d
     if (rc) return rc;
     h->carry_pending = false;
     // the shard's own CDF follows its new weights: mcl_sample_particles (visualize) and a later plain mcl_update search it
+    h->bind_sensor_event = true; h->ev_sensor_bound = false;
     rc = scan_weights(h, h->d_q, h->d_cdf, h->N, 0, nullptr);
+    h->bind_sensor_event = false;
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
+    if (!h->ev_sensor_bound) HIPCHK(h, hipEventRecord(h->ev[EV_SENSOR], h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, kResultWords * 8, hipMemcpyDeviceToHost, h->stream));
     return MCL_OK;
 }
