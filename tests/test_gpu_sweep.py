@@ -461,3 +461,26 @@ def test_far_apart_clusters_need_no_far_pass(orc, engine_mod, spielberg, spielbe
     assert c["off_window_particles"] == 0, c
     pick = rng.choice(n, 4000, replace=False)
     assert np.array_equal(got[pick], oracle_logw(orc, spielberg_oracle, p[:, pick], ang, obs))
+
+
+def test_stage_timings_of_the_sweep_path_add_up(orc, engine_mod, spielberg):
+    """The stage events of this path are bound to dispatches (stop events of hipExtLaunchKernelGGL: the resampling kernel, the
+    kernel before the ray kernel, the ray kernel, k_combine_logw, k_scan_final) instead of recorded between kernels.  The six
+    figures the host reads (hpp timing_stats_) must still be what they were: non-negative, the stages within the total, the ray
+    kernel's own time within the ray stage."""
+    ang = orc.beam_angles(angle_step=1)
+    obs = scan1081()
+    n = 131072
+    e = make_engine(engine_mod, spielberg, ang, n, seed=3)
+    e.set_particles(tracking_cloud(np.random.default_rng(1), n), np.full(n, 1.0 / n))
+    for _ in range(3):
+        e.update((0.05, 0.0, 0.01), obs)
+        t = e.stage_timings()
+        k = e.ray_kernel_ms()
+        assert e.ray_kernel_name() == "k_rays_sweep"
+        assert (t >= 0).all() and t[5] > 0
+        assert 0 < k <= t[3] * 1.001                       # the ray kernel inside the ray stage (ordering + rays + fix-up)
+        assert t[0] > 0 and t[4] > 0
+        assert t[0] + t[2] + t[3] + t[4] <= t[5] * 1.02     # the device stages within the host's wall clock of the call
+        assert t[0] + t[2] + t[3] + t[4] >= t[5] * 0.5
+    e.close()
