@@ -20,7 +20,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o f -- py
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/pmc_write" -o w -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_write.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$R/$OUT/pmc_sq" -o s -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$R/$OUT/pmc_sq2" -o s2 -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_sq2.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT/prof_256k" -o t -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check --particles-per-gpu 262144 > "$R/$OUT/prof_256k.log" 2>&1
 cd "$R"
+# one steady-state update as a timeline (every launch, its start, duration and the idle time before it): 4M and 262 144 particles
+python3 tools/update_timeline.py "$OUT/prof/t_kernel_trace.csv" k_resample_motion "$PROF/${TAG}_timeline_4m.md" > /dev/null
+python3 tools/update_timeline.py "$OUT/prof_256k/t_kernel_trace.csv" k_resample_motion "$PROF/${TAG}_timeline_256k.md" > /dev/null
 # keep only the rows of the ray-stage kernels in the committed PMC files (the full CSVs are tens of MB)
 for p in fetch:f write:w sq:s sq2:s2; do
   d=${p%%:*}; o=${p##*:}
