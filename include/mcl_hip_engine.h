@@ -323,14 +323,21 @@ int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5]);
  * One update of a sharded set, lists known from the previous update's sums:
  *   mcl_export_compact_async -> [s waits] all-gather of the chunks on s -> [engine waits] mcl_stage_resample_compact_async ->
  *   mcl_stage_rays_async (local max log-weight -> *d_local_max) -> [s waits] all-reduce MAX on s -> [engine waits]
- *   mcl_stage_weights_async (reads *d_global_max; writes this shard's part of the SUM vector, 5 + 3 * n_shards + 1 doubles:
+ *   mcl_stage_weights_async (reads *d_global_max; writes this shard's part of the SUM vector, 5 + 3 * n_shards + 2 doubles:
  *   [sum w, sum w x, sum w y, sum w sin, sum w cos | per shard: list length + 1 (0: no list), low / high 32 bits of its
- *   fixed-point weight total | 1.0 if this shard's ray stage overflowed its fix-up lists], the other shards' slots zeroed)
+ *   fixed-point weight total | 1.0 if this shard's ray stage overflowed its fix-up lists | sum w^2], the other shards' slots zeroed)
  *   -> [s waits] all-reduce SUM on s, copy to the host, THE host wait -> mcl_stage_complete(global sums, &redo): waits for the
  *   engine's stream (already drained), takes over the read-backs the synchronous calls do one by one.  *redo = 1 (the last
- *   element of the summed vector is non-zero on every rank then): this shard's log-weights are incomplete -- run
+ *   but one element of the summed vector is non-zero on every rank then): this shard's log-weights are incomplete -- run
  *   mcl_stage_rays, the MAX exchange, mcl_stage_weights, the SUM exchange and mcl_stage_finish once more (all ranks).
  * Results are those of the synchronous calls bit for bit (same kernels, same order). */
+/* Adaptive resampling (cfg.resample_neff_permille = r > 0) in a sharded set.  The decision is the host's, from the sums of the
+ * PREVIOUS update over the whole set (the same numbers on every shard): keep when (sum w)^2 >= r / 1000 * N_total * sum w^2.
+ * mcl_stage_keep then replaces the exchange and the resampling call of this update: every particle is its own parent (reported
+ * as child_first + its index), the motion model runs with the same random streams, and the ray stage adds the previous
+ * update's log-weights minus their global maximum, as mcl_update does.  Launch only.  MCL_ERR_NOT_READY before the first staged
+ * update of a particle set.  (mcl_comm_update and mcl_group_update take the decision themselves.) */
+int mcl_stage_keep(mcl_engine_t *h, int64_t child_first, int64_t n_children_total, const double action[3]);
 int mcl_stream_wait_external(mcl_engine_t *h, void *stream);
 int mcl_external_wait_stream(mcl_engine_t *h, void *stream);
 int mcl_export_compact_async(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries);
@@ -357,10 +364,11 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
  *     stream: all-gather of every shard's fixed-point weights and packed records (8 + 32 B per particle), one global CDF, the
  *     same draw (one more host wait, for the weight total).  Every rank decides from the same numbers, so every rank issues the
  *     same collectives.  The global sums are installed as mcl_stage_finish does; mcl_comm_get_vector returns the summed vector
- *     (5 + 3 * n_ranks + 1 doubles) of the last update.  mcl_comm_set_lists hands over list lengths (-1: none) and weight totals
+ *     (5 + 3 * n_ranks + 2 doubles) of the last update.  mcl_comm_set_lists hands over list lengths (-1: none) and weight totals
  *     found by other means (a host that ran an update through the stage calls);
  *   mcl_comm_stats: bytes the last LIST exchange delivered to this rank (padded chunks) / carried (entries), host waits of the
- *     last update; mcl_comm_last_exchange: whether the last update took the dense exchange, and the bytes it received. */
+ *     last update; mcl_comm_last_exchange: *dense = 0 the last update exchanged lists, 1 it took the dense exchange (with the bytes
+ *     received), 2 it exchanged nothing (adaptive resampling kept the set). */
 int mcl_comm_available(const char **why);
 int mcl_comm_unique_id(unsigned char id[128]);
 int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank);

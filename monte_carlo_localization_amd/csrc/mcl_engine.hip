@@ -198,6 +198,7 @@ struct mcl_engine {
     hipEvent_t ev_children = nullptr, ev_layout = nullptr;
     hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;   // ordering against a caller's stream (mcl_stream_wait_external / mcl_external_wait_stream)
     bool stage_async_rays = false, stage_async_weights = false;
+    bool stage_kept = false;            // the staged flow's last children are the previous particles themselves (mcl_stage_keep)
     struct mcl_comm *comm = nullptr;    // RCCL communicator of a sharded set (mcl_comm_create), or null
     unsigned long long list_epoch = 0;  // counts the rewrites of the compact list (a gathered copy of an older one is stale)
     bool layout_valid = false, layout_pending = false;
@@ -1527,6 +1528,7 @@ static int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     comm_forget(h->comm);                   // a sharded set: the other shards' lists are unknown again
+    h->stage_kept = false;
     return MCL_OK;
 }
 
@@ -1557,6 +1559,7 @@ static int finish_init(mcl_engine *h, int64_t n, int64_t n_total)
     h->pack_valid[0] = h->pack_valid[1] = false;
     h->have_idx = h->have_steps = h->have_logw = false;
     comm_forget(h->comm);                   // a sharded set: the other shards' lists are unknown again
+    h->stage_kept = false;
     h->init_idx++;
     return MCL_OK;
 }
@@ -2345,6 +2348,7 @@ struct ParentSource {
     const uint64_t *gcdf = nullptr, *gtop = nullptr;                // their merged CDF (k_compact_merge)
     const int32_t *idx_in = nullptr;                                // parents decided by an earlier index-only pass (into `records`)
     int32_t *idx_only_out = nullptr;                                // index-only pass: parents go here, nothing else happens
+    bool keep = false;                                              // adaptive resampling kept the set: every particle is its own parent (motion only)
 };
 
 // Launches the staged resample (+ motion) on the engine's stream; no synchronisation.  An index-only pass leaves the
@@ -2355,11 +2359,11 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!ready(h, true)) return fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first");
     const bool have_parents = src.records || src.n_per_rank > 0 || (src.px && src.py && src.pth) || src.idx_only_out || src.gcdf;
-    if (!have_parents || (!d_cdf && !src.idx_in && !src.gcdf) || (!action && !src.idx_only_out) || n_parents <= 0 || n_parents >= MCL_MAX_TOTAL_PARTICLES ||
-        n_children_total >= MCL_MAX_TOTAL_PARTICLES)
+    if (!have_parents || (!d_cdf && !src.idx_in && !src.gcdf && !src.keep) || (!action && !src.idx_only_out) || n_parents <= 0 ||
+        n_parents >= MCL_MAX_TOTAL_PARTICLES || n_children_total >= MCL_MAX_TOTAL_PARTICLES)
         return fail(h, MCL_ERR_INVALID_ARG, "bad stage_resample arguments (totals must stay below 2^27)");
-    if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
-        return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
+    if (h->cfg.weight_mode != MCL_WEIGHT_LOG)
+        return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t n = h->N;
     const bool index_only = src.idx_only_out != nullptr;
@@ -2399,7 +2403,8 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     }
     if (action) motion_scalars(action, a.dt, a.v, a.w);
     a.disp_x = h->cfg.motion_dispersion_x; a.disp_y = h->cfg.motion_dispersion_y; a.disp_th = h->cfg.motion_dispersion_theta;
-    a.do_resample = 1; a.do_motion = 1;
+    a.do_resample = src.keep ? 0 : 1; a.do_motion = 1;
+    a.idx_out_base = src.keep ? child_first : 0;
     h->layout_stale_used = false; h->keys_done = false; h->pc_ready = false;
     // as in mcl_update: the ray stage's per-particle constants, its zeroed scratch and (by the previous update's layout) the sort
     // keys come out of this kernel; the layout of these children is made on the second stream for the next update
@@ -2418,6 +2423,8 @@ static int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const
     h->compact_used = src.gcdf != nullptr;
     h->have_idx = true;
     h->have_logw = false;
+    h->resampled_last = !src.keep;
+    h->stage_kept = src.keep;              // mcl_stage_rays adds the previous update's log-weights (minus their maximum)
     h->update_idx++;
     return MCL_OK;
 }
@@ -2565,7 +2572,11 @@ static int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams,
     if (rc) return rc;
     rc = next_layout_launch(h, n);
     if (rc) return rc;
-    if (!h->ev_rays_bound) HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    if (h->stage_kept) {
+        hipLaunchKernelGGL(mcl::k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_logw, h->d_carry[h->carry_idx], n);
+        h->max_partials_ready = false;
+        HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
+    } else if (!h->ev_rays_bound) HIPCHK(h, hipEventRecord(h->ev[EV_RAYS], h->stream));
     if (!h->max_partials_ready)
         hipLaunchKernelGGL(mcl::k_reduce_max, dim3(mcl::kRedBlocks), dim3(mcl::kRedThreads), 0, h->stream, h->d_logw, n, h->d_maxpart);
     hipLaunchKernelGGL(mcl::k_final_max, dim3(1), dim3(mcl::kRedThreads), 0, h->stream, h->d_maxpart, mcl::kRedBlocks, h->d_scalars, d_max_out);
@@ -2636,8 +2647,8 @@ static int stage_weights_launch(mcl_engine_t *h, double global_max_logw, const d
 {
     if (!h) return MCL_ERR_INVALID_ARG;
     if (!h->have_logw && !d_global_max) return MCL_ERR_NOT_READY;
-    if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
-        return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG and resample_neff_permille 0");
+    if (h->cfg.weight_mode != MCL_WEIGHT_LOG)
+        return fail(h, MCL_ERR_UNSUPPORTED, "the staged (sharded) flow needs weight_mode LOG");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (d_global_max) {
         hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, h->stream, d_global_max, h->d_scalars);
@@ -2648,7 +2659,8 @@ static int stage_weights_launch(mcl_engine_t *h, double global_max_logw, const d
     }
     int rc = weight_stats(h, true, h->d_scalars, true);        // (the scan below finishes the sums)
     if (rc) return rc;
-    h->carry_pending = false;
+    // (adaptive resampling: the carry this wrote -- logw minus the GLOBAL maximum -- becomes current in mcl_stage_finish, once the
+    //  host knows that the update is not redone from the ray stage on)
     // the shard's own CDF follows its new weights: mcl_sample_particles (visualize) and a later plain mcl_update search it
     h->bind_sensor_event = true; h->ev_sensor_bound = false;
     rc = scan_weights(h, h->d_q, h->d_cdf, h->N, 0, nullptr);
@@ -2675,11 +2687,36 @@ int mcl_stage_weights(mcl_engine_t *h, double global_max_logw)
     return stage_weights_finish(h);
 }
 
+// end of a staged update: the carry its weights stage wrote becomes the current one
+static void stage_commit_carry(mcl_engine_t *h)
+{
+    if (h->carry_pending) { h->carry_idx ^= 1; h->carry_valid = true; h->carry_pending = false; }
+    h->stage_kept = false;
+}
+
 int mcl_stage_finish(mcl_engine_t *h, const double global_sums[5])
 {
     if (!h || !global_sums) return MCL_ERR_INVALID_ARG;
     for (int i = 0; i < 5; ++i) h->global_sums[i] = global_sums[i];
+    stage_commit_carry(h);
     return MCL_OK;
+}
+
+// Adaptive resampling in a sharded set (E9).  The DECISION is the host's: keep the set when (sum w)^2 >= r / 1000 * N * sum w^2 over
+// the WHOLE set (the sums of the previous update: five in the exchanged vector, sum w^2 at its end; r = resample_neff_permille),
+// the same numbers on every shard.  mcl_stage_keep then takes the place of the exchange and the resampling: every particle is its
+// own parent (no collective at all), the motion model is applied with the same random streams, and mcl_stage_rays adds the
+// previous update's log-weights minus their global maximum, as mcl_update does.  Launch only (no wait).
+int mcl_stage_keep(mcl_engine_t *h, int64_t child_first, int64_t n_children_total, const double action[3])
+{
+    if (!h || !action) return MCL_ERR_INVALID_ARG;
+    if (h->cfg.resample_neff_permille <= 0) return fail(h, MCL_ERR_UNSUPPORTED, "mcl_stage_keep needs resample_neff_permille > 0");
+    if (!h->carry_valid) return fail(h, MCL_ERR_NOT_READY, "no log-weights of a previous update to carry");
+    ParentSource src;
+    const int c = h->cur;
+    src.px = h->d_x[c]; src.py = h->d_y[c]; src.pth = h->d_th[c];
+    src.keep = true;
+    return stage_resample_launch(h, src, nullptr, h->N, 0, child_first, n_children_total, action);
 }
 
 // ---- the staged flow ordered on the device: nothing below waits for the stream except mcl_stage_complete ----------------
@@ -2756,6 +2793,7 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
     // self-contained kernel) and the two exchanges after it; the children are untouched
     *redo = (h->last_quad && h->h_fix_count != 0) ? 1 : 0;
     for (int i = 0; i < 5; ++i) h->global_sums[i] = global_sums[i];
+    // (the carry of adaptive resampling is committed by mcl_stage_finish, which the host calls once the update stands)
     return MCL_OK;
 }
 
@@ -2818,13 +2856,14 @@ struct mcl_comm {
     uint64_t *d_qall = nullptr, *d_cdfall = nullptr;
     double4 *d_recall = nullptr;
     size_t dense_capacity = 0;                                           // particles (all shards) the three arrays hold
-    bool last_dense = false;
+    bool last_dense = false, last_kept = false;
+    bool vec_valid = false;                                              // vec holds the sums of an update of the current particle set
     uint64_t dense_weights_bytes = 0, dense_records_bytes = 0;
     // what the shards' lists look like (the previous update's summed vector, or mcl_comm_set_lists after a dense update)
     bool lists_known = false;
     int64_t counts[mcl::kMaxShards] = {};
     uint64_t totals[mcl::kMaxShards] = {};
-    double vec[5 + 3 * mcl::kMaxShards + 1] = {};                        // the last summed vector
+    double vec[5 + 3 * mcl::kMaxShards + 2] = {};                        // the last summed vector
     // the lists of the NEXT update, gathered right after this update's sums (beside whatever the host does between updates)
     bool gathered = false;
     unsigned long long gathered_epoch = 0;
@@ -2837,6 +2876,7 @@ static void comm_forget(mcl_comm *c)
     if (!c) return;
     c->lists_known = false;
     c->gathered = false;
+    c->vec_valid = false;
 }
 
 static void comm_free(mcl_comm *c)
@@ -2883,8 +2923,8 @@ int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_rank
     if (!h || !id || n_ranks <= 0 || n_ranks > mcl::kMaxShards || rank < 0 || rank >= n_ranks) return MCL_ERR_INVALID_ARG;
     RcclApi &api = rccl_api();
     if (!api.lib) return fail(h, MCL_ERR_UNSUPPORTED, api.why);
-    if (h->cfg.weight_mode != MCL_WEIGHT_LOG || h->cfg.resample_neff_permille != 0)
-        return fail(h, MCL_ERR_UNSUPPORTED, "a sharded set needs weight_mode LOG and resample_neff_permille 0");
+    if (h->cfg.weight_mode != MCL_WEIGHT_LOG)
+        return fail(h, MCL_ERR_UNSUPPORTED, "a sharded set needs weight_mode LOG");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->comm) { comm_free(h->comm); h->comm = nullptr; }
     mcl_comm *c = new mcl_comm();
@@ -2893,7 +2933,7 @@ int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_rank
     std::memcpy(&u, id, 128);
     const ncclResult_t r = api.CommInitRank(&c->comm, n_ranks, u, rank);          // collective: every rank is in this call
     if (r != ncclSuccess) { c->comm = nullptr; comm_free(c); return fail(h, MCL_ERR_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)); }
-    const size_t words = 1 + 5 + 3 * (size_t)n_ranks + 1;
+    const size_t words = 1 + 5 + 3 * (size_t)n_ranks + 2;
     if (hipMalloc(&c->d_red, words * 8) != hipSuccess || hipHostMalloc(&c->h_red, words * 8) != hipSuccess) {
         comm_free(c);
         return fail(h, MCL_ERR_HIP, "mcl_comm_create: allocation failed");
@@ -2957,7 +2997,7 @@ static int comm_rays_to_sums(mcl_engine_t *h, const float *obs, int32_t n_beams,
 {
     mcl_comm *c = h->comm;
     RcclApi &api = rccl_api();
-    const size_t k = 5 + 3 * (size_t)c->n_ranks + 1;
+    const size_t k = 5 + 3 * (size_t)c->n_ranks + 2;
     int rc = stage_rays_launch(h, obs, n_beams, false, sync_rays ? nullptr : c->d_red);
     if (rc) return rc;
     if (sync_rays) {                      // after an overflow: wait, let the synchronous stage fall back to the self-contained kernel
@@ -3108,10 +3148,22 @@ int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, i
         weight += counts[r] > 0 ? totals[r] : 0ull;
     }
     lists = lists && weight != 0;
-    if (lists && counts[c->rank] != h->compact_n)
-        return fail(h, MCL_ERR_NOT_READY, "this engine's list is not the one the last exchange described (state changed on one rank only?)");
     int rc;
-    if (lists) {
+    // Adaptive resampling (E9): the set is kept when the effective sample size of the WHOLE set (the previous update's summed
+    // vector: every rank has the same numbers) is at least r / 1000 of it -- no exchange at all then
+    bool keep = false;
+    if (h->cfg.resample_neff_permille > 0 && c->vec_valid && h->carry_valid) {
+        const double sw = c->vec[0], sww = c->vec[5 + 3 * G + 1];
+        keep = sww > 0.0 && sw * sw >= ((double)h->cfg.resample_neff_permille / 1000.0) * (double)(n_per_shard * G) * sww;
+    }
+    c->last_kept = keep;
+    if (keep) {
+        c->gathered = false;
+        c->lists_known = false;
+        rc = mcl_stage_keep(h, (int64_t)c->rank * n_per_shard, n_per_shard * G, action);
+    } else if (lists) {
+        if (counts[c->rank] != h->compact_n)
+            return fail(h, MCL_ERR_NOT_READY, "this engine's list is not the one the last exchange described (state changed on one rank only?)");
         // (1) the lists: already here when the previous update gathered them (same lists, same lengths), else now
         bool have = c->gathered && c->gathered_epoch == h->list_epoch;
         for (int r = 0; r < G && have; ++r) have = c->gathered_counts[r] == counts[r];
@@ -3131,22 +3183,29 @@ int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, i
     // (2) + (3)
     rc = comm_rays_to_sums(h, obs, n_beams, false);
     if (rc) return rc;
-    const size_t k = 5 + 3 * (size_t)G + 1;
-    if (c->h_red[1 + k - 1] != 0.0) {
+    const size_t k = 5 + 3 * (size_t)G + 2;
+    if (c->h_red[1 + k - 2] != 0.0) {
         // some shard's fix-up lists overflowed (debug_force_exact at size, a pathological map): every rank once more from the ray stage on
         rc = comm_rays_to_sums(h, obs, n_beams, true);
         if (rc) return rc;
     }
     for (size_t i = 0; i < k; ++i) c->vec[i] = c->h_red[1 + i];
     for (int i = 0; i < 5; ++i) h->global_sums[i] = c->vec[i];
+    c->vec_valid = true;
+    stage_commit_carry(h);
     comm_note_lists(c, c->vec);
+    bool next_keeps = false;
+    if (h->cfg.resample_neff_permille > 0) {
+        const double sw = c->vec[0], sww = c->vec[5 + 3 * G + 1];
+        next_keeps = sww > 0.0 && sw * sw >= ((double)h->cfg.resample_neff_permille / 1000.0) * (double)(n_per_shard * G) * sww;
+    }
     // the lists this update wrote are final: gather them for the next update now, beside the host's work between updates
     // (every rank reads the same vector, so every rank takes the same decision)
     {
         bool all = true;
         uint64_t wsum = 0;
         for (int r = 0; r < G; ++r) { all = all && c->counts[r] >= 0; wsum |= c->counts[r] > 0 ? c->totals[r] : 0ull; }
-        if (all && wsum != 0 && !h->env_comm_no_pregather) {
+        if (all && wsum != 0 && !h->env_comm_no_pregather && !next_keeps) {
             rc = comm_gather_lists(h, c->counts);
             if (rc) return rc;
         }
@@ -3159,7 +3218,7 @@ int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, i
 
 int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n)
 {
-    if (!h || !h->comm || !vec_out || n != 5 + 3 * h->comm->n_ranks + 1) return MCL_ERR_INVALID_ARG;
+    if (!h || !h->comm || !vec_out || n != 5 + 3 * h->comm->n_ranks + 2) return MCL_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i) vec_out[i] = h->comm->vec[i];
     return MCL_OK;
 }
@@ -3167,7 +3226,7 @@ int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n)
 int mcl_comm_last_exchange(const mcl_engine_t *h, int32_t *dense, uint64_t *weights_bytes, uint64_t *records_bytes)
 {
     if (!h || !h->comm) return MCL_ERR_INVALID_ARG;
-    if (dense) *dense = h->comm->last_dense ? 1 : 0;
+    if (dense) *dense = h->comm->last_kept ? 2 : h->comm->last_dense ? 1 : 0;       // 0 lists, 1 dense, 2 none (the set was kept)
     if (weights_bytes) *weights_bytes = h->comm->last_dense ? h->comm->dense_weights_bytes : 0;
     if (records_bytes) *records_bytes = h->comm->last_dense ? h->comm->dense_records_bytes : 0;
     return MCL_OK;
@@ -3225,6 +3284,8 @@ struct mcl_group {
     uint64_t q_total = 0;
     bool have_q_total = false;
     double sums[5] = {0, 0, 0, 0, 0};
+    double sum_ww = 0.0;                           // sum w^2 of the whole set (adaptive resampling)
+    bool kept_last = false;
     double timings[6] = {0, 0, 0, 0, 0, 0};
     uint64_t bytes_weights = 0, bytes_parents = 0;
     std::string err;
@@ -3276,8 +3337,8 @@ int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_
     g_create_error.clear();
     if (!cfg || !devices || !out || n_devices <= 0 || n_devices > mcl::kMaxShards) { g_create_error = "bad group arguments (1..16 devices)"; return MCL_ERR_INVALID_ARG; }
     *out = nullptr;
-    if (cfg->weight_mode != MCL_WEIGHT_LOG || cfg->resample_neff_permille != 0) {
-        g_create_error = "a device group needs weight_mode LOG and resample_neff_permille 0";
+    if (cfg->weight_mode != MCL_WEIGHT_LOG) {
+        g_create_error = "a device group needs weight_mode LOG";
         return MCL_ERR_UNSUPPORTED;
     }
     if ((int64_t)cfg->max_particles * n_devices >= MCL_MAX_TOTAL_PARTICLES) { g_create_error = "particle total must stay below 2^27"; return MCL_ERR_INVALID_ARG; }
@@ -3423,14 +3484,23 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
     // Exchange: when every shard has a compact parent list (the usual case after an update with many beams) the devices copy
     // each other's LISTS (44 B per particle that carries weight); otherwise every weight (8 B per particle) and the
     // selected parents are read where they live.
-    bool compact = g->q_total != 0;
+    // Adaptive resampling (E9, cfg.resample_neff_permille > 0): the set is kept -- no exchange, no resampling -- when the effective
+    // sample size of the WHOLE set after the previous update is at least r / 1000 of it (mcl_update's rule on the group's sums)
+    bool keep = false;
+    {
+        const int r = g->eng[0]->cfg.resample_neff_permille;
+        bool carry = r > 0;
+        for (int s = 0; s < G; ++s) carry = carry && g->eng[s]->carry_valid;
+        if (carry) keep = g->sum_ww > 0.0 && g->sums[0] * g->sums[0] >= ((double)r / 1000.0) * (double)nt * g->sum_ww;
+    }
+    bool compact = g->q_total != 0 && !keep;
     int64_t longest = 0;
     for (int s = 0; s < G; ++s) { compact = compact && g->eng[s]->compact_n >= 0; longest = std::max(longest, g->eng[s]->compact_n); }
     const int64_t centries = std::max<int64_t>(64, (longest + 63) & ~(int64_t)63);
     for (int s = 0; s < G; ++s) {
         mcl_engine *e = g->eng[s];
         GHIP(g, hipSetDevice(e->cfg.device));
-        if (!compact && !e->pack_valid[e->cur]) {      // first update after set_particles / init: the records do not exist yet
+        if (!compact && !keep && !e->pack_valid[e->cur]) {      // first update after set_particles / init: the records do not exist yet
             hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->d_x[e->cur], e->d_y[e->cur],
                                e->d_th[e->cur], n, e->d_pack[e->cur]);
             e->pack_valid[e->cur] = true;
@@ -3449,7 +3519,9 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
             if (s != d) GHIP(g, hipStreamWaitEvent(e->stream, g->ev_ready[s], 0));
         GHIP(g, hipMemsetAsync(g->d_remote[d], 0, 8, e->stream));
         int rc;
-        if (compact) {
+        if (keep) {
+            rc = mcl_stage_keep(e, (int64_t)d * n, nt, action);
+        } else if (compact) {
             const size_t need = (size_t)G * (size_t)centries * 44;
             if (need > g->chunks_capacity[d]) {
                 if (g->d_chunks[d]) { GHIP(g, hipStreamSynchronize(e->stream)); (void)hipFree(g->d_chunks[d]); g->d_chunks[d] = nullptr; }
@@ -3487,6 +3559,7 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
     // phase 3: weights against the global maximum, sums.  The weights (and the compact list) of a shard are rewritten here:
     // every device must have drawn its children first.  The host waits once, for the sums.
     double gs[5] = {0, 0, 0, 0, 0};
+    double sww = 0.0;
     uint64_t qt = 0;
     unsigned long long remote = 0;
     uint64_t listed = 0;
@@ -3520,6 +3593,7 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
             if (rc) return gfail(g, rc, e->err);
         }
         for (int k = 0; k < 5; ++k) gs[k] = 0.0;
+        sww = 0.0;
         qt = 0; remote = 0; listed = 0;
         bool overflow = false;
         for (int d = 0; d < G; ++d) {
@@ -3529,6 +3603,7 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
             stage_rays_note(e);
             overflow = overflow || (e->last_quad && e->h_fix_count != 0);
             for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];      // unpack_result left the LOCAL sums there
+            sww += e->h_scalars[7];
             qt += e->q_total;
             unsigned long long r = 0;
             GHIP(g, hipMemcpy(&r, g->d_remote[d], 8, hipMemcpyDeviceToHost));
@@ -3539,6 +3614,8 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
         if (redo) return gfail(g, MCL_ERR_HIP, "the ray stage's work lists overflowed twice (internal)");
     }
     for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
+    g->sum_ww = sww;
+    g->kept_last = keep;
     g->q_total = qt;
     for (int d = 0; d < G; ++d) mcl_stage_finish(g->eng[d], gs);
     // received per device: the other shards' lists / weights; parents read from peers (dense exchange only)
@@ -3547,6 +3624,7 @@ int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, i
     for (int d = 0; d < G; ++d) shortest = std::min<uint64_t>(shortest, compact ? (uint64_t)counts[d] : 0u);
     g->bytes_weights = compact ? (listed - shortest) * 44u : (uint64_t)(G - 1) * (uint64_t)n * 8u;
     g->bytes_parents = compact ? 0u : (uint64_t)remote * 32u;         // upper bound: children of remote parents x record size
+    if (keep) { g->bytes_weights = 0; g->bytes_parents = 0; }         // nothing was exchanged
     g->compact_last = compact;
     for (int k = 0; k < 5; ++k) {
         double m = 0.0;

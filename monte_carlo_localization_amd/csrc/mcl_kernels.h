@@ -253,7 +253,8 @@ struct ResampleArgs {
     uint32_t seed_lo, seed_hi, update_idx, k0;
     double dt, v, w;                  // motion scalars (cpp:452-471, computed on the host)
     double disp_x, disp_y, disp_th;
-    int do_resample;                  // 0: children = parents (identity), used by tests
+    int do_resample;                  // 0: children = parents (identity): a kept update of adaptive resampling (E9), tests
+    int64_t idx_out_base;             // ... whose parent index is reported as idx_out_base + own index (a shard's first global index)
     int do_motion;
     // sharded particle sets: parents of other shards are fetched on demand instead of being gathered
     const double4 *ppack_rank[kMaxShards];   // records of shard r (peer pointers within one process), or all null
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_resample_motion(ResampleArgs a)
         }
         have_rec = true;
     }
-    if (a.idx_out) a.idx_out[m] = (int32_t)idx;
+    if (a.idx_out) a.idx_out[m] = (int32_t)((a.do_resample || a.idx_in) ? idx : idx + a.idx_out_base);
     if (a.index_only) return;
     if (have_rec) {
     } else if (a.n_per_rank > 0) {
@@ -2607,12 +2608,12 @@ __global__ void k_group_max(GroupMaxArgs a)
 
 // Device-ordered staged flow (mcl_stage_weights_async): this shard's contribution to the one SUM exchange of an update, written
 // where the collective reads it.  vec = [sum w, sum w x, sum w y, sum w sin, sum w cos | per shard: list length + 1 (0: no list),
-// low and high half of the fixed-point weight total | 1 when the ray stage's fix-up lists overflowed]; every other shard's
+// low and high half of the fixed-point weight total | 1 when the ray stage's fix-up lists overflowed | sum w^2]; every other shard's
 // slots are zeroed here, so that the SUM over the shards fills them in.  res = the engine's result block.
 __global__ void k_stage_pack(const unsigned long long *__restrict__ res, double *__restrict__ vec, int n_shards, int self, int listed,
                              unsigned long long list_cap)
 {
-    const int len = 5 + 3 * n_shards + 1;
+    const int len = 5 + 3 * n_shards + 2;
     const double *sc = reinterpret_cast<const double *>(res);
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
         double v = 0.0;
@@ -2621,7 +2622,8 @@ __global__ void k_stage_pack(const unsigned long long *__restrict__ res, double 
         else if (i == 5 + 3 * self) v = (listed && res[16] <= list_cap) ? (double)(res[16] + 1ull) : 0.0;
         else if (i == 6 + 3 * self) v = (double)(res[2] & 0xFFFFFFFFull);
         else if (i == 7 + 3 * self) v = (double)(res[2] >> 32);
-        else if (i == len - 1) v = res[12] != 0ull ? 1.0 : 0.0;
+        else if (i == len - 2) v = res[12] != 0ull ? 1.0 : 0.0;
+        else if (i == len - 1) v = sc[7];                       // sum w^2 (adaptive resampling: the effective sample size of the whole set)
         vec[i] = v;
     }
 }

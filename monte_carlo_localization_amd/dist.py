@@ -88,9 +88,9 @@ class ShardedFilter:
         self.use_lists = os.environ.get("MCL_DIST_NO_LISTS") != "1" and hasattr(shard, "export_compact")
         # the two small all-reduces of an update go through tensors made once (a fresh device tensor per update is an
         # allocation and a blocking copy each way: 0.1 ms of the update at 4M particles)
-        # ([0]: the MAX exchange, [1:]: the SUM exchange with one more element, the ray stage's overflow flag)
-        self.red_dev = torch.zeros(1 + 5 + 3 * self.world + 1, dtype=torch.float64, device=device)
-        self.red_host = torch.zeros(1 + 5 + 3 * self.world + 1, dtype=torch.float64)
+        # ([0]: the MAX exchange, [1:]: the SUM exchange with two more elements: the ray stage's overflow flag and sum w^2)
+        self.red_dev = torch.zeros(1 + 5 + 3 * self.world + 2, dtype=torch.float64, device=device)
+        self.red_host = torch.zeros(1 + 5 + 3 * self.world + 2, dtype=torch.float64)
         if device.type == "cuda":
             self.red_host = self.red_host.pin_memory()
         # device-ordered update (one host wait per update, the exchanged scalars never leave the device): needs the engine's
@@ -102,6 +102,11 @@ class ShardedFilter:
         # in one call, the collectives on its own stream (include/mcl_hip_engine.h: mcl_comm_*).  torch.distributed then only
         # carries the rendezvous and the first update's dense exchange.  Needs the nccl backend (a gloo rehearsal shares one
         # device between the ranks, which RCCL refuses); MCL_DIST_NATIVE=0 keeps the torch collectives.
+        # adaptive resampling (Config.resample_neff_permille = r > 0, an option the reference does not have): the set is kept -- no
+        # exchange, no resampling -- when the effective sample size of the WHOLE set after the previous update is >= r / 1000 of it
+        self.neff_permille = int(getattr(getattr(shard, "cfg", None), "resample_neff_permille", 0)) if hasattr(shard, "stage_keep") else 0
+        self.last_sw = self.last_sww = None                               # sum w and sum w^2 of the whole set after the last update
+        self.kept_last = False
         self.native = False
         self.native_updates = 0                                           # consecutive updates the native call has run
         if (self.device_ordered and hasattr(shard, "comm_update") and os.environ.get("MCL_DIST_NATIVE") != "0"
@@ -187,6 +192,7 @@ class ShardedFilter:
         self.pending_list = None
         self.q_total = None
         self.counts = self.totals = None
+        self.last_sw = self.last_sww = None
         if self.native:
             self.shard.comm_set_lists([-1] * self.world, [0] * self.world)      # no lists: the next update is a dense one on every rank
             self.native_updates = 0
@@ -225,11 +231,20 @@ class ShardedFilter:
         work = dist.all_gather_into_tensor(self.chunk_all[:nbytes * self.world], self.chunk_local[:nbytes], group=self.group, async_op=async_op)
         return (work if async_op else None), entries
 
-    def _update_ordered(self, action, obs):
+    def _update_ordered(self, action, obs, keep=False):
         """One update with the lists known (every update but the first): everything is enqueued, the two small exchanges read
-        and write device memory, the host waits once -- for the summed vector."""
+        and write device memory, the host waits once -- for the summed vector.  keep: adaptive resampling kept the set (no lists)."""
         s, world = self.shard, self.world
         ts = torch.cuda.current_stream(self.device).cuda_stream
+        if keep:
+            if self.pending_list is not None and self.pending_list[0] is not None:
+                self.pending_list[0].wait()
+            self.pending_list = None
+            self._exchange_bytes.update(kind="none", list_bytes_received=0, list_payload_bytes=0, weights_received=0,
+                                        requests_sent=0, records_received=0, distinct_remote_parents=0)
+            s.stream_wait_external(ts)
+            s.stage_keep(self.rank * self.n, self.n_total, action)
+            return self._ordered_after_children(obs, ts)
         if self.pending_list is not None:
             work, entries = self.pending_list                             # issued at the end of the previous update
             self.pending_list = None
@@ -244,7 +259,11 @@ class ShardedFilter:
         s.stream_wait_external(ts)
         s.stage_resample_compact_async(self.chunk_all.data_ptr(), world, entries, self.counts, self.totals, self.n, self.rank,
                                        self.rank * self.n, self.n_total, action)
-        k = 5 + 3 * world + 1
+        return self._ordered_after_children(obs, ts)
+
+    def _ordered_after_children(self, obs, ts):
+        s, world = self.shard, self.world
+        k = 5 + 3 * world + 2
         s.stage_rays_async(obs, self.red_dev.data_ptr())                 # local max log-weight -> red_dev[0]
         s.external_wait_stream(ts)
         dist.all_reduce(self.red_dev[:1], op=dist.ReduceOp.MAX, group=self.group)
@@ -257,11 +276,11 @@ class ShardedFilter:
         self._sync()                                                      # THE host wait of the update
         gs = self.red_host[1:1 + k].numpy().copy()
         s.stage_complete(gs[:5])
-        if gs[-1] != 0.0:
+        if gs[-2] != 0.0:
             # some shard's fix-up lists overflowed (debug_force_exact at size, a pathological map): every rank runs the ray stage
             # and the two exchanges once more, stage by stage (the synchronous ray stage falls back to the self-contained kernel)
             return None
-        return gs[:-1]
+        return np.concatenate([gs[:-2], gs[-1:]])                        # [5 sums | 3 per shard | sum w^2]
 
     def _distinct(self):
         """self.parent (global indices) -> (distinct parents ascending = grouped by owner, position of every child's parent
@@ -346,6 +365,10 @@ class ShardedFilter:
         s = self.shard
         self._host_waits = 0
         gs = None
+        keep = False
+        if self.neff_permille > 0 and self.last_sw is not None and not self.native:
+            keep = self.last_sww > 0.0 and self.last_sw * self.last_sw >= (self.neff_permille / 1000.0) * float(self.n_total) * self.last_sww
+        self.kept_last = keep
         # (1) exchange for resampling + the children
         if self.native:
             # the whole update in one native call -- lists, or the dense exchange when there are none (first update) -- on the
@@ -355,11 +378,22 @@ class ShardedFilter:
                 self.pose = pose
                 self.native_updates += 1
                 self.q_total = self.counts = self.totals = None           # (the communicator keeps them now)
+                self.kept_last = bool(s.comm_stats()["kept"]) if self.neff_permille > 0 else False
                 return pose
             self.native_updates = 0
             self._resample_dense(action)
-        elif self.device_ordered and self._lists_usable():
-            gs = self._update_ordered(action, obs)                       # the whole update; None: once more from the ray stage on
+        elif self.device_ordered and (keep or self._lists_usable()):
+            gs = self._update_ordered(action, obs, keep)                 # the whole update; None: once more from the ray stage on
+        elif keep:
+            if self.pending_list is not None and self.pending_list[0] is not None:
+                self.pending_list[0].wait()
+            if self.pending_q is not None:
+                self.pending_q.wait()
+            self.pending_list = self.pending_q = None
+            self._sync()
+            self._exchange_bytes.update(kind="none", list_bytes_received=0, list_payload_bytes=0, weights_received=0,
+                                        requests_sent=0, records_received=0, distinct_remote_parents=0)
+            s.stage_keep(self.rank * self.n, self.n_total, action)
         elif self._lists_usable():
             self._resample_from_lists(action)
         else:
@@ -369,7 +403,8 @@ class ShardedFilter:
             self._resample_dense(action)
         if gs is None:
             gs = self._stages_after_children(obs)
-        per = gs[5:].reshape(self.world, 3)
+        per = gs[5:5 + 3 * self.world].reshape(self.world, 3)
+        self.last_sw, self.last_sww = float(gs[0]), float(gs[-1])          # (adaptive resampling: N_eff of the whole set)
         self.counts = per[:, 0].astype(np.int64) - 1
         self.totals = np.array([(int(a) + (int(b) << 32)) & 0xFFFFFFFFFFFFFFFF for a, b in per[:, 1:]], dtype=np.uint64)   # exact: halves < 2^32
         self.q_total = int(sum(int(t) for t in self.totals)) & 0xFFFFFFFFFFFFFFFF
@@ -377,7 +412,9 @@ class ShardedFilter:
         s.stage_finish(gs)
         if self.native:
             s.comm_set_lists(self.counts, self.totals)      # what the next (native) update's list exchange works from
-        if self.overlap:
+        next_keeps = (self.neff_permille > 0 and self.last_sww > 0.0
+                      and self.last_sw * self.last_sw >= (self.neff_permille / 1000.0) * float(self.n_total) * self.last_sww)
+        if self.overlap and not next_keeps:
             # this update's weights are final: start the exchange of the next update now, beside the host work between updates
             if self._lists_usable():
                 if not self.native:                  # (the native update gathers on the engine's stream, first thing)
@@ -402,9 +439,10 @@ class ShardedFilter:
         sc = read()
         ql = int(np.float64(sc[2]).view(np.uint64))                      # this shard's fixed-point weight total
         n_list = s.compact_list()[0] if self.use_lists else -1
-        vec = np.zeros(5 + 3 * self.world)
+        vec = np.zeros(5 + 3 * self.world + 1)
         vec[:5] = (sc[1], sc[3], sc[4], sc[5], sc[6])
         vec[5 + 3 * self.rank: 8 + 3 * self.rank] = (float(n_list + 1), float(ql & 0xFFFFFFFF), float(ql >> 32))
+        vec[-1] = sc[7] if len(sc) > 7 else 0.0                          # sum w^2 (adaptive resampling)
         return self._all_reduce_small(vec, dist.ReduceOp.SUM)
 
     def set_particles(self, xyz_colmajor, weights):

@@ -37,7 +37,7 @@ EXPORTS = [
     "mcl_set_debug_count_probes", "mcl_set_particles_shard", "mcl_get_compact_list", "mcl_compact_chunk_bytes", "mcl_export_compact",
     "mcl_stage_resample_compact", "mcl_group_exchanged_lists", "mcl_get_ray_steps16", "mcl_get_planned_ray_kernel",
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
-    "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete",
+    "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete", "mcl_stage_keep",
     "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector", "mcl_comm_last_exchange", "mcl_comm_selftest",
 ]
 
@@ -482,6 +482,11 @@ class Engine:
                                                             C.c_int64(n_per_shard), C.c_int32(self_shard), C.c_int64(child_first),
                                                             C.c_int64(n_children_total), _p(a)), "mcl_stage_resample_compact_async")
 
+    def stage_keep(self, child_first, n_children_total, action):
+        """Adaptive resampling kept the set: motion only, every particle its own parent (launch only)."""
+        a = _c(action, np.float64)
+        self._chk(self.lib.mcl_stage_keep(self._h, C.c_int64(child_first), C.c_int64(n_children_total), _p(a)), "mcl_stage_keep")
+
     def stage_rays_async(self, obs, d_local_max):
         o = _c(obs, np.float32)
         self._chk(self.lib.mcl_stage_rays_async(self._h, _p(o), C.c_int32(o.size), C.c_void_p(d_local_max)), "mcl_stage_rays_async")
@@ -547,7 +552,7 @@ class Engine:
         return pose
 
     def comm_vector(self):
-        vec = np.zeros(5 + 3 * self._comm_ranks + 1)
+        vec = np.zeros(5 + 3 * self._comm_ranks + 2)
         self._chk(self.lib.mcl_comm_get_vector(self._h, _p(vec), C.c_int32(vec.size)), "mcl_comm_get_vector")
         return vec
 
@@ -556,7 +561,7 @@ class Engine:
         self._chk(self.lib.mcl_comm_stats(self._h, C.byref(r), C.byref(p), C.byref(w)), "mcl_comm_stats")
         d, wb, rb = C.c_int32(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.mcl_comm_last_exchange(self._h, C.byref(d), C.byref(wb), C.byref(rb)), "mcl_comm_last_exchange")
-        return dict(list_bytes_received=r.value, list_payload_bytes=p.value, host_waits=w.value, dense=bool(d.value),
+        return dict(list_bytes_received=r.value, list_payload_bytes=p.value, host_waits=w.value, dense=d.value == 1, kept=d.value == 2,
                     weights_received=wb.value, records_received=rb.value)
 
     def scan_weights(self, d_q, d_cdf, n, offset=0):

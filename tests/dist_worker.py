@@ -34,7 +34,8 @@ def main():
     ntot = n_local * world
     device_init = os.environ.get("MCL_TEST_DEVICE_INIT") == "1"        # the engine's own initialiser (Philox keyed by the global index)
     digest = os.environ.get("MCL_TEST_DIGEST") == "1"                  # checksums per 2^20 particles instead of the arrays
-    p = None if device_init else np.stack([rng.normal(0, 0.5, ntot), rng.normal(0, 0.5, ntot), rng.normal(0, 0.4, ntot)])
+    sig = (0.03, 0.03, 0.01) if os.environ.get("MCL_TEST_TIGHT") == "1" else (0.5, 0.5, 0.4)     # tight: weights that stay comparable
+    p = None if device_init else np.stack([rng.normal(0, sig[0], ntot), rng.normal(0, sig[1], ntot), rng.normal(0, sig[2], ntot)])
     mine = slice(rank * n_local, (rank + 1) * n_local)
     w = np.full(n_local, 1.0 / ntot)
     skewed = os.environ.get("MCL_TEST_SKEWED_WEIGHTS") == "1"          # host-supplied weights that differ between the shards
@@ -51,7 +52,8 @@ def main():
     else:
         from monte_carlo_localization_amd import engine
         shard = engine.Engine(max_particles=n_local, device=dev_index, seed=2024, resample_mode=mode,
-                              debug_force_exact=int(os.environ.get("MCL_TEST_FORCE_EXACT", "0")))
+                              debug_force_exact=int(os.environ.get("MCL_TEST_FORCE_EXACT", "0")),
+                              resample_neff_permille=int(os.environ.get("MCL_TEST_NEFF", "0")))
         shard.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
         shard.set_beam_angles(ang)
         if device_init:
@@ -63,11 +65,12 @@ def main():
     sf = ShardedFilter(shard, n_local, device, overlap=overlap)
     if skewed:
         sf.set_particles(p[:, mine], w)                 # every shard quantises against the maximum of the whole set
-    poses, kinds, waits = [], [], []
+    poses, kinds, waits, kept = [], [], [], []
     for _ in range(steps):
         poses.append(sf.update((0.05, 0.0, 0.01), obs))
         kinds.append(sf.exchange_bytes["kind"])
         waits.append(sf.host_waits)                     # stream synchronisations of this update (1: the device-ordered flow)
+        kept.append(int(getattr(sf, 'kept_last', False)))   # adaptive resampling kept the set in this update
     if backend_kind == "oracle":
         parts, q, idx = shard.p, shard.q, shard.idx
     else:
@@ -78,9 +81,9 @@ def main():
     if digest:
         from conftest import block_digests
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=block_digests(parts), q=block_digests(q), idx=block_digests(idx),
-                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), native=np.array(int(getattr(sf, 'native', False))))
+                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), native=np.array(int(getattr(sf, 'native', False))))
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), native=np.array(int(getattr(sf, 'native', False))))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), native=np.array(int(getattr(sf, 'native', False))))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -181,6 +181,52 @@ def test_native_rccl_update_one_rank_equals_the_torch_collectives(tmp_path, vari
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host", ["sync", "ordered", "native"])
+def test_adaptive_resampling_in_the_sharded_hosts_equals_one_engine(tmp_path, host):
+    """Config.resample_neff_permille (E9: keep the set while N_eff of the WHOLE set stays above r / 1000 of it) through dist.py:
+    the decision from the summed vector (sum w, sum w^2 of all shards), mcl_stage_keep instead of the exchange, the carried
+    log-weights added in the ray stage, the carry committed at the end of the update.  Three hosts: stage by stage and
+    device-ordered over gloo (two ranks on the one GPU), the engine's RCCL communicator (one rank).  Against a plain engine
+    with the same option: same kept / resampled pattern (both occur), same parents, particles and weights."""
+    d = tmp_path / host
+    d.mkdir()
+    n, steps, r = 3000, 8, 20
+    extra = dict(MCL_TEST_BEAM_STEP="9", MCL_TEST_NEFF=str(r), MCL_TEST_TIGHT="1")
+    if host == "native":
+        world, n_local = 1, n
+        got = run_world("engine", d, 1, n, steps, 0, False, MCL_TEST_NCCL="1", **extra)
+        assert int(got[0]["native"]) == 1
+    else:
+        world, n_local = 2, n // 2
+        got = run_world("engine", d, 2, n_local, steps, 0, host == "ordered", **extra, **(dict(MCL_DIST_SYNC="1") if host == "sync" else {}))
+    import __graft_entry__ as g
+    g.build()
+    from conftest import GOLDEN
+    from monte_carlo_localization_amd import engine, maps
+    from oracle import oracle as orc
+    m = maps.load_npz(os.path.join(GOLDEN, "map_Spielberg_map.npz"))
+    rng = np.random.default_rng(123)
+    p = np.stack([rng.normal(0, 0.03, n), rng.normal(0, 0.03, n), rng.normal(0, 0.01, n)])
+    e = engine.Engine(max_particles=n, seed=2024, resample_mode=0, resample_neff_permille=r)
+    e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+    e.set_beam_angles(orc.beam_angles(angle_step=9))
+    e.set_particles(p, np.full(n, 1.0 / n))
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::9].copy()
+    kept = []
+    for _ in range(steps):
+        e.update((0.05, 0.0, 0.01), obs)
+        kept.append(int(not e.effective_sample_size()[1]))
+    assert 0 < sum(kept) < steps - 1, kept                                # both branches, as in the single-engine oracle test
+    for rk in range(world):
+        assert list(got[rk]["kept"]) == kept, (rk, list(got[rk]["kept"]), kept)
+    cat = lambda k: np.concatenate([z[k] for z in got], axis=-1)
+    assert np.array_equal(cat("particles"), e.get_particles())
+    assert np.array_equal(cat("idx"), e.resample_indices())
+    np.testing.assert_allclose(got[0]["poses"][-1], e.expected_pose(), rtol=0, atol=1e-12)
+    e.close()
+
+
+@pytest.mark.gpu
 def test_device_ordered_update_redoes_the_ray_stage_after_a_list_overflow(tmp_path):
     """debug_force_exact=2 sends every ray to the fix-up lists, which overflow: the device-ordered update learns that from the
     summed vector (its last element), and every rank runs the ray stage and the exchanges again stage by stage -- same result

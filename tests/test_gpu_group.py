@@ -118,6 +118,35 @@ def test_group_redoes_the_ray_stage_when_a_fix_up_list_overflows(orc, engine_mod
     grp.close(); one.close()
 
 
+def test_group_adaptive_resampling_equals_one_engine(orc, engine_mod, spielberg):
+    """resample_neff_permille in a device group: the decision from the group's sums (sum w, sum w^2 over the shards),
+    mcl_stage_keep on every device instead of the exchange.  Same kept / resampled pattern (both occur), parents, particles and
+    weights as one engine with the option."""
+    from conftest import tracking_cloud
+    ang = orc.beam_angles(angle_step=9)
+    obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::9].copy()
+    n = 3000
+    p = tracking_cloud(np.random.default_rng(4), n, sig=(0.03, 0.03, 0.01))
+    w = np.full(n, 1.0 / n)
+    one = make_engine(engine_mod, spielberg, ang, n, seed=11, resample_neff_permille=20)
+    one.set_particles(p, w)
+    grp = make_group(engine_mod, spielberg, ang, n // 2, 2, seed=11, resample_neff_permille=20)
+    grp.set_particles(p, w)
+    kept = []
+    for k in range(8):
+        one.update(ACTION, obs)
+        grp.update(ACTION, obs)
+        kept.append(not one.effective_sample_size()[1])
+        assert np.array_equal(grp.resample_indices(), one.resample_indices()), f"update {k}"
+        assert np.array_equal(grp.get_particles(), one.get_particles()), f"update {k}"
+        np.testing.assert_allclose(grp.get_weights(), one.get_weights(), rtol=1e-13, atol=0, err_msg=f"update {k}")
+        if kept[-1]:
+            xb = grp.exchange_bytes()
+            assert xb["weights_received_per_device"] == 0 and xb["parent_records_from_peers"] == 0     # nothing was exchanged
+    assert any(kept) and not all(kept[1:]), kept
+    grp.close(); one.close()
+
+
 def test_group_set_particles_with_non_uniform_weights(orc, engine_mod, spielberg):
     """Host-supplied weights that differ between the shards (the second shard holds most of the mass): every shard is
     quantised against the maximum of the WHOLE set, so the global CDF -- and with it every child -- equals one engine's."""
