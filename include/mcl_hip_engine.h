@@ -390,8 +390,10 @@ int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int6
  * the other shards' compact parent lists (44 B per particle that carries weight; mcl_get_compact_list) and draws its own
  * children from the merged lists -- or, when some shard has no list (first update, flat weights), the other shards'
  * fixed-point weights (8 B per particle), scans the same exact global CDF and reads each selected parent where it lives (peer
- * pointer over xGMI); maxima and sums are combined on the host; the phases are ordered by events between the devices' streams.  Results are bit-identical to a single engine holding all particles.  The devices must have peer access to each
- * other; weight_mode LOG and resample_neff_permille 0 only. */
+ * pointer over xGMI); the maximum is taken on the devices (each reads its peers' maxima), the sums are combined on the host (one
+ * wait per update); the phases are ordered by events between the devices' streams.  Results are bit-identical to a single engine
+ * holding all particles.  The devices must have peer access to each other; weight_mode LOG only; resample_neff_permille works
+ * on the sums of the whole set. */
 typedef struct mcl_group mcl_group_t;
 int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_devices, mcl_group_t **out);
 void mcl_group_destroy(mcl_group_t *g);
