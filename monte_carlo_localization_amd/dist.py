@@ -456,3 +456,15 @@ class ShardedFilter:
 
     def expected_pose(self):
         return self.pose
+
+    def effective_sample_size(self):
+        """(N_eff = (sum w)^2 / sum w^2 of the WHOLE set after the last update, whether that update resampled) -- what
+        Engine.effective_sample_size reports for one engine; None before the first update."""
+        if self.native and self.native_updates > 0:
+            v = self.shard.comm_vector()
+            sw, sww = float(v[0]), float(v[-1])
+        elif self.last_sw is not None:
+            sw, sww = self.last_sw, self.last_sww
+        else:
+            return None
+        return (sw * sw / sww if sww > 0.0 else 0.0), not self.kept_last

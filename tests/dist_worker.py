@@ -65,12 +65,13 @@ def main():
     sf = ShardedFilter(shard, n_local, device, overlap=overlap)
     if skewed:
         sf.set_particles(p[:, mine], w)                 # every shard quantises against the maximum of the whole set
-    poses, kinds, waits, kept = [], [], [], []
+    poses, kinds, waits, kept, neff = [], [], [], [], []
     for _ in range(steps):
         poses.append(sf.update((0.05, 0.0, 0.01), obs))
         kinds.append(sf.exchange_bytes["kind"])
         waits.append(sf.host_waits)                     # stream synchronisations of this update (1: the device-ordered flow)
         kept.append(int(getattr(sf, 'kept_last', False)))   # adaptive resampling kept the set in this update
+        neff.append(sf.effective_sample_size()[0] if hasattr(sf, 'effective_sample_size') else 0.0)
     if backend_kind == "oracle":
         parts, q, idx = shard.p, shard.q, shard.idx
     else:
@@ -81,9 +82,9 @@ def main():
     if digest:
         from conftest import block_digests
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=block_digests(parts), q=block_digests(q), idx=block_digests(idx),
-                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), native=np.array(int(getattr(sf, 'native', False))))
+                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), neff=np.array(neff), native=np.array(int(getattr(sf, 'native', False))))
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), native=np.array(int(getattr(sf, 'native', False))))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), neff=np.array(neff), native=np.array(int(getattr(sf, 'native', False))))
     dist.barrier()
     dist.destroy_process_group()
 

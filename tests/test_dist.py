@@ -212,13 +212,15 @@ def test_adaptive_resampling_in_the_sharded_hosts_equals_one_engine(tmp_path, ho
     e.set_beam_angles(orc.beam_angles(angle_step=9))
     e.set_particles(p, np.full(n, 1.0 / n))
     obs = np.load(os.path.join(GOLDEN, "scan_Spielberg_map_origin.npz"))["ranges"][::9].copy()
-    kept = []
+    kept, neff = [], []
     for _ in range(steps):
         e.update((0.05, 0.0, 0.01), obs)
         kept.append(int(not e.effective_sample_size()[1]))
+        neff.append(e.effective_sample_size()[0])
     assert 0 < sum(kept) < steps - 1, kept                                # both branches, as in the single-engine oracle test
     for rk in range(world):
         assert list(got[rk]["kept"]) == kept, (rk, list(got[rk]["kept"]), kept)
+        np.testing.assert_allclose(got[rk]["neff"], neff, rtol=1e-12)     # N_eff of the WHOLE set (sums reduced in another order)
     cat = lambda k: np.concatenate([z[k] for z in got], axis=-1)
     assert np.array_equal(cat("particles"), e.get_particles())
     assert np.array_equal(cat("idx"), e.resample_indices())
