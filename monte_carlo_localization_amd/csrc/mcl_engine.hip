@@ -89,9 +89,10 @@ struct mcl_engine {
     bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
     bool skip_layout_ok = false;        // k_rays_skip has no static LDS (its window is addressed from LDS offset 0)
     // k_rays_sweep on the wedge fields in GLOBAL memory (ranges a 256-cell LDS window cannot hold; MCL_SWEEP_GLOBAL=1 forces it)
-    uint8_t *d_distg = nullptr;         // kWedges fields with a two-cell stop ring: (Hp + 4) x distg_pitch bytes each
-    int distg_pitch = 0, g_cb = 0;      // row pitch; cell bits of a window-relative position (10 .. 12)
-    size_t distg_stride = 0, distg_pad = 0;   // bytes per field; stop-filled bytes before the first / after the last field
+    uint8_t *d_distg = nullptr;         // kWedges mirrored fields with a two-cell stop ring and a tail of stop rows each (k_ring_field)
+    int distg_pitch = 0;                // row pitch
+    size_t distg_stride = 0;            // bytes per field, tail included
+    const char *distg_why_not = nullptr;     // why the global-field form of k_rays_sweep is not available for this map, if it is not
     bool sweep_global = false;          // this map takes the global-field variant (decided at mcl_set_map)
     bool env_sweep_global = false;
     int env_sw_split16 = -1;            // MCL_SW_SPLIT16=0/1 forces RayArgs::split16 (default: by size)
@@ -624,10 +625,10 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
     if (rk == MCL_RAYS_QUAD) { w = windows_ok && h->quad_layout_ok ? "configured: MCL_RAYS_QUAD" : (no_windows ? no_windows : "k_rays_quad's LDS layout check failed"); return windows_ok && h->quad_layout_ok ? 3 : 0; }
     if (rk == MCL_RAYS_CELL) { w = windows_ok && h->cell_layout_ok ? "configured: MCL_RAYS_CELL" : (no_windows ? no_windows : "k_rays_cell's LDS layout check failed"); return windows_ok && h->cell_layout_ok ? 4 : 0; }
     // its windows are 256 cells wide (mcl_rays_sweep.h) and addressed from a raw LDS offset checked at mcl_create
-    // ... or, for ranges beyond that (MAX_RANGE_PX up to 2037), probes the same wedge fields in global memory
+    // ... or, for ranges beyond that, probes the same wedge fields in global memory
     const char *no_sweep = h->quad_ok ? nullptr : no_windows;
     if (!no_sweep) {
-        if (h->sweep_global) { if (!h->d_distg) no_sweep = "MAX_RANGE_PX > 2037: beyond the 11-bit cell field of k_rays_sweep's global-field form"; }
+        if (h->sweep_global) { if (!h->d_distg) no_sweep = h->distg_why_not ? h->distg_why_not : "k_rays_sweep's global-field form: fields not built"; }
         else if (!mcl::sweep_window_fits(h->P)) no_sweep = "MAX_RANGE_PX > 243: a 256-cell window of k_rays_sweep cannot hold a ray plus 8 cells of play";
         else if (!h->sweep_layout_ok) no_sweep = "k_rays_sweep's LDS layout check failed at mcl_create";
     }
@@ -757,9 +758,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int items_per_slice = sweep ? mcl::kWedges / sweep_g : (cell ? mcl::kWedges : 4);
         const int nseg = (int)std::min<int64_t>(max_wg, items_per_slice * (int64_t)nsl);   // one segment per persistent workgroup
         unsigned long long rays_per_seg = (unsigned long long)n * h->B / nseg + 64;
-        // (the global-field form of k_rays_sweep works with 20-22 fractional bits instead of 24: its guard is 4-16 times wider in
-        //  pixels and it hands up to ~0.4 % of the rays of a long-range map to the fix-up pass: room for 3 %)
-        const unsigned long long seg_div = (sweep && h->sweep_global) ? 32 : 256;
+        // (both forms of k_rays_sweep work with 32 fractional bits: a walk of ~70 rays is handed over once in several thousand)
+        const unsigned long long seg_div = 256;
         unsigned long long segcap = std::max<unsigned long long>(2048, (rays_per_seg / seg_div + 7) & ~7ull);
         if ((unsigned long long)n * h->B <= (4ull << 20)) segcap = (2 * rays_per_seg + 7) & ~7ull;   // small launch: room for every ray
         if ((unsigned long long)nseg * segcap > h->fix_alloc) {
@@ -893,7 +893,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
             a.beam_csx = h->sweep_global ? h->d_beam_csxg : h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
-            a.distg = h->d_distg + h->distg_pad; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch; a.g_cb = h->g_cb;
+            a.distg = h->d_distg; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
                 HIPCHK(h, hipMalloc(&h->d_far_list, (size_t)h->cap * sizeof(uint32_t)));
@@ -1306,15 +1306,11 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
     // budget S - (P+2) - 3 is at least 48 cells, otherwise k_rays_skip's full-LDS nibble window is used
     { const int S = h->env_qside > 0 ? h->env_qside : 280; h->qside = (S - (P + 2) - 3 >= 32) ? S : 0; }
     // k_rays_sweep: the 256-cell LDS windows hold ranges up to 243 px; beyond that (or with MCL_SWEEP_GLOBAL=1) the same walk
-    // probes the wedge fields in global memory, positions relative to an origin of the lane's own in a cell field of g_cb bits that
-    // holds a ray's reach (2^cb >= range + 11: 10 bits up to 1013 px, 11 up to 2037; 22 / 21 fractional bits -- a direction
-    // component of up to 2^22 fits v_mad_i32_i24)
+    // probes mirrored copies of the wedge fields in global memory, a position's cell dwords being absolute offsets there (no
+    // bound on the range from the position format)
     h->sweep_global = h->env_sweep_global || !mcl::sweep_window_fits(P);
-    h->g_cb = 0;
-    if (h->sweep_global)
-        for (int cb = 10; cb <= 11 && !h->g_cb; ++cb)
-            if ((1 << cb) >= P + 11) h->g_cb = cb;
-    const bool want_wedges = h->qside > 0 || (h->sweep_global && h->g_cb != 0);     // wedge + quadrant fields (k_rays_far reads the latter)
+    h->distg_why_not = nullptr;
+    const bool want_wedges = h->qside > 0 || h->sweep_global;     // wedge + quadrant fields (k_rays_far reads the latter)
     build_sensor_table(h->cfg, P, h->table);
     const int tw = P + 1;
     std::vector<float> L((size_t)tw * tw);
@@ -1372,22 +1368,29 @@ int mcl_set_map(mcl_engine_t *h, const int8_t *data, uint32_t width, uint32_t he
         }
         (void)hipFree(d_nxt); (void)hipFree(d_prv); (void)hipFree(d_rows);
         if (rc_w != MCL_OK) return fail(h, rc_w, "building the wedge fields failed");
-        if (h->sweep_global && h->g_cb != 0) {
-            // the copies k_rays_sweep<.., GLOBAL> probes: every field with a two-cell ring of stop bytes (k_ring_field)
-            // Memory safety does not rest on the rays being valid: a position can be at most 2^cb rows / columns away from the lane's
-            // own (in-grid) cell, so with (2^cb + 2) rows of stop bytes before the first and after the last field every address
-            // the kernel can form lies inside this allocation (and a ray that strays there reads "stop" and ends).
-            h->distg_pitch = (h->Wp + 4 + 63) & ~63;
-            h->distg_stride = (size_t)(h->Hp + 4) * (size_t)h->distg_pitch;
-            h->distg_pad = (size_t)((1 << h->g_cb) + 2) * (size_t)h->distg_pitch;
-            const size_t galloc = h->distg_stride * mcl::kWedges + 2 * h->distg_pad;
-            HIPCHK(h, hipMalloc(&h->d_distg, galloc));
-            HIPCHK(h, hipMemsetAsync(h->d_distg, 0xFF, galloc, h->stream));
-            for (int k = 0; k < mcl::kWedges; ++k)
-                hipLaunchKernelGGL(mcl::k_ring_field, dim3((h->distg_pitch + 255) / 256, h->Hp + 4), dim3(256), 0, h->stream, h->d_distw + (size_t)k * fsz,
-                                   h->Wp, h->Hp, h->Wps, h->distg_pitch, h->d_distg + h->distg_pad + (size_t)k * h->distg_stride);
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->sweep_global) {
+            // the copies k_rays_sweep<.., GLOBAL> probes: every field mirrored for its quadrant, with a two-cell ring of stop bytes
+            // and a TAIL of stop rows (k_ring_field; the allocation is stop-filled first).  Memory safety does not rest on the rays
+            // being valid: a walk starts in a cell of the ringed grid, runs towards +x, +y only and advances by at most P samples
+            // in total whatever bytes it reads (mcl::sweep_global_layout: the largest offset it can form lies inside its own
+            // field's tail; tests/test_sweep_addressing.py enumerates the corners).
+            const mcl::SweepGlobalLayout gl = mcl::sweep_global_layout(h->Wp, h->Hp, P);
+            if (!gl.ok) {
+                h->distg_why_not = "k_rays_sweep's global-field form needs the sixteen ringed fields (with their tails) in less than 2^32 bytes and rows / pitch below 2^24: this map is too large for it";
+            } else {
+                h->distg_pitch = gl.pitch;
+                h->distg_stride = gl.stride;
+                HIPCHK(h, hipMalloc(&h->d_distg, gl.alloc));
+                HIPCHK(h, hipMemsetAsync(h->d_distg, 0xFF, gl.alloc, h->stream));
+                for (int k = 0; k < mcl::kWedges; ++k) {
+                    const int q = k >> mcl::kWedgeShift;
+                    hipLaunchKernelGGL(mcl::k_ring_field, dim3((h->distg_pitch + 255) / 256, h->Hp + 4), dim3(256), 0, h->stream, h->d_distw + (size_t)k * fsz,
+                                       h->Wp, h->Hp, h->Wps, h->distg_pitch, (q == 0 || q == 3) ? 1 : 0, (q == 0 || q == 1) ? 1 : 0,
+                                       h->d_distg + (size_t)k * h->distg_stride);
+                }
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+            }
         }
     }
     HIPCHK(h, hipMemcpy(h->d_L, L.data(), L.size() * sizeof(float), hipMemcpyHostToDevice));

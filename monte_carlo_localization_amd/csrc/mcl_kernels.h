@@ -688,10 +688,9 @@ struct RayArgs {
     const double2 *slice_mean;     // k_rays_cell: mean pixel position of every slice of the sorted order (k_slice_means)
     const uint8_t *distw;          // k_rays_cell: kWedges wedge fields (mcl_wedge.h), field k at distw + k * distw_stride
     size_t distw_stride;
-    const uint8_t *distg;          // k_rays_sweep<.., GLOBAL>: the same fields with a two-cell ring of stop bytes around the padded grid:
-    size_t distg_stride;           //   padded cell (y, x) of field k at distg + k * distg_stride + (y + 2) * distg_pitch + (x + 2)
-    int distg_pitch;
-    int g_cb;                      // k_rays_sweep<.., GLOBAL>: cell bits of a window-relative position (fraction bits = 32 - g_cb)
+    const uint8_t *distg;          // k_rays_sweep<.., GLOBAL>: the same fields mirrored per quadrant, with a two-cell ring of stop bytes around the
+    size_t distg_stride;           //   padded grid and a tail of stop rows: mirrored padded cell (y, x) of field k at distg + k * distg_stride +
+    int distg_pitch;               //   (y + 2) * distg_pitch + (x + 2); distg is the START of the allocation (every offset the kernel forms is >= 0)
     int qside;                     // k_rays_quad: window side in cells (1 byte per cell)
     int nslices;                   // k_rays_quad: particle slices; grid = 4 * nslices
     unsigned long long *fix_list;  // k_rays_quad -> k_rays_fix: (particle << 16 | beam) of undecided rays
@@ -1497,21 +1496,22 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_quad(RayArgs a)
 }
 
 // ---- wedge fields (mcl_wedge.h) built on the device at set_map ------------------------------------------------
-// one thread per row of the padded grid: next / previous stop cell in the row (dist == 0 marks a stop)
-// A wedge field (Hp x Wps bytes, LDS encoding: stop = 0xFF, skips 1..127) -> the copy k_rays_sweep<.., GLOBAL> probes in global
-// memory: (Hp + 4) rows of `pitch` bytes, the padded grid at offset (2, 2), everything else -- the two-cell ring around it and the
-// row padding -- stop.  A jump from inside the grid lands inside it or at most one cell beyond (the skip field counts the
-// outside as stop), so no address a walk computes leaves the array.
-__global__ __launch_bounds__(256) void k_ring_field(const uint8_t *__restrict__ src, int Wp, int Hp, int Wps, int pitch, uint8_t *__restrict__ dst)
+// The copy of wedge field k that k_rays_sweep<.., GLOBAL> probes in place (mcl_rays_sweep.h): (Hp + 4) rows of `pitch` bytes holding
+// the padded grid MIRRORED in the axes along which the wedge's rays run backwards (sxp / syp = 0), at offset (2, 2); everything
+// else -- the two-cell ring around it and the row padding -- stop.  Every ray of the wedge runs towards +x, +y in this frame.
+// The tail of stop rows behind the field is left by the memset of the allocation (mcl_set_map).
+__global__ __launch_bounds__(256) void k_ring_field(const uint8_t *__restrict__ src, int Wp, int Hp, int Wps, int pitch, int sxp, int syp,
+                                                   uint8_t *__restrict__ dst)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;          // destination column / row
     if (x >= pitch) return;
-    const int gx = x - 2, gy = y - 2;
+    const int mx = x - 2, my = y - 2;                                             // cell of the mirrored padded grid
     uint8_t v = 0xFF;
-    if (gx >= 0 && gx < Wp && gy >= 0 && gy < Hp) v = src[(size_t)gy * Wps + gx];
+    if (mx >= 0 && mx < Wp && my >= 0 && my < Hp) v = src[(size_t)(syp ? my : Hp - 1 - my) * Wps + (sxp ? mx : Wp - 1 - mx)];
     dst[(size_t)y * pitch + x] = v;
 }
 
+// one thread per row of the padded grid: next / previous stop cell in the row (dist == 0 marks a stop)
 __global__ void k_row_tables(const uint8_t *__restrict__ dist, int Wp, int Hp, int Wps, int32_t *__restrict__ nxt, int32_t *__restrict__ prv)
 {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;

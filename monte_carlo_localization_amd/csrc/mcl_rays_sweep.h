@@ -25,12 +25,16 @@ namespace mcl {
 
 constexpr int kSwUnder = 127;            // table rows below "no hit": samples left in [-127, -1] after an over-long jump
 constexpr int kSwUnit = 1024;            // particles per scheduling unit: one pass of the 16 waves of a workgroup
-constexpr int kSwFx = 24;                // fractional bits of a window-relative position; the cell index is the top byte
+constexpr int kSwFx = 32;                // fractional bits of a position: the low dword of a 64-bit value, the cell index is the high dword
 constexpr int kSwSide = 256;             // window side = LDS row pitch: (cell y, cell x) -> address is one v_perm_b32
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
-// fixed-point scale of a direction component: 2^24 - 0.625, so that |component| = 1 rounds to 2^24 - 1 (the operand of
-// v_mad_u32_u24 has 24 bits); the guard pays for it with 0.625 unit per sample
-constexpr double kSwDirScale = 16777216.0 - 0.625;
+// fixed-point scale of a direction component: 2^32 - 3, so that |component| = 1 stays below 2^32 (the operand of v_mad_u64_u32
+// has 32 bits) with the + 1 of MCL_SW_ROTATE and its two roundings on top; the guard pays for it with 3 units (2^-32 px) per sample
+constexpr double kSwDirScale = 4294967296.0 - 3.0;
+// level-1 error bound per axis in units of 2^-32 px: a direction component is off by at most 3 units (scale: -3 .. 0, the + 1 of
+// the inner magic, two roundings of half a unit: -3 .. +2) on each of at most P samples, the origin by half a unit, the
+// reference's own accumulated rounding (cpp:622-625: P sequential fp64 adds) by < 0.2 unit (3e-11 px, mcl_kernels.h); + slack
+__host__ __device__ inline uint32_t sweep_guard_units(int P) { return 3u * (uint32_t)(P + 1) + ((uint32_t)(P + 1) >> 6) + 8u; }
 
 __host__ __device__ inline bool sweep_window_fits(int P) { return kSwSide - (P + 2) - 3 >= kSwMinExtent; }
 
@@ -297,65 +301,74 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
     if (threadIdx.x == 0) nitems_out[0] = carry_sh * ngroups;
 }
 
-// One probe trip.  Positions are window-relative fixed point [cell:8][fraction:24] and carry the guard bias G; the window
-// is stored MIRRORED per quadrant so that every ray of the wedge runs towards +x and +y, which makes both direction
-// components unsigned 24-bit operands X and lets the position advance by T += skip * X (v_mad_u32_u24: no end point, no
-// sign).  The LDS address of cell (y, x) in a 256-byte pitch is the two top bytes side by side: one v_perm_b32.
-//   frac(T) < 2G  <=>  the unbiased sample lies within G units of a cell boundary (either side);
-// the cell is read at the biased position, which differs from the true cell only for such a sample.
+// One probe trip.  A position is a 64-bit fixed-point number per axis: the cell index in the high dword, a 32-bit fraction
+// in the low one; it advances by T += skip * X with ONE v_mad_u64_u32 per axis (4.5 cycles, profiles/r02_op_rates.txt; the
+// 24-bit form of rounds 2-4 needed a v_mad_u32_u24 and a v_and each).  The window is stored MIRRORED per quadrant so that every
+// ray of the wedge runs towards +x and +y: both direction components are unsigned 32-bit operands X.  The high dwords are the
+// cell coordinates as they stand (LDS address = row << 8 | column: one v_lshl_or_b32), the low dwords are the fractions as they
+// stand: positions carry the guard bias G, so
+//   frac(T) < 2G  <=>  the unbiased sample lies within G units (2^-32 px) of a cell boundary (either side)
+// is one v_min3_u32 over the two low dwords, no masks; the cell is read at the biased position, which differs from the true cell
+// only for such a sample.  Five VALU per trip (rounds 2-4: seven).
 // BYIN = the skip that leads to this sample (the own cell's on the first trip, the byte just read afterwards).
-#define MCL_SW_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, XX, XY, SEL, MASK, LB) \
-    "v_mad_u32_u24 " TX ", " BYIN ", " XX ", " TXIN "\n\t"                                                \
-    "v_mad_u32_u24 " TY ", " BYIN ", " XY ", " TYIN "\n\t"                                                \
-    "v_perm_b32 " AD ", " TY ", " TX ", " SEL "\n\t"                                                      \
+#define MCL_SW_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, TXLO, TXHI, TYLO, TYHI, AD, BY, GOUT, REMOUT, XX, XY, LB) \
+    "v_mad_u64_u32 " TX ", vcc, " BYIN ", " XX ", " TXIN "\n\t"                                           \
+    "v_mad_u64_u32 " TY ", vcc, " BYIN ", " XY ", " TYIN "\n\t"                                           \
+    "v_lshl_or_b32 " AD ", " TYHI ", 8, " TXHI "\n\t"                                                     \
     "ds_read_i8 " BY ", " AD " offset:" LB "\n\t"                                                         \
-    "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                              \
-    "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                              \
-    "v_min3_u32 " GOUT ", " GIN ", " T0 ", " T1 "\n\t"                                                    \
+    "v_min3_u32 " GOUT ", " GIN ", " TXLO ", " TYLO "\n\t"                                                \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                            \
     "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                   \
     "s_andn2_b64 exec, exec, vcc\n\t"
 
+// The rotated direction of the next beam in the mirrored frame, as integers in the low dwords of v44 (x) and v46 (y):
+//   Xx = aq cb - bq sb,  Xy = +-(bq cb + aq sb)   (aq, bq = the particle's cos / sin times +-kSwDirScale; v[40:43] = cb, sb)
+// with the 1.5 * 2^52 magic folded into the inner FMA: two v_fma_f64 per component (rounds 2-4: mul, fma, add), each rounding to
+// a whole unit -- |error| <= 1 unit, paid for by the guard.  The inner magic carries +1: the sum is then >= 0 whatever the two
+// roundings do to a component that is 0 in exact arithmetic (a ray along an axis), see guard_units in k_rays_sweep.
+// NEGA / NEGB = "-" in the quadrants where the sign of the y component differs from x's.
+#define MCL_SW_ROTATE(NEGA, NEGB)                                                                                               \
+        "v_fma_f64 v[48:49], -%[bq], v[42:43], %[magic1]\n\t"                                                                  \
+        "v_fma_f64 v[44:45], %[aq], v[40:41], v[48:49]\n\t"                                                                    \
+        "v_fma_f64 v[48:49], " NEGA "%[aq], v[42:43], %[magic1]\n\t"                                                           \
+        "v_fma_f64 v[46:47], " NEGB "%[bq], v[40:41], v[48:49]\n\t"
+
 // The beam walk over the slots every live lane of the wave has, as one asm block: all 64 lanes active, no per-slot validity
-// tests.  NEGY = "-" in the quadrants where the sign of the y component differs from x's (see aq / bq below).
-//   v[40:43] direction of the beam (cos, sin); v[44:45] / v[46:47] rotated direction + magic: Xx = v44, Xy = v46, and once
-//   those exist v45 / v47 are the trip's scratch; v[48:49] product, then LDS address / cell byte / table offset;
-//   v[50:51] pending table entry; v54 v55 T; v56 guard minimum; v57 samples left
-#define MCL_SW_WALK(NEGY)                                                                                                      \
+// tests, no per-ray test for undecided rays either: the guard minimum %[g] runs over ALL the rays of the walk and is looked at
+// once, after it (with 32 fractional bits a sample falls inside the guard once in a few million; the lane that has one hands
+// the walk's rays to the fix-up list, see below).
+//   v[40:43] direction of the beam (cos, sin); v[44:45] / v[46:47] rotated direction + magic: Xx = v44, Xy = v46;
+//   v[48:49] inner FMA, then LDS address / cell byte / table offset; v[50:51] pending table entry;
+//   v[52:53] Tx (fraction, cell); v[54:55] Ty; v57 samples left
+// (the trips after the first: six per turn of the loop -- a ray makes 3.4, a wave 4.5 -- so that the walk sees not-taken exit
+//  branches only; the countdown and its taken branch cost a wave ~20 cycles per trip in a chain that is latency-bound,
+//  tools/ubench/trip_rates.hip)
+#define MCL_SW_TRIP_NEXT MCL_SW_TRIP("v57", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]")
+#define MCL_SW_WALK(NEGA, NEGB)                                                                                                \
     asm volatile(                                                                                                              \
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
         "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0: keeps the vmcnt pattern of the steady state */                 \
         "3:\n\t"                                                                                                               \
         "s_waitcnt vmcnt(1)\n\t" /* direction landed (the table entry may be in flight) */                                     \
-        "v_mul_f64 v[48:49], %[bq], v[42:43]\n\t"                                                                              \
-        "v_fma_f64 v[44:45], %[aq], v[40:41], -v[48:49]\n\t"                                                                   \
-        "v_mul_f64 v[48:49], %[aq], v[42:43]\n\t"                                                                              \
-        "v_fma_f64 v[46:47], %[bq], v[40:41], v[48:49]\n\t"                                                                    \
-        "v_add_f64 v[44:45], v[44:45], %[magic]\n\t"                                                                           \
-        "v_add_f64 v[46:47], " NEGY "v[46:47], %[magic]\n\t"                                                                   \
+        MCL_SW_ROTATE(NEGA, NEGB)                                                                                              \
         "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t" /* next beam's direction */                                         \
-        "s_movk_i32 %[cd], 300\n\t"                                                                                            \
-        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[sel]", "%[mask]", "%[lb]") \
+        "s_movk_i32 %[cd], 50\n\t"                                                                                             \
+        MCL_SW_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]") \
         "s_cbranch_execz 2f\n"                                                                                                 \
         "1:\n\t"                                                                                                               \
-        MCL_SW_TRIP("v57", "v56", "v49", "v54", "v55", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[sel]", "%[mask]", "%[lb]") \
-        "s_cbranch_execz 2f\n\t"                                                                                               \
+        MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
+        MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
+        MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
+        MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
+        MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
+        MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
         "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
         "s_cbranch_scc0 1b\n\t"                                                                                                \
         "s_mov_b32 %[expired], 1\n" /* malformed window (impossible): the pass is redone by the fix-up path */                 \
         "2:\n\t"                                                                                                               \
         "s_mov_b64 exec, -1\n\t"                                                                                               \
-        "v_cmp_gt_u32 vcc, %[thr], v56\n\t" /* undecided: a sample within the guard of a boundary */                           \
-        "s_cbranch_vccz 4f\n\t"                                                                                                \
-        "s_mov_b64 exec, vcc\n\t"                                                                                              \
-        "v_mov_b32 %[ambj2], %[ambj1]\n\t"                                                                                     \
-        "v_mov_b32 %[ambj1], %[j16]\n\t" /* (beam + 1) << 4 */                                                                 \
-        "v_add_u32 %[ambcnt], 1, %[ambcnt]\n\t"                                                                                \
-        "v_mov_b32 v57, %[zrow]\n\t"                                                                                           \
-        "s_mov_b64 exec, -1\n"                                                                                                 \
-        "4:\n\t"                                                                                                               \
         "s_waitcnt vmcnt(1)\n\t" /* previous beam's table entry landed */                                                      \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
         "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
@@ -365,78 +378,60 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 3b\n\t"                                                                                                \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]"                                                                                   \
-        : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2), \
+        : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [g] "+v"(gwalk),                                              \
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
-        : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e),       \
-          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
-          [sel] "s"(permsel), [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff),          \
-          [lb] "n"(kQLdsBase)                                                                                                  \
-        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
-          "v55", "v56", "v57")
+        : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                     \
+          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8),                        \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
+        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",    \
+          "v53", "v54", "v55", "v57")
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
-// holds (MAX_RANGE_PX up to 2041; cpp:195 puts no bound on it).  Positions are [cell:cb][fraction:fb] relative to an origin of the
-// LANE's own (its particle's cell at index 8, or 2^cb - 9 along an axis the wedge's rays run down), cb + fb = 32 with 2^cb >= range + 11
-// (cb = 10 up to 1013 px of range, 11 up to 2037): there is no window a particle could miss.  Every ray it traces must be INSIDE its
-// wedge -- a ray the wedge's skip field does not hold for could jump a wall next to the map border and leave the field -- which is why
-// this form's virtual beams repeat the scan's first / last real beam (mcl_set_beam_angles) instead of continuing its angular grid.  Nothing is mirrored: direction
-// components are signed and fit v_mad_i32_i24 (|X| <= 2^fb <= 2^23).  The cell's byte comes from a copy of the wedge field with a two-cell ring of stop bytes
-// around the padded grid (RayArgs::distg), so that no address a ray can reach lies outside the array: a jump from inside the grid
-// lands inside it or on the ring (the skip field counts the outside as stop), and a stop ends the walk.  A trip is 10 VALU
-// (5 four-cycle + 5 two-cycle) + one global byte load; its latency (L1 / L2 hits: the fields around the cloud stay resident) is
-// covered by the other seven waves of the SIMD where the LDS round trip was before.
-#define MCL_SWG_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, T0, T1, AD, BY, GOUT, REMOUT, XX, XY, FB, PITCH, MASK, BASE, LB) \
-    "v_mad_i32_i24 " TX ", " BYIN ", " XX ", " TXIN "\n\t"                                                \
-    "v_mad_i32_i24 " TY ", " BYIN ", " XY ", " TYIN "\n\t"                                                \
-    "v_lshrrev_b32 " T0 ", " FB ", " TY "\n\t"                                                            \
-    "v_lshrrev_b32 " T1 ", " FB ", " TX "\n\t"                                                            \
-    "v_mad_u32_u24 " AD ", " T0 ", " PITCH ", " T1 "\n\t"                                                 \
-    "v_add_u32 " AD ", " AD ", " LB "\n\t"                                                                \
+// holds (cpp:195 puts no bound on MAX_RANGE_PX).  The fields are read in place from copies that are MIRRORED per quadrant like
+// the LDS windows (RayArgs::distg: every ray runs towards +x, +y; direction components are unsigned), each with a two-cell ring of
+// stop bytes and a tail of stop rows behind it.  There is no window: the cell dwords of a position are the lane's ABSOLUTE
+// row and byte offset in the allocation (the field's offset rides in the column dword), the address of a cell is
+// row * pitch + column from the start of the allocation: one v_mad_u32_u24 -- five VALU per trip here as well (round 4: ten),
+// and no bound on the range from the position format.  Memory safety does not rest on the rays being valid: a walk advances by at most P
+// samples in total (a skip larger than the samples left ends it before the jump is made), so from a cell of the ringed grid it can only form
+// addresses inside its field's tail, whatever bytes it reads (mcl_set_map sizes the tail; tests/test_sweep_addressing.py).
+// A trip's latency (L1 / L2 hits: the fields around the cloud stay resident) is covered by the other seven waves of the SIMD.
+#define MCL_SWG_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, TXLO, TXHI, TYLO, TYHI, AD, BY, GOUT, REMOUT, XX, XY, PITCH, BASE) \
+    "v_mad_u64_u32 " TX ", vcc, " BYIN ", " XX ", " TXIN "\n\t"                                           \
+    "v_mad_u64_u32 " TY ", vcc, " BYIN ", " XY ", " TYIN "\n\t"                                           \
+    "v_mad_u32_u24 " AD ", " TYHI ", " PITCH ", " TXHI "\n\t"                                             \
     "global_load_sbyte " BY ", " AD ", " BASE "\n\t"                                                      \
-    "v_and_b32 " T0 ", " MASK ", " TX "\n\t"                                                              \
-    "v_and_b32 " T1 ", " MASK ", " TY "\n\t"                                                              \
-    "v_min3_u32 " GOUT ", " GIN ", " T0 ", " T1 "\n\t"                                                    \
+    "v_min3_u32 " GOUT ", " GIN ", " TXLO ", " TYLO "\n\t"                                                \
     "s_waitcnt vmcnt(0)\n\t"                                                                              \
     "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                   \
     "s_andn2_b64 exec, exec, vcc\n\t"
 
 // (memory reads return in order: the trip's vmcnt(0) also lands the next beam's direction and the previous beam's table entry,
 //  which were requested before it -- the two vmcnt(1) of the LDS walk are satisfied trivially here)
-#define MCL_SWG_WALK()                                                                                                         \
+#define MCL_SWG_TRIP_NEXT MCL_SWG_TRIP("v57", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[pitch]", "%[gbase]")
+#define MCL_SWG_WALK(NEGA, NEGB)                                                                                               \
     asm volatile(                                                                                                              \
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
         "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
         "3:\n\t"                                                                                                               \
         "s_waitcnt vmcnt(1)\n\t"                                                                                               \
-        "v_mul_f64 v[48:49], %[bq], v[42:43]\n\t"                                                                              \
-        "v_fma_f64 v[44:45], %[aq], v[40:41], -v[48:49]\n\t"                                                                   \
-        "v_mul_f64 v[48:49], %[aq], v[42:43]\n\t"                                                                              \
-        "v_fma_f64 v[46:47], %[bq], v[40:41], v[48:49]\n\t"                                                                    \
-        "v_add_f64 v[44:45], v[44:45], %[magic]\n\t"                                                                           \
-        "v_add_f64 v[46:47], v[46:47], %[magic]\n\t"                                                                           \
+        MCL_SW_ROTATE(NEGA, NEGB)                                                                                              \
         "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
         "s_mov_b32 %[cd], %[cdinit]\n\t"                                                                                       \
-        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]") \
+        MCL_SWG_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[pitch]", "%[gbase]") \
         "s_cbranch_execz 2f\n"                                                                                                 \
         "1:\n\t"                                                                                                               \
-        MCL_SWG_TRIP("v57", "v56", "v49", "v54", "v55", "v54", "v55", "v45", "v47", "v48", "v49", "v56", "v57", "v44", "v46", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]") \
-        "s_cbranch_execz 2f\n\t"                                                                                               \
+        MCL_SWG_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                              \
+        MCL_SWG_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                              \
+        MCL_SWG_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                              \
+        MCL_SWG_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                              \
         "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
         "s_cbranch_scc0 1b\n\t"                                                                                                \
         "s_mov_b32 %[expired], 1\n"                                                                                            \
         "2:\n\t"                                                                                                               \
         "s_mov_b64 exec, -1\n\t"                                                                                               \
-        "v_cmp_gt_u32 vcc, %[thr], v56\n\t"                                                                                    \
-        "s_cbranch_vccz 4f\n\t"                                                                                                \
-        "s_mov_b64 exec, vcc\n\t"                                                                                              \
-        "v_mov_b32 %[ambj2], %[ambj1]\n\t"                                                                                     \
-        "v_mov_b32 %[ambj1], %[j16]\n\t"                                                                                       \
-        "v_add_u32 %[ambcnt], 1, %[ambcnt]\n\t"                                                                                \
-        "v_mov_b32 v57, %[zrow]\n\t"                                                                                           \
-        "s_mov_b64 exec, -1\n"                                                                                                 \
-        "4:\n\t"                                                                                                               \
         "s_waitcnt vmcnt(1)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
         "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
@@ -446,14 +441,14 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 3b\n\t"                                                                                                \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]"                                                                                   \
-        : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [ambcnt] "+v"(ambcnt), [ambj1] "+v"(ambj1), [ambj2] "+v"(ambj2), \
+        : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [g] "+v"(gwalk),                                              \
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
-        : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e),       \
-          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8), [mask] "s"(fmask),      \
-          [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit), [lb] "v"(lane_base),                  \
-          [magic] "s"(6755399441055744.0), [thr] "s"(gthresh), [zrow] "s"(zrow), [zoff] "s"(zoff)                               \
-        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54",    \
-          "v55", "v56", "v57")
+        : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                     \
+          [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8),                        \
+          [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit4),                                                     \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff)                                                                   \
+        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",    \
+          "v53", "v54", "v55", "v57")
 
 template <bool COUNT, bool GLOBAL = false>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
@@ -474,19 +469,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = a.fix_cap + 1ull;
         return;
     }
-    // window side in cells and fractional bits of a position: the 256-cell LDS window with 24 bits, or (GLOBAL) the span of the
-    // cb-bit cell field with 32 - cb bits
-    const int S = GLOBAL ? (1 << a.g_cb) : kSwSide;
-    const uint32_t fbits = GLOBAL ? (uint32_t)(32 - a.g_cb) : (uint32_t)kSwFx;
-    // level-1 error bound per axis, in units of 2^-24 px: 0.5 for the origin + (0.5 rounding + 0.625 scale, kSwDirScale)
-    // per sample, s <= P + 1 samples, + 5 for the fp64 rounding of the rotated direction.  GLOBAL (units of 2^-fb px, the
-    // direction scaled by exactly 2^fb): 0.5 for the origin + 0.5 per sample + 2 of slack
-    const uint32_t guard_units = GLOBAL ? ((uint32_t)(a.P + 1) + 1u) / 2u + 3u : (9u * (uint32_t)(a.P + 1) + 7u) / 8u + 6u;
+    // extent of the mirrored frame in cells: the 256-cell LDS window, or (GLOBAL) the ringed field (its two axes differ)
+    const int Sx = GLOBAL ? a.Wp + 4 : kSwSide, Sy = GLOBAL ? a.Hp + 4 : kSwSide;
+    const uint32_t guard_units = sweep_guard_units(a.P);       // level-1 error bound per axis, units of 2^-32 px
     const uint32_t gthresh = a.force_exact ? 0xFFFFFFFFu : 2u * guard_units;
-    const uint32_t fmask = (1u << fbits) - 1u;
     const uint32_t gpitch = (uint32_t)a.distg_pitch;           // GLOBAL: row pitch of the ringed wedge fields
-    const uint32_t cdinit = (uint32_t)a.P + 64u;               // GLOBAL: trip countdown (a walk makes at most P trips)
-    const uint32_t permsel = 0x0C0C0703u;                      // v_perm_b32(Ty, Tx): byte 0 = Tx[31:24], byte 1 = Ty[31:24], rest 0
+    const uint32_t cdinit = (uint32_t)a.P + 64u;               // GLOBAL: trip countdown of the per-slot loop (a walk makes at most P trips)
+    const uint32_t cdinit4 = cdinit / 4u + 1u;                 // ... and of the asm walk's loop, four trips per turn
     const uint32_t st8 = (uint32_t)__builtin_amdgcn_readfirstlane(a.ltd_cols * 8);
     const uint32_t zrow = (uint32_t)(a.P + 1);                 // "samples left" that selects the all-zero row
     const unsigned char *ldsb = lds_raw;
@@ -516,20 +505,15 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     for (int gw = 0; gw < G; ++gw) {
     const int kbin = grp * G + gw;
     const int q = kbin >> kWedgeShift;
-    // GLOBAL: nothing is mirrored (direction components are signed there)
-    const int sxp = GLOBAL || (q == 0 || q == 3), syp = GLOBAL || (q == 0 || q == 1);
+    const int sxp = (q == 0 || q == 3), syp = (q == 0 || q == 1);      // the wedge's rays run up (true) or down the axis
     const bool negy = sxp != syp;
     const int mlo = 3;
     int wx0, wy0;
-    // GLOBAL: no window.  Every LANE has its own origin: its particle's cell sits at index 8 (or S - 9 along an axis the wedge's
-    // rays run down), so a ray's cells stay inside [0, S) whatever the run's extent, and the cell byte is
-    // gbase[lane_base + row * pitch + column] with lane_base = the lane origin's offset in the ringed field (32-bit wrap-around
-    // arithmetic: the sum is a valid offset whenever the cell is in the ringed field, which every reachable cell is)
-    const uint8_t *gbase = nullptr;
-    const bool qsx = (q == 0 || q == 3), qsy = (q == 0 || q == 1);      // the wedge's rays run up (true) or down the axis
+    // GLOBAL: no window.  Field kbin of RayArgs::distg is mirrored like a window would be, and a position's cell dwords are the
+    // absolute row and (field offset + column) in the allocation: nothing a particle could miss but the ringed grid itself
+    const uint32_t foff = GLOBAL ? (uint32_t)((size_t)kbin * a.distg_stride) : 0u;     // < 2^32: checked by mcl_set_map
     if (GLOBAL) {
-        wx0 = 0; wy0 = 0;
-        gbase = a.distg + (size_t)kbin * a.distg_stride;
+        wx0 = -2; wy0 = -2;                                                // ringed frame: column c = padded cell c - 2
         if (gw > 0) __syncthreads();                                       // every wave is done with the previous pass's chunk counter
         if (threadIdx.x == 0) chunk_sh = 0u;
         __syncthreads();
@@ -614,24 +598,16 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         }
         int n1 = jb > ja ? jb - ja : 0, n2 = a.B > ja2 ? a.B - ja2 : 0;
         if (!have) { n1 = 0; n2 = 0; }
-        double wpx, wpy;
+        // position in the (unmirrored) frame: column c of the frame = padded cell wx0 + c
+        const double wpx = pci.z - (double)(wx0 - 1), wpy = pci.w - (double)(wy0 - 1);
         bool inwin;
-        uint32_t lane_base = 0u;
         if (GLOBAL) {
-            // the particle's own padded cell must exist in the field (NaN fails the comparisons); its position relative to the
-            // lane's origin keeps the fraction of the pixel coordinate
+            // the particle's own padded cell must exist in the field (NaN fails the comparisons)
             inwin = pci.z >= -1.0 && pci.z < (double)(a.Wp - 1) && pci.w >= -1.0 && pci.w < (double)(a.Hp - 1);
-            const int ocx = inwin ? (int)floor(pci.z) + 1 : 0, ocy = inwin ? (int)floor(pci.w) + 1 : 0;
-            const int r0x = qsx ? 8 : S - 9, r0y = qsy ? 8 : S - 9;
-            wpx = inwin ? pci.z - (double)(ocx - 1 - r0x) : (double)r0x + 0.5;
-            wpy = inwin ? pci.w - (double)(ocy - 1 - r0y) : (double)r0y + 0.5;
-            lane_base = (uint32_t)((ocy - r0y + 2) * a.distg_pitch + (ocx - r0x + 2));
         } else {
-            wpx = pci.z - (double)(wx0 - 1);
-            wpy = pci.w - (double)(wy0 - 1);
             const double fwd = (double)(a.P + 2), bwd = 2.0;
-            const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)S) : (wpx - fwd >= 0.0 && wpx + bwd < (double)S);
-            const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)S) : (wpy - fwd >= 0.0 && wpy + bwd < (double)S);
+            const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)Sx) : (wpx - fwd >= 0.0 && wpx + bwd < (double)Sx);
+            const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)Sy) : (wpy - fwd >= 0.0 && wpy + bwd < (double)Sy);
             inwin = inx && iny;
         }
         uint32_t i = 0xFFFFFFFFu;                                  // particle index, loaded by the rare paths that need it
@@ -647,29 +623,28 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // a lane without rays gets a zero direction and zero samples from the window's cell (2, 2): every probe it
         // makes reads that cell, whose byte is never 0, and leaves the loop at once; its table column is the zero column B
         const bool live = total > 0;
-        // position in the mirrored window (the rays of the wedge run towards +x, +y there)
-        // (GLOBAL: a lane without rays probes padded cell (0, 0) from index (8, 8) of an origin of its own)
-        if (GLOBAL && !live) lane_base = (uint32_t)((0 - 8 + 2) * a.distg_pitch + (0 - 8 + 2));
-        const double dpos = GLOBAL ? 8.5 : 2.5;
-        const double lpx = live ? (sxp ? wpx : (double)S - wpx) : dpos, lpy = live ? (syp ? wpy : (double)S - wpy) : dpos;
+        // position in the mirrored frame (the rays of the wedge run towards +x, +y there)
+        const double dpos = 2.5;
+        const double lpx = live ? (sxp ? wpx : (double)Sx - wpx) : dpos, lpy = live ? (syp ? wpy : (double)Sy - wpy) : dpos;
         const double p0x = lpx + kMagic, p0y = lpy + kMagic;
         const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
         const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
         int d0;
-        if (GLOBAL) d0 = (int)gbase[(size_t)(uint32_t)((uint32_t)cy0 * gpitch + (uint32_t)cx0 + lane_base)];      // the own cell (a dead lane: cell (0, 0))
+        if (GLOBAL) d0 = (int)a.distg[(size_t)foff + (size_t)(uint32_t)cy0 * gpitch + (uint32_t)cx0];      // the own cell (a dead lane: cell (2, 2) of the ringed field)
         else d0 = ldsb[((cy0 & (kSwSide - 1)) << 8) | (cx0 & (kSwSide - 1))];
         const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
         // no stop within range: look at sample P only (it is free: the skip says so), which ends the walk with "no hit"
         const uint32_t s0e = (uint32_t)(s0 <= a.P ? s0 : a.P);
         const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
-        // window-relative origin in 2^-24 px, biased by the guard (see MCL_SW_TRIP)
-        const double pscale = GLOBAL ? (double)(1u << fbits) : 16777216.0;
-        const uint32_t P0x = (uint32_t)rint_i32(lpx * pscale - 2147483648.0) + 0x80000000u + guard_units;
-        const uint32_t P0y = (uint32_t)rint_i32(lpy * pscale - 2147483648.0) + 0x80000000u + guard_units;
+        // origin in the mirrored frame in 2^-32 px, biased by the guard (see MCL_SW_TRIP), rounded to nearest by the 2^52 magic add:
+        // fraction in the low dword, cell in the high one (GLOBAL: plus the field's byte offset in the column dword)
+        const double m0x = __builtin_fma(lpx, 4294967296.0, (double)guard_units) + 4503599627370496.0;
+        const double m0y = __builtin_fma(lpy, 4294967296.0, (double)guard_units) + 4503599627370496.0;
+        const unsigned long long P0x = ((unsigned long long)(((uint32_t)__double2hiint(m0x) & 0xFFFFFu) + foff) << 32) | (uint32_t)__double2loint(m0x);
+        const unsigned long long P0y = ((unsigned long long)((uint32_t)__double2hiint(m0y) & 0xFFFFFu) << 32) | (uint32_t)__double2loint(m0y);
         const int rem_start = live ? a.P - (int)s0e : 0;
-        // direction components in the mirrored window: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
-        // (GLOBAL: signed components scaled by exactly 2^fb)
-        const double dsc = GLOBAL ? (double)(1u << fbits) : (sxp ? kSwDirScale : -kSwDirScale);
+        // direction components in the mirrored frame: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
+        const double dsc = sxp ? kSwDirScale : -kSwDirScale;
         const double aq = live ? pci.x * dsc : 0.0, bq = live ? pci.y * dsc : 0.0;
         // A lane whose scan BEGINS or ENDS inside this wedge has fewer beams here than the lanes whose scan covers the wedge
         // (with sixty-four headings 20 degrees apart -- the chunks of a uniform cloud -- anything from 1 to a full wedge's 90),
@@ -697,7 +672,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         const int jfirst = n1 > 0 ? ja : (n2 > 0 ? ja2 : 0);
         const int jwalk = padded && ja == 0 ? jb - tmin : jfirst;       // first (possibly virtual) beam of the lock-step walk
         double acc_fast = 0.0, acc = 0.0;
-        uint32_t ambcnt = 0, ambj1 = 0, ambj2 = 0;
+        uint32_t gwalk = g0;                                       // guard minimum over every sample of the asm walk
         int t_done = 0;
         bool expired_fast = false;
         const bool fast = !COUNT && !want_steps && !wraps && tmax > 0 && tmin > 0;
@@ -716,8 +691,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
-            if constexpr (GLOBAL) { MCL_SWG_WALK(); }
-            else { if (negy) MCL_SW_WALK("-"); else MCL_SW_WALK(""); }
+            if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK("-", "-"); else MCL_SWG_WALK("", ""); }
+            else { if (negy) MCL_SW_WALK("-", "-"); else MCL_SW_WALK("", ""); }
             expired_fast = expired != 0u;
         }
         if (fast) t_done = part + 1u == parts ? tmin : tmax;       // the ragged rest belongs to the last piece
@@ -741,56 +716,53 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     if (wraps && jn == jb && n1 > 0 && t < n1) jn = ja2;    // end of the first range: continue with the second
                     j = min(jn, jlast);
                 }
-                const uint32_t Xx = (uint32_t)rint_i32(__builtin_fma(aq, cs.x, -(bq * cs.y)));
-                const double yd = __builtin_fma(bq, cs.x, aq * cs.y);
-                const uint32_t Xy = (uint32_t)rint_i32(negy ? -yd : yd);
+                // (the same two nested FMAs as MCL_SW_ROTATE: >= 0 by construction)
+                const uint32_t Xx = (uint32_t)__double2loint(__builtin_fma(aq, cs.x, __builtin_fma(-bq, cs.y, 6755399441055745.0)));
+                const uint32_t Xy = negy ? (uint32_t)__double2loint(__builtin_fma(-bq, cs.x, __builtin_fma(-aq, cs.y, 6755399441055745.0)))
+                                         : (uint32_t)__double2loint(__builtin_fma(bq, cs.x, __builtin_fma(aq, cs.y, 6755399441055745.0)));
                 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.beam_cs) + ((uint32_t)j << 4));
                 int rem;
                 uint32_t g;
                 bool expired = false;
                 if (!COUNT && GLOBAL) {
-                    uint32_t Tx, Ty, t0, t1, addr, byte;
                     unsigned long long saved_exec;
                     uint32_t countdown;
                     asm volatile(
                         "s_mov_b64 %[sv], exec\n\t"
                         "s_mov_b32 %[cd], %[cdinit]\n\t"
-                        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]")
+                        MCL_SWG_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[pitch]", "%[gbase]")
                         "s_cbranch_execz 2f\n"
                         "1:\n\t"
-                        MCL_SWG_TRIP("%[rem]", "%[g]", "%[by]", "%[tx]", "%[ty]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[fb]", "%[pitch]", "%[mask]", "%[gbase]", "%[lb]")
+                        MCL_SWG_TRIP("%[rem]", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[pitch]", "%[gbase]")
                         "s_cbranch_execz 2f\n\t"
                         "s_sub_u32 %[cd], %[cd], 1\n\t"
                         "s_cbranch_scc0 1b\n"
                         "2:\n\t"
                         "s_mov_b64 exec, %[sv]"
-                        : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
-                          [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                        : [g] "=&v"(g), [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
                         : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
-                          [mask] "s"(fmask), [fb] "s"(fbits), [pitch] "s"(gpitch), [gbase] "s"(gbase), [cdinit] "s"(cdinit), [lb] "v"(lane_base)
-                        : "memory", "vcc", "scc");
+                          [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit)
+                        : "memory", "vcc", "scc", "v48", "v49", "v52", "v53", "v54", "v55");
                     expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
                 } else if (!COUNT) {
-                    uint32_t Tx, Ty, t0, t1, addr, byte;
                     unsigned long long saved_exec;
                     uint32_t countdown;
                     asm volatile(
                         "s_mov_b64 %[sv], exec\n\t"
                         "s_movk_i32 %[cd], 300\n\t"
-                        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[sel]", "%[mask]", "%[lb]")
+                        MCL_SW_TRIP("%[rem0]", "%[g0]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[lb]")
                         "s_cbranch_execz 2f\n"
                         "1:\n\t"
-                        MCL_SW_TRIP("%[rem]", "%[g]", "%[by]", "%[tx]", "%[ty]", "%[tx]", "%[ty]", "%[t0]", "%[t1]", "%[ad]", "%[by]", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[sel]", "%[mask]", "%[lb]")
+                        MCL_SW_TRIP("%[rem]", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "%[rem]", "%[xx]", "%[xy]", "%[lb]")
                         "s_cbranch_execz 2f\n\t"
                         "s_sub_u32 %[cd], %[cd], 1\n\t"
                         "s_cbranch_scc0 1b\n"
                         "2:\n\t"
                         "s_mov_b64 exec, %[sv]"
-                        : [tx] "=&v"(Tx), [ty] "=&v"(Ty), [t0] "=&v"(t0), [t1] "=&v"(t1), [ad] "=&v"(addr), [by] "=&v"(byte), [g] "=&v"(g),
-                          [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
+                        : [g] "=&v"(g), [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
                         : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
-                          [mask] "s"(fmask), [sel] "s"(permsel), [lb] "n"(kQLdsBase)
-                        : "memory", "vcc", "scc");
+                          [lb] "n"(kQLdsBase)
+                        : "memory", "vcc", "scc", "v48", "v49", "v52", "v53", "v54", "v55");
                     // the countdown only expires if the window is malformed (impossible): every ray of the pass to the fix-up list
                     expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
                 } else {
@@ -798,19 +770,15 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     int trips = 0;
                     rem = rem_start;
                     g = g0;
-                    uint32_t Tx = P0x, Ty = P0y, by = s0e;
+                    unsigned long long Tx = P0x, Ty = P0y;
+                    uint32_t by = s0e;
                     do {
-                        if (GLOBAL) {                     // signed components (v_mad_i32_i24)
-                            Tx += (uint32_t)((int)by * (int)Xx);
-                            Ty += (uint32_t)((int)by * (int)Xy);
-                        } else {
-                            Tx += (by & 0xFFFFFFu) * (Xx & 0xFFFFFFu);
-                            Ty += (by & 0xFFFFFFu) * (Xy & 0xFFFFFFu);
-                        }
-                        const uint32_t gm = (Tx & fmask) < (Ty & fmask) ? (Tx & fmask) : (Ty & fmask);
+                        Tx += (unsigned long long)by * Xx;
+                        Ty += (unsigned long long)by * Xy;
+                        const uint32_t gm = (uint32_t)Tx < (uint32_t)Ty ? (uint32_t)Tx : (uint32_t)Ty;
                         g = g < gm ? g : gm;
-                        if (GLOBAL) by = (uint32_t)(int)(int8_t)gbase[(size_t)(uint32_t)((Ty >> fbits) * gpitch + (Tx >> fbits) + lane_base)];
-                        else by = (uint32_t)(int)(int8_t)ldsb[((Ty >> kSwFx) << 8) | (Tx >> kSwFx)];
+                        if (GLOBAL) by = (uint32_t)(int)(int8_t)a.distg[(size_t)(uint32_t)((uint32_t)(Ty >> 32) * gpitch + (uint32_t)(Tx >> 32))];
+                        else by = (uint32_t)(int)(int8_t)ldsb[(((uint32_t)(Ty >> 32) & (kSwSide - 1)) << 8) | ((uint32_t)(Tx >> 32) & (kSwSide - 1))];
                         uint32_t nr;
                         const bool over = __builtin_usub_overflow((uint32_t)rem, by, &nr);
                         go = !over;
@@ -836,20 +804,17 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             }
             acc += lt_pending;
         }
-        // undecided rays of the asm walk: up to two per lane were parked; a lane with more (or an expired countdown)
-        // hands its whole range of that walk to the fix-up list and drops what it summed there
-        if (expired_fast) ambcnt = 3u;
-        if (!live) ambcnt = 0u;                                    // a lane without rays traces a dummy ray: nothing to redo
-        if (ambcnt != 0u) {
-            const int nlist = ambcnt > 2u ? walk_n : (int)ambcnt;
+        // A lane of the asm walk with a sample inside the guard (one walk in several thousand: the guard is 2^-22 px wide), or
+        // an expired countdown: the real beams of its walk go to the fix-up list and what it summed there is dropped
+        if (live && walk_n > 0 && (expired_fast || gwalk < gthresh)) {
             const int jr0 = n1 > 0 ? ja : ja2, jr1 = n1 > 0 ? jb : a.B;      // the lane's real beams of this walk (virtual ones add 0 whatever they hit)
-            for (int k = 0; k < nlist; ++k) {
-                const int jamb = ambcnt > 2u ? jwalk + walk_t0 + k : (int)((k == 0 ? ambj1 : ambj2) >> 4) - 1 - a.beam_margin;
+            for (int k = 0; k < walk_n; ++k) {
+                const int jamb = jwalk + walk_t0 + k;
                 if (jamb < jr0 || jamb >= jr1) continue;
                 const unsigned int fslot = atomicAdd(&fixn_sh, 1u);
                 if (fslot < a.fix_cap) fix_seg[fslot] = ((unsigned long long)sl << 16) | (unsigned long long)(jamb & 0xFFFF);
             }
-            if (ambcnt > 2u) acc_fast = 0.0;
+            acc_fast = 0.0;
         }
         // the sum of this particle's rays in this wedge joins the slot's accumulator: one fp64 atomic per (slot, wedge), a wave's
         // sixty-four on 512 contiguous bytes; exact and order-independent (E4).  Round 2 kept one partial-sum array per wedge

@@ -100,4 +100,30 @@ MCL_HD inline int wedge_skip_cell(const int32_t *nxt, const int32_t *prv, int Wp
     return (int)(rt + 1);
 }
 
+// Layout of the sixteen mirrored, ringed wedge fields k_rays_sweep<.., GLOBAL> probes in place (mcl_rays_sweep.h, k_ring_field),
+// and the proof obligation that goes with it: the kernel forms the byte offset  row * pitch + column  from the START of the
+// allocation, with column = k * stride + cell column.  A walk of field k starts in a cell of the ringed grid (row < Hp + 4,
+// column < Wp + 4 <= pitch), runs towards +x, +y only and advances by at most P samples of at most one cell per axis in total
+// (a skip larger than the samples left ends the walk before the jump is made; the start's fraction and the guard bias add
+// less than one more cell), so the largest offset it can form is
+//   k * stride + (Hp + 4 + P) * pitch + (Wp + 4 + P)   =  sweep_global_max_offset(k)
+// which must lie inside field k's own stride (rows of stop bytes behind the ringed grid: the tail), and the whole allocation
+// below 2^32 (the offset is a 32-bit VGPR); the multiplicands of the kernel's v_mad_u32_u24 (row, pitch) must fit 24 bits.
+struct SweepGlobalLayout { bool ok; int pitch; int rows; size_t stride, alloc; };
+inline SweepGlobalLayout sweep_global_layout(int Wp, int Hp, int P)
+{
+    SweepGlobalLayout g{};
+    g.pitch = (Wp + 4 + 63) & ~63;
+    const int tail = P + 2 + (P + 4 + g.pitch - 1) / g.pitch;        // rows the walk can run past the ringed grid, column overflow included
+    g.rows = Hp + 4 + tail;
+    g.stride = (size_t)g.rows * (size_t)g.pitch;
+    g.alloc = g.stride * (size_t)kWedges;
+    g.ok = g.alloc < ((size_t)1 << 32) && g.rows + P < (1 << 24) && g.pitch < (1 << 24) && P >= 1;
+    return g;
+}
+inline size_t sweep_global_max_offset(const SweepGlobalLayout &g, int Wp, int Hp, int P, int k)
+{
+    return (size_t)k * g.stride + (size_t)(Hp + 4 + P) * (size_t)g.pitch + (size_t)(Wp + 4 + P);
+}
+
 }  // namespace mcl

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcl_hip_engine.so")
+# (MCL_LIB: another build of the same library, for A/B runs on one box -- a development aid, never set by the product or the tests)
+LIB_PATH = os.environ.get("MCL_LIB") or os.path.join(_HERE, "libmcl_hip_engine.so")
 
 MCL_OK = 0
 MCL_ERR_NOT_READY = -2
