@@ -46,7 +46,9 @@ typedef enum {
     MCL_ERR_NOT_READY = -2,     /* map / beam angles / particles not set yet        */
     MCL_ERR_HIP = -3,           /* a HIP runtime call failed; see mcl_last_error()  */
     MCL_ERR_NO_DEVICE = -4,     /* no gfx950 device visible                         */
-    MCL_ERR_UNSUPPORTED = -5    /* e.g. ray steps requested but not kept            */
+    MCL_ERR_UNSUPPORTED = -5,   /* e.g. ray steps requested but not kept            */
+    MCL_ERR_PEER = -6,          /* sharded update: another rank reported a failure; the update is void on every rank */
+    MCL_ERR_TIMEOUT = -7        /* sharded update: a collective did not finish in time; the communicator was aborted  */
 } mcl_status;
 
 typedef enum {

@@ -2596,6 +2596,14 @@ __global__ __launch_bounds__(kRedThreads) void k_final_max(const double *__restr
 }
 
 __global__ void k_copy_double(const double *__restrict__ src, double *__restrict__ dst) { dst[0] = src[0]; }
+__global__ void k_set_double(double *__restrict__ dst, double v) { dst[0] = v; }
+// keeps a stream busy for `ms` milliseconds (at most two seconds): the test switch of the sharded update's bounded wait
+__global__ void k_spin_ms(double ms)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
+    const unsigned long long ticks = (unsigned long long)((ms < 2000.0 ? ms : 2000.0) * 1e5);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 
 // mcl_group_update: the maximum over the shards' maxima, read where they live (peer pointers)
 struct GroupMaxArgs { const double *src[kMaxShards]; int n; double *out; };

@@ -344,6 +344,30 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
 //  branches only; the countdown and its taken branch cost a wave ~20 cycles per trip in a chain that is latency-bound,
 //  tools/ubench/trip_rates.hip)
 #define MCL_SW_TRIP_NEXT MCL_SW_TRIP("v57", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]")
+// (timing-only experiment switches of tools/ab: never defined by the product build)
+#ifdef MCL_EXP_ROW0
+#define MCL_EXP_TABLE_OFFSET "v_mad_i32_i24 v48, v57, 0, %[zoff]\n\t"
+#else
+#define MCL_EXP_TABLE_OFFSET "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"
+#endif
+#if defined(MCL_EXP_RECUR)
+// next beam's direction by rotating this beam's by the scan increment (timing only: no load, six more VALU)
+#define MCL_EXP_DIR_LOAD "v_mul_f64 v[48:49], v[42:43], %[sdl]\n\t" "v_fma_f64 v[52:53], v[40:41], %[cdl], -v[48:49]\n\t" \
+                         "v_mul_f64 v[48:49], v[40:41], %[sdl]\n\t" "v_fma_f64 v[54:55], v[42:43], %[cdl], v[48:49]\n\t" \
+                         "v_mov_b64 v[40:41], v[52:53]\n\t" "v_mov_b64 v[42:43], v[54:55]\n\t"
+#define MCL_EXP_WAIT2 "s_waitcnt vmcnt(0)\n\t"
+#elif defined(MCL_EXP_NODIR)
+#define MCL_EXP_DIR_LOAD "s_nop 0\n\t"
+#define MCL_EXP_WAIT2 "s_waitcnt vmcnt(0)\n\t"
+#else
+#define MCL_EXP_DIR_LOAD "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"
+#define MCL_EXP_WAIT2 "s_waitcnt vmcnt(1)\n\t"
+#endif
+#if defined(MCL_EXP_RECUR)
+#define MCL_EXP_EXTRA_OPERANDS , [cdl] "s"(exp_cdl), [sdl] "s"(exp_sdl)
+#else
+#define MCL_EXP_EXTRA_OPERANDS
+#endif
 #define MCL_SW_WALK(NEGA, NEGB)                                                                                                \
     asm volatile(                                                                                                              \
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_waitcnt vmcnt(1)\n\t" /* direction landed (the table entry may be in flight) */                                     \
         MCL_SW_ROTATE(NEGA, NEGB)                                                                                              \
         "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
-        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t" /* next beam's direction */                                         \
+        MCL_EXP_DIR_LOAD /* next beam's direction */                                                                           \
         "s_movk_i32 %[cd], 50\n\t"                                                                                             \
         MCL_SW_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]") \
         "s_cbranch_execz 2f\n"                                                                                                 \
@@ -369,9 +393,9 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_mov_b32 %[expired], 1\n" /* malformed window (impossible): the pass is redone by the fix-up path */                 \
         "2:\n\t"                                                                                                               \
         "s_mov_b64 exec, -1\n\t"                                                                                               \
-        "s_waitcnt vmcnt(1)\n\t" /* previous beam's table entry landed */                                                      \
+        MCL_EXP_WAIT2 /* previous beam's table entry landed */                                                                 \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
-        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
+        MCL_EXP_TABLE_OFFSET                                                                                                   \
         "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"                                                                                \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
         "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
         : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                     \
           [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8),                        \
-          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase) MCL_EXP_EXTRA_OPERANDS                       \
         : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",    \
           "v53", "v54", "v55", "v57")
 
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_mov_b64 exec, -1\n\t"                                                                                               \
         "s_waitcnt vmcnt(1)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
-        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
+        MCL_EXP_TABLE_OFFSET                                                                                                   \
         "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"                                                                                \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
         "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
@@ -691,6 +715,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
+#if defined(MCL_EXP_RECUR)
+            const double exp_cdl = cos(1.0 / a.beam_inv_inc), exp_sdl = sin(1.0 / a.beam_inv_inc);
+#endif
             if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK("-", "-"); else MCL_SWG_WALK("", ""); }
             else { if (negy) MCL_SW_WALK("-", "-"); else MCL_SW_WALK("", ""); }
             expired_fast = expired != 0u;

@@ -34,6 +34,16 @@ integer scan and the log-weights are exact fp64 sums, resample indices and weigh
 for any number of ranks.  (Several GPUs driven by ONE process do the same through `mcl_group_*` in the
 library itself, with peer copies and peer pointers instead of collectives.)
 
+Failure protocol (a rank that fails must not hang its peers): every update ends with the SUM all-reduce, and that vector carries one
+more element, the ERROR WORD -- the number of ranks that failed in this update.  A rank whose engine call fails (or that finds its
+state inconsistent, or MCL_DIST_FAIL="<rank>:<update>:<call prefix>" says so: the test switch) stops its local work but STILL
+ENTERS EVERY COLLECTIVE of the update with the agreed sizes (`_local` wraps every engine call of an update; a rank that has failed
+requests no parents, answers requests with whatever its buffers hold, contributes -inf and a zero vector) and raises the word.
+After the exchange EVERY rank raises engine.ShardedUpdateError from the same update (`.local` tells whose failure it was); the
+particle set must be set or initialised again (set_particles / reset()) before the next update.  What this cannot cover -- a rank
+that dies or never arrives -- is bounded by the process group's timeout (torch.distributed.init_process_group(timeout=...)) in
+this flow and by MCL_COMM_TIMEOUT_MS in the native one (include/mcl_hip_engine.h: mcl_comm_update).
+
 `shard` is anything with the staging interface of engine.Engine (compact_list / export_compact / stage_resample_compact /
 export_state / scan_weights / stage_resample_indices / stage_distinct_parents / export_records_at / stage_motion_records /
 stage_rays / scalars / stage_weights / stage_finish); tests drive this class on CPU tensors over gloo with an oracle-backed
@@ -47,6 +57,8 @@ import sys
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from .engine import ShardedUpdateError
 
 
 class ShardedFilter:
@@ -89,8 +101,9 @@ class ShardedFilter:
         # the two small all-reduces of an update go through tensors made once (a fresh device tensor per update is an
         # allocation and a blocking copy each way: 0.1 ms of the update at 4M particles)
         # ([0]: the MAX exchange, [1:]: the SUM exchange with two more elements: the ray stage's overflow flag and sum w^2)
-        self.red_dev = torch.zeros(1 + 5 + 3 * self.world + 2, dtype=torch.float64, device=device)
-        self.red_host = torch.zeros(1 + 5 + 3 * self.world + 2, dtype=torch.float64)
+        # ... and, last, the error word of the failure protocol (ranks that failed in this update)
+        self.red_dev = torch.zeros(1 + 5 + 3 * self.world + 2 + 1, dtype=torch.float64, device=device)
+        self.red_host = torch.zeros(1 + 5 + 3 * self.world + 2 + 1, dtype=torch.float64)
         if device.type == "cuda":
             self.red_host = self.red_host.pin_memory()
         # device-ordered update (one host wait per update, the exchanged scalars never leave the device): needs the engine's
@@ -109,9 +122,23 @@ class ShardedFilter:
         self.kept_last = False
         self.native = False
         self.native_updates = 0                                           # consecutive updates the native call has run
-        if (self.device_ordered and hasattr(shard, "comm_update") and os.environ.get("MCL_DIST_NATIVE") != "0"
+        # (opt-in, MCL_DIST_NATIVE=1: no RCCL call of the engine's own communicator has run with more than one rank yet -- no
+        #  multi-GPU box in any round -- so the default on a node is torch's collectives, whose RCCL use is the common one)
+        if (self.device_ordered and hasattr(shard, "comm_update") and os.environ.get("MCL_DIST_NATIVE") == "1"
                 and dist.get_backend(group) == "nccl"):
             self.native = self._make_native_comm()
+        # failure protocol: what this rank found wrong in the current update (None: nothing), the update count, the test switch
+        self._err = None
+        self._pending_err = None                                          # a failure while preparing the NEXT update's exchange
+        self.updates = 0
+        self._fail_at = None
+        spec = os.environ.get("MCL_DIST_FAIL")
+        if spec:
+            try:
+                r, u, name = spec.split(":", 2)
+                self._fail_at = (int(r), int(u), name)
+            except ValueError:
+                raise ValueError("MCL_DIST_FAIL must be <rank>:<update>:<engine call prefix>") from None
 
     @property
     def host_waits(self):
@@ -166,6 +193,34 @@ class ShardedFilter:
             pass
         return False
 
+    # ---- failure protocol
+    def _local(self, name, *args, default=None):
+        """An engine call of the current update.  Skipped once this rank has failed; a failure is NOTED, not raised: the
+        collectives of the update go on and the error word tells every rank."""
+        if self._err is not None:
+            return default
+        f = self._fail_at
+        if f is not None and f[0] == self.rank and f[1] == self.updates and name.startswith(f[2]):
+            self._err = RuntimeError(f"injected failure before {name} (MCL_DIST_FAIL)")
+            return default
+        try:
+            return getattr(self.shard, name)(*args)
+        except Exception as ex:                        # noqa: BLE001 -- whatever the engine raised: this rank has failed
+            self._err = ex
+            return default
+
+    def _void(self, failed_ranks):
+        """Every rank arrives here from the same update: forget what the exchange knew and raise."""
+        err, self._err = self._err, None
+        self.pending_q = self.pending_list = None
+        self.q_total = self.counts = self.totals = None
+        self.last_sw = self.last_sww = None
+        self.native_updates = 0
+        if err is not None:
+            raise ShardedUpdateError(f"rank {self.rank}: {err} [sharded update void on every rank]", getattr(err, "status", None), local=True) from err
+        raise ShardedUpdateError(f"rank {self.rank}: {int(failed_ranks)} rank(s) of the sharded set reported a failure in this update: it is void on "
+                                 "every rank (set or initialise the particles again)", -6, local=False)
+
     def _all_reduce_small(self, values, op):
         """values (a short float64 sequence) -> their reduction over the ranks, as a numpy array."""
         k = len(values)
@@ -193,6 +248,7 @@ class ShardedFilter:
         self.q_total = None
         self.counts = self.totals = None
         self.last_sw = self.last_sww = None
+        self._err = self._pending_err = None
         if self.native:
             self.shard.comm_set_lists([-1] * self.world, [0] * self.world)      # no lists: the next update is a dense one on every rank
             self.native_updates = 0
@@ -211,7 +267,7 @@ class ShardedFilter:
             self.chunk_local = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self.chunk_all = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
         if int(self.counts[self.rank]) > 0:
-            self.shard.export_compact(self.chunk_local.data_ptr(), entries)
+            self._local("export_compact", self.chunk_local.data_ptr(), entries)
         self._sync()
         work = dist.all_gather_into_tensor(self.chunk_all[:nbytes * self.world], self.chunk_local[:nbytes], group=self.group, async_op=async_op)
         return (work if async_op else None), entries
@@ -224,10 +280,10 @@ class ShardedFilter:
             self.chunk_local = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self.chunk_all = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
         ts = torch.cuda.current_stream(self.device).cuda_stream
-        self.shard.stream_wait_external(ts)          # (the buffers may be fresh, or still read by the previous update's collective)
+        self._local("stream_wait_external", ts)      # (the buffers may be fresh, or still read by the previous update's collective)
         if int(self.counts[self.rank]) > 0:
-            self.shard.export_compact_async(self.chunk_local.data_ptr(), entries)
-        self.shard.external_wait_stream(ts)
+            self._local("export_compact_async", self.chunk_local.data_ptr(), entries)
+        self._local("external_wait_stream", ts)
         work = dist.all_gather_into_tensor(self.chunk_all[:nbytes * self.world], self.chunk_local[:nbytes], group=self.group, async_op=async_op)
         return (work if async_op else None), entries
 
@@ -242,8 +298,8 @@ class ShardedFilter:
             self.pending_list = None
             self._exchange_bytes.update(kind="none", list_bytes_received=0, list_payload_bytes=0, weights_received=0,
                                         requests_sent=0, records_received=0, distinct_remote_parents=0)
-            s.stream_wait_external(ts)
-            s.stage_keep(self.rank * self.n, self.n_total, action)
+            self._local("stream_wait_external", ts)
+            self._local("stage_keep", self.rank * self.n, self.n_total, action)
             return self._ordered_after_children(obs, ts)
         if self.pending_list is not None:
             work, entries = self.pending_list                             # issued at the end of the previous update
@@ -256,25 +312,33 @@ class ShardedFilter:
         self._exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (world - 1),
                                    list_payload_bytes=44 * (listed - int(self.counts[self.rank])), weights_received=0,
                                    requests_sent=0, records_received=0, distinct_remote_parents=0)
-        s.stream_wait_external(ts)
-        s.stage_resample_compact_async(self.chunk_all.data_ptr(), world, entries, self.counts, self.totals, self.n, self.rank,
-                                       self.rank * self.n, self.n_total, action)
+        self._local("stream_wait_external", ts)
+        self._local("stage_resample_compact_async", self.chunk_all.data_ptr(), world, entries, self.counts, self.totals, self.n, self.rank,
+                    self.rank * self.n, self.n_total, action)
         return self._ordered_after_children(obs, ts)
 
     def _ordered_after_children(self, obs, ts):
         s, world = self.shard, self.world
         k = 5 + 3 * world + 2
-        s.stage_rays_async(obs, self.red_dev.data_ptr())                 # local max log-weight -> red_dev[0]
-        s.external_wait_stream(ts)
+        self._local("stage_rays_async", obs, self.red_dev.data_ptr())    # local max log-weight -> red_dev[0]
+        self._local("external_wait_stream", ts)
+        if self._err is not None:
+            self.red_dev[:1].fill_(float("-inf"))
         dist.all_reduce(self.red_dev[:1], op=dist.ReduceOp.MAX, group=self.group)
-        s.stream_wait_external(ts)
-        vec = self.red_dev[1:1 + k]
-        s.stage_weights_async(self.red_dev.data_ptr(), vec.data_ptr(), world, self.rank)
-        s.external_wait_stream(ts)
+        self._local("stream_wait_external", ts)
+        vec = self.red_dev[1:1 + k + 1]                                   # the summed vector and, behind it, the error word
+        self._local("stage_weights_async", self.red_dev.data_ptr(), vec.data_ptr(), world, self.rank)
+        self._local("external_wait_stream", ts)
+        if self._err is not None:
+            vec.zero_()
+        vec[k:].fill_(0.0 if self._err is None else 1.0)
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
-        self.red_host[:1 + k].copy_(self.red_dev[:1 + k], non_blocking=True)
+        self.red_host[:1 + k + 1].copy_(self.red_dev[:1 + k + 1], non_blocking=True)
         self._sync()                                                      # THE host wait of the update
         gs = self.red_host[1:1 + k].numpy().copy()
+        failed = float(self.red_host[1 + k])
+        if failed != 0.0 or self._err is not None:
+            self._void(failed)
         s.stage_complete(gs[:5])
         if gs[-2] != 0.0:
             # some shard's fix-up lists overflowed (debug_force_exact at size, a pathological map): every rank runs the ray stage
@@ -286,7 +350,8 @@ class ShardedFilter:
         """self.parent (global indices) -> (distinct parents ascending = grouped by owner, position of every child's parent
         among them): a bitmap over the global indices and its popcount prefix inside the engine (passes over
         n_total / 32 words, not n_total elements)."""
-        k = self.shard.stage_distinct_parents(self.parent.data_ptr(), self.n, self.n_total, self.uniq_buf.data_ptr(), self.slot_buf.data_ptr())
+        k = self._local("stage_distinct_parents", self.parent.data_ptr(), self.n, self.n_total, self.uniq_buf.data_ptr(), self.slot_buf.data_ptr(),
+                        default=0)              # (a rank that has failed requests no parents)
         return self.uniq_buf[:k], self.slot_buf
 
     def _records_at(self, local_idx, out):
@@ -294,7 +359,7 @@ class ShardedFilter:
         if local_idx.numel() == 0:
             return out
         self._sync()                 # the engine has its own stream: the indices (tensor ops / a collective) must be complete
-        self.shard.export_records_at(local_idx.data_ptr(), int(local_idx.numel()), out.data_ptr())
+        self._local("export_records_at", local_idx.data_ptr(), int(local_idx.numel()), out.data_ptr())
         return out
 
     def _fetch_parents(self):
@@ -341,29 +406,31 @@ class ShardedFilter:
         self._exchange_bytes.update(kind="lists", list_bytes_received=44 * entries * (self.world - 1),
                                    list_payload_bytes=44 * (listed - int(self.counts[self.rank])), weights_received=0,
                                    requests_sent=0, records_received=0, distinct_remote_parents=0)
-        self.shard.stage_resample_compact(self.chunk_all.data_ptr(), self.world, entries, self.counts, self.totals, self.n, self.rank,
-                                          self.rank * self.n, self.n_total, action)
+        self._local("stage_resample_compact", self.chunk_all.data_ptr(), self.world, entries, self.counts, self.totals, self.n, self.rank,
+                    self.rank * self.n, self.n_total, action)
 
     def _resample_dense(self, action):
         s = self.shard
         if self.pending_q is None:
-            s.export_state(0, 0, 0, self.loc_q.data_ptr())
+            self._local("export_state", 0, 0, 0, self.loc_q.data_ptr())
             dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group)
         else:
             self.pending_q.wait()                                        # issued at the end of the previous update
             self.pending_q = None
         self._sync()
         self._exchange_bytes.update(kind="dense", weights_received=8 * self.n * (self.world - 1), list_bytes_received=0, list_payload_bytes=0)
-        s.scan_weights(self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
+        self._local("scan_weights", self.glob_q.data_ptr(), self.glob_cdf.data_ptr(), self.n_total, 0)
         q_total = self.q_total if self.q_total is not None else int(self.glob_cdf[-1].item()) & 0xFFFFFFFFFFFFFFFF
-        s.stage_resample_indices(self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, self.parent.data_ptr())
+        self._local("stage_resample_indices", self.glob_cdf.data_ptr(), self.n_total, q_total, self.rank * self.n, self.n_total, self.parent.data_ptr())
         table, slot = self._fetch_parents()
         self._sync()
-        s.stage_motion_records(table.data_ptr(), int(table.shape[0]), slot.data_ptr(), self.rank * self.n, self.n_total, action)
+        self._local("stage_motion_records", table.data_ptr(), int(table.shape[0]), slot.data_ptr(), self.rank * self.n, self.n_total, action)
 
     def update(self, action, obs):
         s = self.shard
         self._host_waits = 0
+        self.updates += 1
+        self._err, self._pending_err = self._pending_err, None            # (a failure while preparing this update's exchange is this update's)
         gs = None
         keep = False
         if self.neff_permille > 0 and self.last_sw is not None and not self.native:
@@ -372,16 +439,18 @@ class ShardedFilter:
         # (1) exchange for resampling + the children
         if self.native:
             # the whole update in one native call -- lists, or the dense exchange when there are none (first update) -- on the
-            # engine's stream.  (None: the communicator declined without touching anything; dist.py's own dense exchange then.)
-            pose = s.comm_update(action, obs)
-            if pose is not None:
-                self.pose = pose
-                self.native_updates += 1
-                self.q_total = self.counts = self.totals = None           # (the communicator keeps them now)
-                self.kept_last = bool(s.comm_stats()["kept"]) if self.neff_permille > 0 else False
-                return pose
-            self.native_updates = 0
-            self._resample_dense(action)
+            # engine's stream.  A failure on any rank raises ShardedUpdateError on every rank (the engine's own protocol).
+            try:
+                pose = s.comm_update(action, obs)
+            except ShardedUpdateError:
+                self.native_updates = 0
+                self.q_total = self.counts = self.totals = None
+                raise
+            self.pose = pose
+            self.native_updates += 1
+            self.q_total = self.counts = self.totals = None               # (the communicator keeps them now)
+            self.kept_last = bool(s.comm_stats()["kept"]) if self.neff_permille > 0 else False
+            return pose
         elif self.device_ordered and (keep or self._lists_usable()):
             gs = self._update_ordered(action, obs, keep)                 # the whole update; None: once more from the ray stage on
         elif keep:
@@ -393,7 +462,7 @@ class ShardedFilter:
             self._sync()
             self._exchange_bytes.update(kind="none", list_bytes_received=0, list_payload_bytes=0, weights_received=0,
                                         requests_sent=0, records_received=0, distinct_remote_parents=0)
-            s.stage_keep(self.rank * self.n, self.n_total, action)
+            self._local("stage_keep", self.rank * self.n, self.n_total, action)
         elif self._lists_usable():
             self._resample_from_lists(action)
         else:
@@ -410,18 +479,17 @@ class ShardedFilter:
         self.q_total = int(sum(int(t) for t in self.totals)) & 0xFFFFFFFFFFFFFFFF
         gs = gs[:5]
         s.stage_finish(gs)
-        if self.native:
-            s.comm_set_lists(self.counts, self.totals)      # what the next (native) update's list exchange works from
         next_keeps = (self.neff_permille > 0 and self.last_sww > 0.0
                       and self.last_sw * self.last_sw >= (self.neff_permille / 1000.0) * float(self.n_total) * self.last_sww)
         if self.overlap and not next_keeps:
             # this update's weights are final: start the exchange of the next update now, beside the host work between updates
+            # (a failure of these engine calls belongs to the NEXT update: its exchange is entered all the same, then it is void)
             if self._lists_usable():
-                if not self.native:                  # (the native update gathers on the engine's stream, first thing)
-                    self.pending_list = (self._start_list_gather_ordered if self.device_ordered else self._start_list_gather)(True)
+                self.pending_list = (self._start_list_gather_ordered if self.device_ordered else self._start_list_gather)(True)
             else:
-                s.export_state(0, 0, 0, self.loc_q.data_ptr())
+                self._local("export_state", 0, 0, 0, self.loc_q.data_ptr())
                 self.pending_q = dist.all_gather_into_tensor(self.glob_q, self.loc_q, group=self.group, async_op=True)
+            self._pending_err, self._err = self._err, None
         k = 1.0 / gs[0] if gs[0] > 0 else 1.0
         self.pose = np.array([gs[1] * k, gs[2] * k, np.arctan2(gs[3] * k, gs[4] * k)])
         return self.pose
@@ -430,20 +498,29 @@ class ShardedFilter:
         """Ray stage, MAX exchange, weights, SUM exchange -- stage by stage, the host reading each value (first update, dense
         exchange, the CPU stand-in, the redo after an overflow).  Returns the summed vector."""
         s = self.shard
-        s.stage_rays(obs)
+        self._local("stage_rays", obs)
         # (2) global max log-weight
-        read = getattr(s, "host_scalars", s.scalars)                      # the stage calls already read SCALARS back
-        s.stage_weights(float(self._all_reduce_small([read()[0]], dist.ReduceOp.MAX)[0]))
+        read = "host_scalars" if hasattr(s, "host_scalars") else "scalars"      # the stage calls already read SCALARS back
+        sc = self._local(read)
+        local_max = float(sc[0]) if self._err is None else float("-inf")
+        self._local("stage_weights", float(self._all_reduce_small([local_max], dist.ReduceOp.MAX)[0]))
         # (3) global sums: sum w, sum wx, sum wy, sum w sin, sum w cos; per rank (filled by that rank only): list length + 1
-        # (0: no list) and the two halves of its fixed-point weight total
-        sc = read()
-        ql = int(np.float64(sc[2]).view(np.uint64))                      # this shard's fixed-point weight total
-        n_list = s.compact_list()[0] if self.use_lists else -1
-        vec = np.zeros(5 + 3 * self.world + 1)
-        vec[:5] = (sc[1], sc[3], sc[4], sc[5], sc[6])
-        vec[5 + 3 * self.rank: 8 + 3 * self.rank] = (float(n_list + 1), float(ql & 0xFFFFFFFF), float(ql >> 32))
-        vec[-1] = sc[7] if len(sc) > 7 else 0.0                          # sum w^2 (adaptive resampling)
-        return self._all_reduce_small(vec, dist.ReduceOp.SUM)
+        # (0: no list) and the two halves of its fixed-point weight total; sum w^2; the error word
+        sc = self._local(read)
+        cl = self._local("compact_list") if self.use_lists else None
+        vec = np.zeros(5 + 3 * self.world + 2)
+        if self._err is None:
+            ql = int(np.float64(sc[2]).view(np.uint64))                  # this shard's fixed-point weight total
+            n_list = cl[0] if cl is not None else -1
+            vec[:5] = (sc[1], sc[3], sc[4], sc[5], sc[6])
+            vec[5 + 3 * self.rank: 8 + 3 * self.rank] = (float(n_list + 1), float(ql & 0xFFFFFFFF), float(ql >> 32))
+            vec[-2] = sc[7] if len(sc) > 7 else 0.0                      # sum w^2 (adaptive resampling)
+        else:
+            vec[-1] = 1.0
+        out = self._all_reduce_small(vec, dist.ReduceOp.SUM)
+        if out[-1] != 0.0 or self._err is not None:
+            self._void(out[-1])
+        return out[:-1]
 
     def set_particles(self, xyz_colmajor, weights):
         """Host-supplied particles for this shard (any non-negative weights): every shard quantises its weights against the

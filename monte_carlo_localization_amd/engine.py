@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("MCL_LIB") or os.path.join(_HERE, "libmcl_hip_engine.s
 
 MCL_OK = 0
 MCL_ERR_NOT_READY = -2
+MCL_ERR_PEER = -6          # sharded update: another rank reported a failure; the update is void on every rank
+MCL_ERR_TIMEOUT = -7       # sharded update: a collective did not finish in time; the communicator was aborted
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 WEIGHT_LOG, WEIGHT_PRODUCT = 0, 1
 RAYS_AUTO, RAYS_MARCH, RAYS_SKIP, RAYS_QUAD, RAYS_CELL, RAYS_SWEEP = 0, 1, 2, 3, 4, 5
@@ -56,7 +58,21 @@ class Config(C.Structure):
 
 
 class EngineError(RuntimeError):
-    pass
+    """A call through the C ABI returned a negative mcl_status; `.status` holds it."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+class ShardedUpdateError(EngineError):
+    """An update of a SHARDED set is void on every rank: this rank failed locally (`.local` is True, the message says how) or
+    another rank did (MCL_ERR_PEER), or a collective ran out of time and the communicator was aborted (MCL_ERR_TIMEOUT).  Every
+    rank raises from the same update; the particle set must be set or initialised again on every rank before the next one."""
+
+    def __init__(self, msg, status=None, local=False):
+        super().__init__(msg, status)
+        self.local = local
 
 
 _lib = None
@@ -193,7 +209,7 @@ class Engine:
 
     def _chk(self, rc, what):
         if rc != MCL_OK:
-            raise EngineError(f"{what} rc={rc}: {self.lib.mcl_last_error(self._h).decode()}")
+            raise EngineError(f"{what} rc={rc}: {self.lib.mcl_last_error(self._h).decode()}", rc)
 
     # -- map / beams
     def set_map(self, grid, resolution, origin_x, origin_y):
@@ -541,15 +557,16 @@ class Engine:
         self._chk(self.lib.mcl_comm_set_lists(self._h, _p(c), _p(t)), "mcl_comm_set_lists")
 
     def comm_update(self, action, obs):
-        """One sharded update in one native call; the pose of the whole set, or None when this update needs the dense exchange
-        (no lists yet: nothing was touched)."""
+        """One sharded update in one native call (lists, or the dense exchange when there are none); the pose of the whole set.
+        Any failure -- this rank's, a peer's, a collective that ran out of time -- raises ShardedUpdateError on EVERY rank from
+        the same update (include/mcl_hip_engine.h: the failure protocol of mcl_comm_update); nothing falls back to another exchange."""
         a = _c(action, np.float64)
         o = _c(obs, np.float32)
         pose = np.zeros(3)
         rc = self.lib.mcl_comm_update(self._h, _p(a), _p(o), C.c_int32(o.size), _p(pose))
-        if rc == MCL_ERR_NOT_READY:
-            return None
-        self._chk(rc, "mcl_comm_update")
+        if rc != MCL_OK:
+            raise ShardedUpdateError(f"mcl_comm_update rc={rc}: {self.lib.mcl_last_error(self._h).decode()}", rc,
+                                     local=rc not in (MCL_ERR_PEER, MCL_ERR_TIMEOUT))
         return pose
 
     def comm_vector(self):

@@ -66,8 +66,28 @@ def main():
     if skewed:
         sf.set_particles(p[:, mine], w)                 # every shard quantises against the maximum of the whole set
     poses, kinds, waits, kept, neff = [], [], [], [], []
-    for _ in range(steps):
-        poses.append(sf.update((0.05, 0.0, 0.01), obs))
+    # MCL_TEST_EXPECT_FAIL=1 (the failure protocol, dist.py): an update may raise ShardedUpdateError -- on EVERY rank, from the same
+    # update; the worker notes (update, whose failure, seconds), initialises the particle set again and goes on
+    expect_fail = os.environ.get("MCL_TEST_EXPECT_FAIL") == "1"
+    failures = []
+    import time
+    from monte_carlo_localization_amd.engine import ShardedUpdateError
+    for it in range(steps):
+        t0 = time.perf_counter()
+        try:
+            pose = sf.update((0.05, 0.0, 0.01), obs)
+        except ShardedUpdateError as ex:
+            if not expect_fail:
+                raise
+            failures.append((it, int(ex.local), time.perf_counter() - t0))
+            print(f"[worker {rank}] update {it}: {ex}", file=sys.stderr, flush=True)
+            if device_init:
+                shard.init_particles_pose((0.0, 0.0, 0.0), n_local, rank * n_local, ntot)
+                sf.reset()
+            else:
+                sf.set_particles(p[:, mine], w)
+            continue
+        poses.append(pose)
         kinds.append(sf.exchange_bytes["kind"])
         waits.append(sf.host_waits)                     # stream synchronisations of this update (1: the device-ordered flow)
         kept.append(int(getattr(sf, 'kept_last', False)))   # adaptive resampling kept the set in this update
@@ -82,9 +102,9 @@ def main():
     if digest:
         from conftest import block_digests
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=block_digests(parts), q=block_digests(q), idx=block_digests(idx),
-                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), neff=np.array(neff), native=np.array(int(getattr(sf, 'native', False))))
+                 poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), neff=np.array(neff), native=np.array(int(getattr(sf, 'native', False))), failures=np.array(failures, dtype=np.float64).reshape(-1, 3))
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), neff=np.array(neff), native=np.array(int(getattr(sf, 'native', False))))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=parts, q=q, idx=idx, poses=np.array(poses), kinds=np.array(kinds), waits=np.array(waits), kept=np.array(kept), neff=np.array(neff), native=np.array(int(getattr(sf, 'native', False))), failures=np.array(failures, dtype=np.float64).reshape(-1, 3))
     dist.barrier()
     dist.destroy_process_group()
 

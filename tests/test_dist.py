@@ -88,6 +88,107 @@ def test_two_ranks_host_weights_that_differ_between_shards_gloo_cpu(tmp_path, mo
     assert (np.concatenate([z["idx"] for z in two]) >= 96).mean() > 0.9      # the parents come from the heavy shard
 
 
+def check_void_update(res, world, failing_rank, update_index, n_updates):
+    """Every rank raised from the SAME update (the failing rank with its own error, the others with the peer's), quickly; the
+    updates after the re-initialisation succeeded and every rank reports the same poses."""
+    for r in range(world):
+        f = res[r]["failures"]
+        assert f.shape == (1, 3), (r, f)
+        assert int(f[0, 0]) == update_index
+        # (the failing rank reports its own failure; another rank normally reports the peer's -- unless what the failing rank
+        #  contributed to an exchange made one of its own stages fail too: then it reports that, also a void update)
+        assert int(f[0, 1]) == 1 or r != failing_rank
+        assert f[0, 2] < 10.0                                          # seconds from the call to the exception
+        assert res[r]["poses"].shape == (n_updates - 1, 3) and np.isfinite(res[r]["poses"]).all()
+        assert np.array_equal(res[r]["poses"], res[0]["poses"])
+
+
+@pytest.mark.parametrize("update,call,overlap,void", [(1, "stage_resample_indices", False, 0), (2, "stage_resample_compact", False, 1),
+                                                      (2, "export_compact", True, 2), (2, "stage_rays", True, 1), (3, "stage_weights", False, 2),
+                                                      (1, "stage_distinct_parents", True, 0)])
+def test_a_failing_rank_voids_the_update_on_every_rank_gloo_cpu(tmp_path, update, call, overlap, void):
+    """dist.py's failure protocol over the CPU stand-in: rank 1 fails before one engine call of one update (MCL_DIST_FAIL) --
+    the dense exchange of the first update, the list exchange of the later ones, the ray stage, the weights stage, the export
+    that prepares the next update's exchange.  It still enters every collective; both ranks raise ShardedUpdateError from that
+    update within seconds; after set_particles the next updates run."""
+    res = run_world("oracle", tmp_path, 2, 96, 4, 0, overlap, MCL_DIST_FAIL=f"1:{update}:{call}", MCL_TEST_EXPECT_FAIL="1")
+    # (`void` = index of the update that raised.  With overlap, export_compact runs at the END of an update, for the next one's
+    #  exchange: the failure is the NEXT update's -- that exchange is entered all the same, then the update is void)
+    check_void_update(res, 2, 1, void, 4)
+
+
+def test_a_failing_rank_among_four_gloo_cpu(tmp_path):
+    res = run_world("oracle", tmp_path, 4, 48, 4, 0, True, MCL_DIST_FAIL="2:2:stage_resample", MCL_TEST_EXPECT_FAIL="1")
+    check_void_update(res, 4, 2, 1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flow", ["ordered", "sync"])
+def test_a_failing_rank_voids_the_update_on_every_rank_hip_engine(tmp_path, flow):
+    """The same with the real engine in both ranks (gloo, the ranks share the GPU): the device-ordered flow (the error word is
+    written on the device, behind the summed vector) and the stage-by-stage one."""
+    env = dict(MCL_DIST_FAIL="1:2:stage_resample", MCL_TEST_EXPECT_FAIL="1", MCL_TEST_BEAM_STEP="6")
+    if flow == "sync":
+        env["MCL_DIST_SYNC"] = "1"
+    res = run_world("engine", tmp_path, 2, 65536, 4, 0, True, **env)
+    check_void_update(res, 2, 1, 1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["resample", "rays", "weights"])
+def test_native_rccl_update_soft_failure_one_rank(tmp_path, stage):
+    """mcl_comm_update's failure protocol with the one-rank RCCL communicator (MCL_COMM_FAIL: the rank reports a failure
+    before that stage of update 2): the call still issues its collectives, returns an error at once -- ShardedUpdateError,
+    `.local` -- the communicator stays usable, and after the re-initialisation the next updates succeed."""
+    res = run_world("engine", tmp_path, 1, 65536, 4, 0, False, MCL_DIST_NATIVE="1", MCL_TEST_NCCL="1", MCL_TEST_BEAM_STEP="6",
+                    MCL_COMM_FAIL=f"0:2:{stage}", MCL_TEST_EXPECT_FAIL="1")
+    assert int(res[0]["native"]) == 1
+    check_void_update(res, 1, 0, 1, 4)
+
+
+@pytest.mark.gpu
+def test_native_rccl_update_bounded_wait_aborts_the_communicator(tmp_path):
+    """A collective that does not finish within MCL_COMM_TIMEOUT_MS (here: the rank's own stream is kept busy for three times
+    the bound before the last all-reduce, MCL_COMM_FAIL=0:2:stall -- what a peer that never arrives looks like from the
+    host): the wait ends, the communicator is aborted, the call returns MCL_ERR_TIMEOUT, later calls say "create again"."""
+    import ctypes as C
+    from monte_carlo_localization_amd import engine, maps
+    from oracle import oracle as orc
+    os.environ["MCL_COMM_TIMEOUT_MS"] = "150"
+    os.environ["MCL_COMM_FAIL"] = "0:2:stall"
+    try:
+        m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
+        ang = orc.beam_angles(angle_step=6)
+        obs = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"][::6].copy()
+        e = engine.Engine(max_particles=65536, seed=5)
+        ok, why = e.comm_available()
+        if not ok:
+            pytest.skip(f"no RCCL: {why}")
+        e.set_map(m.data, m.resolution, m.origin_x, m.origin_y)
+        e.set_beam_angles(ang)
+        e.init_particles_pose((0.0, 0.0, 0.0), 65536, 0, 65536)
+        e.comm_create(e.comm_unique_id(), 1, 0)
+        e.comm_update((0.05, 0.0, 0.01), obs)
+        import time
+        t0 = time.perf_counter()
+        with pytest.raises(engine.ShardedUpdateError) as ei:
+            e.comm_update((0.05, 0.0, 0.01), obs)
+        assert ei.value.status == engine.MCL_ERR_TIMEOUT and not ei.value.local
+        assert time.perf_counter() - t0 < 10.0
+        with pytest.raises(engine.ShardedUpdateError, match="create again"):
+            e.comm_update((0.05, 0.0, 0.01), obs)
+        # a new communicator, the particles initialised again: the sharded update works again
+        e.comm_create(e.comm_unique_id(), 1, 0)
+        e.init_particles_pose((0.0, 0.0, 0.0), 65536, 0, 65536)
+        os.environ.pop("MCL_COMM_FAIL")
+        pose = e.comm_update((0.05, 0.0, 0.01), obs)
+        assert np.isfinite(pose).all()
+        e.close()
+    finally:
+        os.environ.pop("MCL_COMM_TIMEOUT_MS", None)
+        os.environ.pop("MCL_COMM_FAIL", None)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,overlap", [(0, False), (1, False), (0, True), (1, True)])
 def test_two_ranks_equal_one_rank_hip_engine(tmp_path, mode, overlap):
@@ -166,7 +267,7 @@ def test_native_rccl_update_one_rank_equals_the_torch_collectives(tmp_path, vari
     extra = dict(MCL_TEST_BEAM_STEP="3", MCL_TEST_NCCL="1")
     if variant == "overflow":
         extra["MCL_TEST_FORCE_EXACT"] = "2"
-    nat = run_world("engine", dn, 1, n, 4, 0, False, **extra, **(dict(MCL_COMM_NO_LISTS="1") if variant == "dense" else {}))
+    nat = run_world("engine", dn, 1, n, 4, 0, False, MCL_DIST_NATIVE="1", **extra, **(dict(MCL_COMM_NO_LISTS="1") if variant == "dense" else {}))
     ref = run_world("engine", dt, 1, n, 4, 0, False, MCL_DIST_NATIVE="0", **extra, **(dict(MCL_DIST_NO_LISTS="1") if variant == "dense" else {}))
     assert int(nat[0]["native"]) == 1 and int(ref[0]["native"]) == 0
     for k in ("idx", "particles", "q", "poses"):
@@ -194,7 +295,7 @@ def test_adaptive_resampling_in_the_sharded_hosts_equals_one_engine(tmp_path, ho
     extra = dict(MCL_TEST_BEAM_STEP="9", MCL_TEST_NEFF=str(r), MCL_TEST_TIGHT="1")
     if host == "native":
         world, n_local = 1, n
-        got = run_world("engine", d, 1, n, steps, 0, False, MCL_TEST_NCCL="1", **extra)
+        got = run_world("engine", d, 1, n, steps, 0, False, MCL_TEST_NCCL="1", MCL_DIST_NATIVE="1", **extra)
         assert int(got[0]["native"]) == 1
     else:
         world, n_local = 2, n // 2

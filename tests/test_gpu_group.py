@@ -265,14 +265,16 @@ def test_group_on_two_distinct_devices_equals_one_engine(orc, engine_mod, spielb
 
 
 @pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: RCCL with one rank per device")
-@pytest.mark.parametrize("mode", [0, 1])
-def test_two_ranks_over_rccl_on_two_devices_equal_one_rank(tmp_path, mode):
+@pytest.mark.parametrize("mode,native", [(0, "0"), (1, "0"), (0, "1"), (1, "1")])
+def test_two_ranks_over_rccl_on_two_devices_equal_one_rank(tmp_path, mode, native):
     """ShardedFilter over the nccl (= RCCL) backend, one rank per DISTINCT device: the all-gather of the compact lists and the
-    small all-reduces as bench.py --gpus 2 issues them.  Skipped on a one-GPU box, where the same code runs over gloo."""
+    small all-reduces as bench.py --gpus 2 issues them (native "0": torch's collectives, the default; "1": the engine's own
+    communicator, mcl_comm_update, MCL_DIST_NATIVE=1).  Skipped on a one-GPU box, where the same code runs over gloo."""
     from test_dist import run_world, check_equal
     d2, d1 = tmp_path / "w2", tmp_path / "w1"
     d2.mkdir(); d1.mkdir()
-    two = run_world("engine", d2, 2, 131072, 4, mode, True, MCL_TEST_BEAM_STEP="4", MCL_TEST_NCCL="1")
+    two = run_world("engine", d2, 2, 131072, 4, mode, True, MCL_TEST_BEAM_STEP="4", MCL_TEST_NCCL="1", MCL_DIST_NATIVE=native)
+    assert int(two[0]["native"]) == int(native)
     one = run_world("engine", d1, 1, 262144, 4, mode, False, MCL_TEST_BEAM_STEP="4")
     check_equal(two, one, 131072)
     assert list(two[0]["kinds"]) == ["dense", "lists", "lists", "lists"]

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     ("one engine (`mcl_update`)", "single", [], {}),
-    ("sharded, 1 rank, the engine's RCCL communicator (`mcl_comm_update`; the default on the nccl backend)", "native", ["--force-dist"], {}),
+    ("sharded, 1 rank, the engine's RCCL communicator (`mcl_comm_update`, `MCL_DIST_NATIVE=1`)", "native", ["--force-dist"], {"MCL_DIST_NATIVE": "1"}),
     ("sharded, 1 rank, torch collectives, device-ordered (`MCL_DIST_NATIVE=0`)", "ordered", ["--force-dist"], {"MCL_DIST_NATIVE": "0"}),
     ("sharded, 1 rank, torch collectives, stage by stage (`MCL_DIST_NATIVE=0 MCL_DIST_SYNC=1`: round 3's flow)", "sync", ["--force-dist"],
      {"MCL_DIST_NATIVE": "0", "MCL_DIST_SYNC": "1"}),
