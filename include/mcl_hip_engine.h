@@ -234,6 +234,12 @@ int mcl_host_skip_field_dir(const int8_t *data, uint32_t width, uint32_t height,
  * [2*pi*k/MCL_WEDGES, 2*pi*(k+1)/MCL_WEDGES]); the fields MCL_RAYS_CELL stages in LDS. */
 #define MCL_WEDGES 16
 int mcl_host_skip_field_wedge(const int8_t *data, uint32_t width, uint32_t height, int32_t wedge, uint8_t *out, size_t n);
+/* Layout of the copies of the wedge fields that the global-field form of the ray kernel (ranges beyond 243 px) probes in place:
+ * out = [usable (0 / 1), row pitch, rows per field (ringed grid + tail of stop rows), bytes per field, bytes of the allocation,
+ * the largest byte offset a walk can form].  The kernel addresses the allocation from its start with offsets >= 0; a walk
+ * starts inside the ringed grid of its field and advances by at most max_range_px samples of at most one cell per axis, so
+ * out[5] < out[4] < 2^32 is the whole memory-safety argument (tests/test_sweep_addressing.py enumerates it).  Host only. */
+int mcl_host_sweep_global_layout(uint32_t width, uint32_t height, int32_t max_range_px, int64_t out[6]);
 
 /* ---- multi-GPU staging (one engine per rank; collectives are the host's) -- */
 /* Device pointers of engine-owned buffers so the host can hand them to RCCL without copies. */

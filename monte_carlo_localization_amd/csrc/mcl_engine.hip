@@ -71,6 +71,12 @@ struct mcl_engine {
     double2 *d_beam_cs = nullptr;
     double2 *d_beam_csx = nullptr;      // k_rays_sweep's copy with virtual beams either side (set_beam_angles)
     double2 *d_beam_csxg = nullptr;     // the same for the global-field form: a virtual beam repeats the first / last REAL beam
+    // k_rays_sweep<.., REC> (an evenly spaced scan): directions of the grid angles a0 + j inc, every beam's offset from its grid angle
+    // (one entry per table column), cos / sin of the increment; rec_ok: the scan qualifies
+    double2 *d_beam_csi = nullptr;
+    double *d_beam_err = nullptr;
+    double rec_c = 1.0, rec_s = 0.0;
+    bool rec_ok = false;
     int beam_pad = 0, beam_margin = 0;
     int32_t *d_obs_idx = nullptr;
     float *d_obs = nullptr;
@@ -85,6 +91,7 @@ struct mcl_engine {
     int ltd_cols = 0;
     bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
+    bool sweep_rec_layout_ok = false;   // the same for the <.., REC> instantiations (LDS form: window + offset table; global form: the table)
     bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
     bool skip_layout_ok = false;        // k_rays_skip has no static LDS (its window is addressed from LDS offset 0)
     // k_rays_sweep on the wedge fields in GLOBAL memory (ranges a 256-cell LDS window cannot hold; MCL_SWEEP_GLOBAL=1 forces it)
@@ -892,6 +899,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
             a.beam_csx = h->sweep_global ? h->d_beam_csxg : h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
+            a.beam_csi = h->d_beam_csi; a.beam_err = h->d_beam_err; a.rec_c = h->rec_c; a.rec_s = h->rec_s;
             a.distg = h->d_distg; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {
@@ -908,7 +916,12 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
         const bool sweep_glob = sweep && h->sweep_global;       // probes in global memory: no window in LDS
-        size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwSide * mcl::kSwSide) : (size_t)h->qside * h->qside;
+        // REC: the walk turns the beam direction by the scan's increment instead of fetching it (evenly spaced scans; the beams'
+        // offsets from the grid sit in LDS behind the window: 8 bytes per table column)
+        // (... as long as two workgroups still fit a CU's 160 KB: up to ~1800 table columns; more beams than that fetch their directions)
+        const bool sweep_rec = sweep && h->rec_ok && h->sweep_rec_layout_ok && h->d_beam_err != nullptr &&
+                               (size_t)mcl::kSwSide * mcl::kSwSide + (size_t)h->ltd_cols * 8 <= 80 * 1024 - 64;
+        size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwSide * mcl::kSwSide) + (sweep_rec ? (size_t)h->ltd_cols * 8 : 0) : (size_t)h->qside * h->qside;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();
@@ -918,7 +931,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU (2 .. 16 per segment: no difference, round 4)
         if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
@@ -928,7 +943,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
         } else {
-            if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
@@ -1231,6 +1248,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_sweep_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     {   // The hand-written probe loops address their LDS window from a raw offset: k_rays_sweep / k_rays_cell / k_rays_quad
         // from kQLdsBase (their static LDS must end exactly there), k_rays_skip from 0 (it must have no static LDS).  A
         // toolchain that lays a kernel out differently takes that kernel out of choose_ray_mode's choices -- the engine then
@@ -1241,6 +1260,17 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
         };
         const size_t qb = (size_t)mcl::kQLdsBase;
         h->sweep_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), qb);
+        {
+            // (the global form has one static word less: its dynamic LDS -- 16-byte aligned -- still starts at kQLdsBase)
+            auto static_lds_fits = [](const void *fn, size_t lo, size_t hi) {
+                hipFuncAttributes fa{};
+                return hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes > lo && fa.sharedSizeBytes <= hi;
+            };
+            h->sweep_rec_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), qb) &&
+                                     static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true>), qb) &&
+                                     static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, true, true>), 0, qb) &&
+                                     static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, true, true>), 0, qb);
+        }
         h->cell_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), qb);
         h->quad_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), qb);
         h->skip_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), 0) &&
@@ -1268,7 +1298,7 @@ void mcl_destroy(mcl_engine_t *h)
     dfree(h->d_idx); dfree(h->d_steps); dfree(h->d_part); dfree(h->d_maxpart); dfree(h->d_result); if (h->h_result) { (void)hipHostFree(h->h_result); h->h_result = nullptr; } dfree(h->d_inject); dfree(h->d_pc); dfree(h->d_qr); dfree(h->d_far); dfree(h->d_far_list); dfree(h->d_far_sorted); dfree(h->d_far_cnt); dfree(h->d_pcs); dfree(h->d_ths); dfree(h->d_distw); dfree(h->d_distg); dfree(h->d_leaders); dfree(h->d_pack[0]); dfree(h->d_pack[1]); dfree(h->d_perm); dfree(h->d_skey); dfree(h->d_srank); dfree(h->d_skey2); dfree(h->d_sval2); dfree(h->d_sort_tmp); dfree(h->d_hist); dfree(h->d_histpart); dfree(h->d_tile_used); dfree(h->d_bbox); dfree(h->d_cut_start); dfree(h->d_cut_end); dfree(h->d_tilemap); dfree(h->d_tilemark); dfree(h->d_slice_mean); dfree(h->d_fix_list); dfree(h->d_fix_count); dfree(h->d_exact_list);
     dfree(h->d_grid); dfree(h->d_dist); dfree(h->d_dist4); dfree(h->d_L); dfree(h->d_table);
     for (int q = 0; q < 4; ++q) dfree(h->d_distq[q]);
-    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_beam_csxg); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
+    dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_beam_csxg); dfree(h->d_beam_csi); dfree(h->d_beam_err); dfree(h->d_obs_idx); dfree(h->d_Lt); dfree(h->d_Ltd); dfree(h->d_items); dfree(h->d_centres); dfree(h->d_nitems); dfree(h->d_unit_sums); dfree(h->d_unit_begin); dfree(h->d_nunits); dfree(h->d_obs); dfree(h->d_free);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     for (int i = 0; i < EV_COUNT; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1482,6 +1512,32 @@ int mcl_set_beam_angles(mcl_engine_t *h, const float *angles, int32_t n_beams)
         csxg[i] = make_double2(std::cos(ac), std::sin(ac));
     }
     dfree(h->d_angle); dfree(h->d_beam_cs); dfree(h->d_beam_csx); dfree(h->d_beam_csxg); dfree(h->d_obs_idx); dfree(h->d_obs);
+    dfree(h->d_beam_csi); dfree(h->d_beam_err);
+    h->rec_ok = false;
+    if (h->beam_margin > 0 && !getenv("MCL_SWEEP_NO_REC")) {
+        // REC: the walk turns the direction by the grid increment instead of fetching it (mcl_rays_sweep.h).  Every beam must lie
+        // within 2e-6 rad of the grid through the first and the last (the second-order term of its offset, e^2 / 2 * 2^32 units,
+        // then stays below 1e-2 unit of the guard's budget): the float rounding of a0 + j inc, which is what a lidar driver
+        // publishes, is a few 1e-8.
+        const int ecols = (n_beams + 2 * h->beam_margin + 64) & ~63;          // = ltd_cols (ensure_lt)
+        std::vector<double2> csi(ncsx);
+        std::vector<double> err((size_t)ecols, 0.0);
+        double worst = 0.0;
+        for (int i = 0; i < ncsx; ++i) {
+            const int j = i - h->beam_margin;
+            const double ag = (double)angles[0] + (double)j * inc;
+            csi[i] = make_double2(std::cos(ag), std::sin(ag));
+            if (j >= 0 && j < n_beams && i < ecols) { err[i] = (double)angles[j] - ag; worst = std::max(worst, std::fabs(err[i])); }
+        }
+        if (worst <= 2e-6 && ncsx <= ecols + 8) {
+            HIPCHK(h, hipMalloc(&h->d_beam_csi, (size_t)ncsx * sizeof(double2)));
+            HIPCHK(h, hipMemcpy(h->d_beam_csi, csi.data(), (size_t)ncsx * sizeof(double2), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMalloc(&h->d_beam_err, (size_t)ecols * sizeof(double)));
+            HIPCHK(h, hipMemcpy(h->d_beam_err, err.data(), (size_t)ecols * sizeof(double), hipMemcpyHostToDevice));
+            h->rec_c = std::cos(inc); h->rec_s = std::sin(inc);
+            h->rec_ok = true;
+        }
+    }
     if (h->h_obs) { (void)hipHostFree(h->h_obs); h->h_obs = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_obs, (size_t)n_beams * sizeof(float)));
     HIPCHK(h, hipHostMalloc(&h->h_obs, (size_t)n_beams * sizeof(float)));
@@ -2209,6 +2265,16 @@ int mcl_host_skip_field(const int8_t *data, uint32_t width, uint32_t height, uin
     std::vector<uint8_t> d;
     build_distance_field(data, (int)width, (int)height, Wp, Hp, Wps, d);
     for (int y = 0; y < Hp; ++y) std::memcpy(out + (size_t)y * Wp, d.data() + (size_t)y * Wps, Wp);
+    return MCL_OK;
+}
+
+int mcl_host_sweep_global_layout(uint32_t width, uint32_t height, int32_t max_range_px, int64_t out[6])
+{
+    if (!out || width == 0 || height == 0 || max_range_px < 1) return MCL_ERR_INVALID_ARG;
+    const int Wp = (int)width + 1, Hp = (int)height + 1;
+    const mcl::SweepGlobalLayout g = mcl::sweep_global_layout(Wp, Hp, max_range_px);
+    out[0] = g.ok ? 1 : 0; out[1] = g.pitch; out[2] = g.rows; out[3] = (int64_t)g.stride; out[4] = (int64_t)g.alloc;
+    out[5] = (int64_t)mcl::sweep_global_max_offset(g, Wp, Hp, max_range_px, mcl::kWedges - 1);
     return MCL_OK;
 }
 

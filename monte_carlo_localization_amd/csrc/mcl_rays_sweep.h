@@ -321,65 +321,53 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
     "v_sub_co_u32 " REMOUT ", vcc, " REM ", " BY "\n\t"                                                   \
     "s_andn2_b64 exec, exec, vcc\n\t"
 
-// The rotated direction of the next beam in the mirrored frame, as integers in the low dwords of v44 (x) and v46 (y):
+// ---- the direction of a beam, two ways ----------------------------------------------------------------------------------------
+// TAB (any monotone scan): (cos a_j, sin a_j) of every beam from a table in global memory (RayArgs::beam_csx), one 16-byte
+// gather per ray, rotated by the particle's heading:
 //   Xx = aq cb - bq sb,  Xy = +-(bq cb + aq sb)   (aq, bq = the particle's cos / sin times +-kSwDirScale; v[40:43] = cb, sb)
 // with the 1.5 * 2^52 magic folded into the inner FMA: two v_fma_f64 per component (rounds 2-4: mul, fma, add), each rounding to
 // a whole unit -- |error| <= 1 unit, paid for by the guard.  The inner magic carries +1: the sum is then >= 0 whatever the two
-// roundings do to a component that is 0 in exact arithmetic (a ray along an axis), see guard_units in k_rays_sweep.
+// roundings do to a component that is 0 in exact arithmetic (a ray along an axis), see sweep_guard_units.
 // NEGA / NEGB = "-" in the quadrants where the sign of the y component differs from x's.
-#define MCL_SW_ROTATE(NEGA, NEGB)                                                                                               \
+#define MCL_SW_DIR_TAB(NEGA, NEGB)                                                                                              \
+        "s_waitcnt vmcnt(1)\n\t" /* direction landed (the table entry may be in flight) */                                     \
         "v_fma_f64 v[48:49], -%[bq], v[42:43], %[magic1]\n\t"                                                                  \
         "v_fma_f64 v[44:45], %[aq], v[40:41], v[48:49]\n\t"                                                                    \
         "v_fma_f64 v[48:49], " NEGA "%[aq], v[42:43], %[magic1]\n\t"                                                           \
-        "v_fma_f64 v[46:47], " NEGB "%[bq], v[40:41], v[48:49]\n\t"
-
-// The beam walk over the slots every live lane of the wave has, as one asm block: all 64 lanes active, no per-slot validity
-// tests, no per-ray test for undecided rays either: the guard minimum %[g] runs over ALL the rays of the walk and is looked at
-// once, after it (with 32 fractional bits a sample falls inside the guard once in a few million; the lane that has one hands
-// the walk's rays to the fix-up list, see below).
-//   v[40:43] direction of the beam (cos, sin); v[44:45] / v[46:47] rotated direction + magic: Xx = v44, Xy = v46;
-//   v[48:49] inner FMA, then LDS address / cell byte / table offset; v[50:51] pending table entry;
-//   v[52:53] Tx (fraction, cell); v[54:55] Ty; v57 samples left
-// (the trips after the first: six per turn of the loop -- a ray makes 3.4, a wave 4.5 -- so that the walk sees not-taken exit
-//  branches only; the countdown and its taken branch cost a wave ~20 cycles per trip in a chain that is latency-bound,
-//  tools/ubench/trip_rates.hip)
-#define MCL_SW_TRIP_NEXT MCL_SW_TRIP("v57", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]")
-// (timing-only experiment switches of tools/ab: never defined by the product build)
-#ifdef MCL_EXP_ROW0
-#define MCL_EXP_TABLE_OFFSET "v_mad_i32_i24 v48, v57, 0, %[zoff]\n\t"
-#else
-#define MCL_EXP_TABLE_OFFSET "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"
-#endif
-#if defined(MCL_EXP_RECUR)
-// next beam's direction by rotating this beam's by the scan increment (timing only: no load, six more VALU)
-#define MCL_EXP_DIR_LOAD "v_mul_f64 v[48:49], v[42:43], %[sdl]\n\t" "v_fma_f64 v[52:53], v[40:41], %[cdl], -v[48:49]\n\t" \
-                         "v_mul_f64 v[48:49], v[40:41], %[sdl]\n\t" "v_fma_f64 v[54:55], v[42:43], %[cdl], v[48:49]\n\t" \
-                         "v_mov_b64 v[40:41], v[52:53]\n\t" "v_mov_b64 v[42:43], v[54:55]\n\t"
-#define MCL_EXP_WAIT2 "s_waitcnt vmcnt(0)\n\t"
-#elif defined(MCL_EXP_NODIR)
-#define MCL_EXP_DIR_LOAD "s_nop 0\n\t"
-#define MCL_EXP_WAIT2 "s_waitcnt vmcnt(0)\n\t"
-#else
-#define MCL_EXP_DIR_LOAD "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"
-#define MCL_EXP_WAIT2 "s_waitcnt vmcnt(1)\n\t"
-#endif
-#if defined(MCL_EXP_RECUR)
-#define MCL_EXP_EXTRA_OPERANDS , [cdl] "s"(exp_cdl), [sdl] "s"(exp_sdl)
-#else
-#define MCL_EXP_EXTRA_OPERANDS
-#endif
-#define MCL_SW_WALK(NEGA, NEGB)                                                                                                \
-    asm volatile(                                                                                                              \
-        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
-        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
-        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0: keeps the vmcnt pattern of the steady state */                 \
-        "3:\n\t"                                                                                                               \
-        "s_waitcnt vmcnt(1)\n\t" /* direction landed (the table entry may be in flight) */                                     \
-        MCL_SW_ROTATE(NEGA, NEGB)                                                                                              \
+        "v_fma_f64 v[46:47], " NEGB "%[bq], v[40:41], v[48:49]\n\t"                                                            \
         "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
-        MCL_EXP_DIR_LOAD /* next beam's direction */                                                                           \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t" /* next beam's direction */
+// REC (an evenly spaced scan, mcl_set_beam_angles: every angle within 2e-6 rad of the grid a0 + j inc -- any real lidar's): no
+// gather.  The 16-byte gather of TAB costs the ray stage a tenth of its time (the texture path takes 64 addresses and 1 KB per
+// ray; timing-only variants in profiles/r05_experiments).  Here the lane carries the scaled, mirrored direction of the GRID angle
+// of its current beam as two fp64 values (xs, ys) and turns them by the grid increment per beam,
+//   xs' = c xs - nu s ys,  ys' = c ys + nu s xs        (c, s = cos / sin of the increment; nu = -1 in the quadrants mirrored in one axis)
+// (four fp64 instructions; the error of 90 such steps is 2^-13 unit), and the beam's own offset from the grid e_j = a_j - (a0 + j inc)
+// -- the float rounding of its angle, a few 1e-8 rad, 8 bytes per beam in LDS behind the window -- enters to first order where the
+// integers are made:  Xx = xs - nu e ys + (magic + 1),  Xy = ys + nu e xs + (magic + 1)   (the second-order term e^2 / 2 is below
+// 1e-2 unit).  Same two roundings, same bound as TAB.  v[40:41] = e_j, read one beam ahead.
+// NEGX = "-" / NEGY = "" normally, "" / "-" where nu = -1.
+#define MCL_SW_DIR_REC(NEGX, NEGY)                                                                                              \
+        "s_waitcnt lgkmcnt(0)\n\t" /* e_j landed (trivially: the previous beam's trips waited for later reads) */              \
+        "v_add_f64 v[48:49], %[xs], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[44:45], " NEGX "v[40:41], %[ys], v[48:49]\n\t"                                                            \
+        "v_add_f64 v[48:49], %[ys], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[46:47], " NEGY "v[40:41], %[xs], v[48:49]\n\t"                                                            \
+        "v_mul_f64 v[42:43], %[rs], %[ys]\n\t"                                                                                 \
+        "v_mul_f64 v[48:49], %[rs], %[xs]\n\t"                                                                                 \
+        "v_fma_f64 %[xs], %[rc], %[xs], -v[42:43]\n\t"                                                                         \
+        "v_fma_f64 %[ys], %[rc], %[ys], v[48:49]\n\t"                                                                          \
+        "v_add_u32 %[je], %[je], %[ince]\n\t"                                                                                  \
+        "ds_read_b64 v[40:41], %[je]\n\t" /* next beam's offset from the grid */
+
+// ---- the trips of one ray: the first, then six per turn of a loop -- a ray makes 3.4, a wave 4.5 -- so that the walk sees not-taken
+// exit branches only (the countdown and its taken branch cost a wave ~20 cycles per trip in a chain that is latency-bound,
+// tools/ubench/trip_rates.hip)
+#define MCL_SW_TRIP_FIRST MCL_SW_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]")
+#define MCL_SW_TRIP_NEXT MCL_SW_TRIP("v57", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]")
+#define MCL_SW_TRIPS_LDS                                                                                                       \
         "s_movk_i32 %[cd], 50\n\t"                                                                                             \
-        MCL_SW_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[lb]") \
+        MCL_SW_TRIP_FIRST                                                                                                      \
         "s_cbranch_execz 2f\n"                                                                                                 \
         "1:\n\t"                                                                                                               \
         MCL_SW_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                               \
@@ -392,23 +380,60 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 1b\n\t"                                                                                                \
         "s_mov_b32 %[expired], 1\n" /* malformed window (impossible): the pass is redone by the fix-up path */                 \
         "2:\n\t"                                                                                                               \
-        "s_mov_b64 exec, -1\n\t"                                                                                               \
-        MCL_EXP_WAIT2 /* previous beam's table entry landed */                                                                 \
+        "s_mov_b64 exec, -1\n\t"
+
+// The beam walk over the slots every live lane of the wave has, as one asm block: all 64 lanes active, no per-slot validity
+// tests, no per-ray test for undecided rays either: the guard minimum %[g] runs over ALL the rays of the walk and is looked at
+// once, after it (with 32 fractional bits a sample falls inside the guard once in a few million; the lane that has one hands
+// the walk's rays to the fix-up list, see below).
+//   v[40:43] direction of the beam (TAB) / v[40:41] its offset from the grid (REC); v[44:45] / v[46:47] rotated direction +
+//   magic: Xx = v44, Xy = v46; v[48:49] scratch, then LDS address / cell byte / table offset; v[50:51] pending table entry;
+//   v[52:53] Tx (fraction, cell); v[54:55] Ty; v57 samples left
+// The table entry of a ray is requested when the ray ends and added when the NEXT ray has ended: TAB keeps two reads in flight
+// (entry, next direction: they return in order), REC one.
+#define MCL_SW_TAIL(WAITCNT)                                                                                                   \
+        WAITCNT /* previous beam's table entry landed */                                                                       \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
-        MCL_EXP_TABLE_OFFSET                                                                                                   \
+        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
         "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"                                                                                \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
         "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
         "s_cbranch_scc0 3b\n\t"                                                                                                \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
-        "v_add_f64 %[acc], %[acc], v[50:51]"                                                                                   \
+        "v_add_f64 %[acc], %[acc], v[50:51]"
+#define MCL_SW_CLOBBERS "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v57"
+
+#define MCL_SW_WALK_TAB(NEGA, NEGB)                                                                                            \
+    asm volatile(                                                                                                              \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
+        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0: keeps the vmcnt pattern of the steady state */                 \
+        "3:\n\t"                                                                                                               \
+        MCL_SW_DIR_TAB(NEGA, NEGB)                                                                                             \
+        MCL_SW_TRIPS_LDS                                                                                                       \
+        MCL_SW_TAIL("s_waitcnt vmcnt(1)\n\t")                                                                                  \
         : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [g] "+v"(gwalk),                                              \
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
         : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                     \
           [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8),                        \
-          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase) MCL_EXP_EXTRA_OPERANDS                       \
-        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",    \
-          "v53", "v54", "v55", "v57")
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
+        : MCL_SW_CLOBBERS)
+
+#define MCL_SW_WALK_REC(NEGX, NEGY)                                                                                            \
+    asm volatile(                                                                                                              \
+        "ds_read_b64 v[40:41], %[je]\n\t"                                                                                      \
+        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0 */                                                              \
+        "3:\n\t"                                                                                                               \
+        MCL_SW_DIR_REC(NEGX, NEGY)                                                                                             \
+        MCL_SW_TRIPS_LDS                                                                                                       \
+        MCL_SW_TAIL("s_waitcnt vmcnt(0)\n\t")                                                                                  \
+        : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xs] "+v"(xs), [ys] "+v"(ys),                  \
+          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
+        : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
+          [ince] "v"(inc8), [inc8] "v"(inc8), [rc] "s"(a.rec_c), [rs] "s"(rec_s), [ltb] "s"(a.Ltd), [st8] "s"(st8),             \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
+        : MCL_SW_CLOBBERS)
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
 // holds (cpp:195 puts no bound on MAX_RANGE_PX).  The fields are read in place from copies that are MIRRORED per quadrant like
@@ -431,20 +456,12 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
     "s_andn2_b64 exec, exec, vcc\n\t"
 
 // (memory reads return in order: the trip's vmcnt(0) also lands the next beam's direction and the previous beam's table entry,
-//  which were requested before it -- the two vmcnt(1) of the LDS walk are satisfied trivially here)
+//  which were requested before it -- the vmcnt waits of the LDS walk are satisfied trivially here)
+#define MCL_SWG_TRIP_FIRST MCL_SWG_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[pitch]", "%[gbase]")
 #define MCL_SWG_TRIP_NEXT MCL_SWG_TRIP("v57", "%[g]", "v49", "v[52:53]", "v[54:55]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[pitch]", "%[gbase]")
-#define MCL_SWG_WALK(NEGA, NEGB)                                                                                               \
-    asm volatile(                                                                                                              \
-        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
-        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
-        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
-        "3:\n\t"                                                                                                               \
-        "s_waitcnt vmcnt(1)\n\t"                                                                                               \
-        MCL_SW_ROTATE(NEGA, NEGB)                                                                                              \
-        "v_add_u32 %[j16], %[j16], %[inc16]\n\t"                                                                               \
-        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
+#define MCL_SW_TRIPS_GLB                                                                                                       \
         "s_mov_b32 %[cd], %[cdinit]\n\t"                                                                                       \
-        MCL_SWG_TRIP("%[rem0]", "%[g]", "%[s0]", "%[p0x]", "%[p0y]", "v[52:53]", "v[54:55]", "v52", "v53", "v54", "v55", "v48", "v49", "%[g]", "v57", "v44", "v46", "%[pitch]", "%[gbase]") \
+        MCL_SWG_TRIP_FIRST                                                                                                     \
         "s_cbranch_execz 2f\n"                                                                                                 \
         "1:\n\t"                                                                                                               \
         MCL_SWG_TRIP_NEXT "s_cbranch_execz 2f\n\t"                                                                              \
@@ -455,26 +472,43 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 1b\n\t"                                                                                                \
         "s_mov_b32 %[expired], 1\n"                                                                                            \
         "2:\n\t"                                                                                                               \
-        "s_mov_b64 exec, -1\n\t"                                                                                               \
-        "s_waitcnt vmcnt(1)\n\t"                                                                                               \
-        "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
-        MCL_EXP_TABLE_OFFSET                                                                                                   \
-        "v_add_u32 %[j8b], %[j8b], %[inc8]\n\t"                                                                                \
+        "s_mov_b64 exec, -1\n\t"
+
+#define MCL_SWG_WALK_TAB(NEGA, NEGB)                                                                                           \
+    asm volatile(                                                                                                              \
+        "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t"                                                                     \
+        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
-        "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
-        "s_cbranch_scc0 3b\n\t"                                                                                                \
-        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
-        "v_add_f64 %[acc], %[acc], v[50:51]"                                                                                   \
+        "3:\n\t"                                                                                                               \
+        MCL_SW_DIR_TAB(NEGA, NEGB)                                                                                             \
+        MCL_SW_TRIPS_GLB                                                                                                       \
+        MCL_SW_TAIL("s_waitcnt vmcnt(1)\n\t")                                                                                  \
         : [acc] "+v"(acc_fast), [j16] "+v"(j16), [j8b] "+v"(j8b), [g] "+v"(gwalk),                                              \
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
         : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                     \
           [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8),                        \
           [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit4),                                                     \
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff)                                                                   \
-        : "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",    \
-          "v53", "v54", "v55", "v57")
+        : MCL_SW_CLOBBERS)
 
-template <bool COUNT, bool GLOBAL = false>
+#define MCL_SWG_WALK_REC(NEGX, NEGY)                                                                                           \
+    asm volatile(                                                                                                              \
+        "ds_read_b64 v[40:41], %[je]\n\t"                                                                                      \
+        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
+        "3:\n\t"                                                                                                               \
+        MCL_SW_DIR_REC(NEGX, NEGY)                                                                                             \
+        MCL_SW_TRIPS_GLB                                                                                                       \
+        MCL_SW_TAIL("s_waitcnt vmcnt(0)\n\t")                                                                                  \
+        : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xs] "+v"(xs), [ys] "+v"(ys),                  \
+          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
+        : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
+          [ince] "v"(inc8), [inc8] "v"(inc8), [rc] "s"(a.rec_c), [rs] "s"(rec_s), [ltb] "s"(a.Ltd), [st8] "s"(st8),             \
+          [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit4),                                                     \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff)                                                                   \
+        : MCL_SW_CLOBBERS)
+
+template <bool COUNT, bool GLOBAL = false, bool REC = false>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -489,7 +523,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // AUTO / MCL_RAYS_SWEEP off this kernel when it differs (choose_ray_mode), so this branch is not reachable through the ABI;
     // should a toolchain ever lay the static words out differently anyway, the launch reports a full fix-up list -- which the
     // host answers by re-running the stage with k_rays_skip -- instead of aborting the device.
-    if (!GLOBAL && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
+    if ((!GLOBAL || REC) && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != (uint32_t)kQLdsBase) {
         if (threadIdx.x == 0) a.fix_count[(size_t)blockIdx.x * 8] = a.fix_cap + 1ull;
         return;
     }
@@ -503,6 +537,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const uint32_t st8 = (uint32_t)__builtin_amdgcn_readfirstlane(a.ltd_cols * 8);
     const uint32_t zrow = (uint32_t)(a.P + 1);                 // "samples left" that selects the all-zero row
     const unsigned char *ldsb = lds_raw;
+    // REC: every beam's offset from the scan's angular grid (RayArgs::beam_err, 8 bytes per table column), behind the window; the
+    // walk reads it from the raw LDS offset `ebase` (published by the first barrier of the item loop, like fixn_sh)
+    constexpr uint32_t ebase = (uint32_t)kQLdsBase + (GLOBAL ? 0u : (uint32_t)(kSwSide * kSwSide));
+    if (REC) {
+        double *etab = reinterpret_cast<double *>(lds_raw + (GLOBAL ? 0 : kSwSide * kSwSide));
+        for (int c = threadIdx.x; c < a.ltd_cols; c += kRayThreads) etab[c] = a.beam_err[c];
+    }
     if (threadIdx.x == 0) fixn_sh = 0u;                        // published by the first barrier of the item loop
     // the segment belongs to this workgroup alone: the append counter lives in LDS and entries are plain stores (the list
     // is read by k_rays_fix, a later kernel); the count goes to memory once, at the end
@@ -715,11 +756,20 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
-#if defined(MCL_EXP_RECUR)
-            const double exp_cdl = cos(1.0 / a.beam_inv_inc), exp_sdl = sin(1.0 / a.beam_inv_inc);
-#endif
-            if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK("-", "-"); else MCL_SWG_WALK("", ""); }
-            else { if (negy) MCL_SW_WALK("-", "-"); else MCL_SW_WALK("", ""); }
+            if constexpr (REC) {
+                // the direction of the GRID angle of the walk's first beam, scaled and mirrored like aq / bq (see MCL_SW_DIR_REC)
+                const double2 ci = a.beam_csi[(live ? jw : a.B) + a.beam_margin];
+                double xs = __builtin_fma(aq, ci.x, -(bq * ci.y)), ys = __builtin_fma(bq, ci.x, aq * ci.y);
+                if (negy) ys = -ys;
+                const double rec_s = negy ? -a.rec_s : a.rec_s;           // wave-uniform
+                uint32_t je = ebase + ((uint32_t)((live ? jw : a.B) + a.beam_margin) << 3);
+                (void)j16; (void)inc16;
+                if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK_REC("", "-"); else MCL_SWG_WALK_REC("-", ""); }
+                else { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
+            } else {
+                if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK_TAB("-", "-"); else MCL_SWG_WALK_TAB("", ""); }
+                else { if (negy) MCL_SW_WALK_TAB("-", "-"); else MCL_SW_WALK_TAB("", ""); }
+            }
             expired_fast = expired != 0u;
         }
         if (fast) t_done = part + 1u == parts ? tmin : tmax;       // the ragged rest belongs to the last piece

@@ -42,6 +42,7 @@ EXPORTS = [
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
     "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete", "mcl_stage_keep",
     "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector", "mcl_comm_last_exchange", "mcl_comm_selftest",
+    "mcl_host_sweep_global_layout",
 ]
 
 

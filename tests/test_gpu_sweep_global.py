@@ -179,3 +179,85 @@ def test_fine025_at_size_through_auto(orc, engine_mod, maps_mod, spielberg):
     c = e.counters()
     assert c["off_window_particles"] == 0 and c["level2_rays"] < 0.02 * n * ang.size
     e.close()
+
+
+@pytest.mark.lds_windows
+@pytest.mark.parametrize("shape", [(400, 60), (60, 400)])
+def test_narrow_map_long_range_particles_on_the_border(orc, engine_mod, shape):
+    """A map NARROWER than a ray is long (60 x 400 cells at 0.025 m: 479 px of range), a spread cloud with particles on the
+    border cells, in walls and outside: every step index and log-weight against the oracle.  The global-field form addresses the
+    allocation of the sixteen mirrored fields from its start with offsets >= 0; a walk that leaves the grid runs into its field's
+    tail of stop rows (csrc/mcl_wedge.h: sweep_global_layout; tests/test_sweep_addressing.py is the arithmetic).
+    cpp:195 puts no bound on MAX_RANGE_PX, cpp:632-636 none on the map size."""
+    H, W = shape
+    rng = np.random.default_rng(8)
+    grid = np.zeros((H, W), np.int8)
+    grid[rng.random((H, W)) < 0.01] = 100                                  # a few pillars
+    grid[0, :] = grid[-1, :] = 100                                          # walls along two sides, the other two open to the outside
+    res, ox, oy = 0.025, -1.0, -2.0
+    om = orc.OracleMap(grid, res, ox, oy)
+    P = om.max_range_px
+    assert P == 479 and min(H, W) < P
+    ang = orc.beam_angles(angle_step=9)
+    n = 2048
+    p = np.stack([ox + rng.uniform(-0.02 * W * res, 1.02 * W * res, n), oy + rng.uniform(-0.02 * H * res, 1.02 * H * res, n),
+                  rng.uniform(-np.pi, np.pi, n)])
+    # the border cells themselves, both ends of both axes, headings along the axes and the diagonals
+    edge = np.array([[ox + 0.5 * res, oy + 0.5 * res], [ox + (W - 0.5) * res, oy + 0.5 * res], [ox + 0.5 * res, oy + (H - 0.5) * res],
+                     [ox + (W - 0.5) * res, oy + (H - 0.5) * res], [ox + 1e-9, oy + 0.3 * H * res], [ox + W * res - 1e-9, oy + 0.6 * H * res]])
+    k = 0
+    for ex, ey in edge:
+        for th in np.arange(8) * (np.pi / 4):
+            p[:, k] = (ex, ey, th)
+            k += 1
+    p[:, 200:328] = p[:, 200:201] + rng.normal(0, 0.01, (3, 128))           # two full waves of near-identical rays
+    obs = rng.uniform(0.2, 13.0, ang.size).astype(np.float32)
+    L = orc.eng_log_table(orc.sensor_table(P))
+    want_logw, _, _ = orc.eng_log_weights(om, p, ang, orc.obs_index(obs, om), L)
+    _, want_steps = orc.cast_many(om, np.repeat(p[0], ang.size), np.repeat(p[1], ang.size),
+                                  (p[2][:, None] + ang.astype(np.float64)[None, :]).ravel())
+    for keep in (1, 0):
+        e = engine_mod.Engine(max_particles=n, seed=9, keep_ray_steps=keep, ray_kernel=engine_mod.RAYS_SWEEP)
+        e.set_map(grid, res, ox, oy)
+        e.set_beam_angles(ang)
+        assert "global memory" in e.planned_ray_kernel()[1]
+        e.set_particles(p, np.full(n, 1.0 / n))
+        e.sensor_update(obs)
+        assert e.ray_kernel_name() == "k_rays_sweep"
+        if keep:
+            assert np.array_equal(e.ray_steps().astype(np.int32).ravel(), np.asarray(want_steps, np.int32).ravel())
+        assert np.array_equal(e.log_weights(), want_logw)
+        e.close()
+
+
+@pytest.mark.lds_windows
+@pytest.mark.parametrize("glob", ["0", "1"])
+def test_turned_and_fetched_beam_directions_agree(orc, engine_mod, spielberg, monkeypatch, glob):
+    """The two ways the walk gets a beam's direction (mcl_rays_sweep.h: REC turns the grid direction by the scan increment and adds
+    the beam's own offset; TAB fetches (cos, sin) per ray -- MCL_SWEEP_NO_REC=1, and what a scan that is not evenly spaced gets):
+    same parents, particles and log-weights over five updates, in both forms of the kernel; the REC engine against the oracle."""
+    monkeypatch.setenv("MCL_SWEEP_GLOBAL", glob)
+    ang = orc.beam_angles(angle_step=2)
+    obs = S.scan1081()[::2].copy()
+    n = 131072
+    engines = []
+    for norec in (False, True):
+        if norec:
+            monkeypatch.setenv("MCL_SWEEP_NO_REC", "1")
+        e = make_engine(engine_mod, spielberg, ang, n, seed=78)
+        e.init_particles_pose((0.0, 0.0, 0.0), n)
+        engines.append(e)
+    for k in range(5):
+        for e in engines:
+            e.update((0.05, 0.0, 0.01), obs)
+            assert e.ray_kernel_name() == "k_rays_sweep"
+        assert np.array_equal(engines[0].resample_indices(), engines[1].resample_indices()), k
+        assert np.array_equal(engines[0].log_weights(), engines[1].log_weights()), k
+        assert np.array_equal(engines[0].get_particles(), engines[1].get_particles()), k
+    om = orc.OracleMap(spielberg.data, spielberg.resolution, spielberg.origin_x, spielberg.origin_y)
+    parts = engines[0].get_particles()
+    pick = np.random.default_rng(3).choice(n, 2048, replace=False)
+    logw, _, _ = orc.eng_log_weights(om, np.ascontiguousarray(parts[:, pick]), ang, orc.obs_index(obs, om), orc.eng_log_table(orc.sensor_table(om.max_range_px)))
+    assert np.array_equal(engines[0].log_weights()[pick], logw)
+    for e in engines:
+        e.close()
