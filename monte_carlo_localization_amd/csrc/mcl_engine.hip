@@ -91,6 +91,7 @@ struct mcl_engine {
     int ltd_cols = 0;
     bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
+    int env_sweep_pairs = -1;           // MCL_SWEEP_PAIRS: -1 the engine decides, 0 / 1 forced (A/B measurements)
     bool sweep_rec_layout_ok = false;   // the same for the <.., REC> instantiations (LDS form: window + offset table; global form: the table)
     bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
     bool skip_layout_ok = false;        // k_rays_skip has no static LDS (its window is addressed from LDS offset 0)
@@ -921,6 +922,10 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // (... as long as two workgroups still fit a CU's 160 KB: up to ~1800 table columns; more beams than that fetch their directions)
         const bool sweep_rec = sweep && h->rec_ok && h->sweep_rec_layout_ok && h->d_beam_err != nullptr &&
                                (size_t)mcl::kSwSide * mcl::kSwSide + (size_t)h->ltd_cols * 8 <= 80 * 1024 - 64;
+        // PAIRS (two rays per lane) where the walk waits for memory: always in the global-field form; in LDS windows for a set
+        // that was set / initialised since the last update (the spread cloud of a re-localisation: -11 % on its first update, where
+        // the tracking cloud gains nothing and the levine stand-in loses 2 %); MCL_SWEEP_PAIRS=0 / 1 overrides
+        const bool sweep_pairs = sweep_rec && (h->env_sweep_pairs >= 0 ? h->env_sweep_pairs != 0 : (sweep_glob || a.far_windowed != 0));
         size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwSide * mcl::kSwSide) + (sweep_rec ? (size_t)h->ltd_cols * 8 : 0) : (size_t)h->qside * h->qside;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
@@ -931,8 +936,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU (2 .. 16 per segment: no difference, round 4)
         if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep && sweep_rec && sweep_pairs) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
@@ -943,8 +949,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
         } else {
-            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep && sweep_rec && sweep_pairs) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
@@ -1150,6 +1157,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     h->env_no_bucket_cuts = getenv("MCL_NO_BUCKET_CUTS") != nullptr;
     if (const char *e = getenv("MCL_SWEEP_GLOBAL")) h->env_sweep_global = atoi(e) != 0;
     if (const char *e = getenv("MCL_SW_SPLIT16")) h->env_sw_split16 = atoi(e) != 0;
+    if (const char *e = getenv("MCL_SWEEP_PAIRS")) h->env_sweep_pairs = atoi(e) != 0 ? 1 : 0;
     h->env_no_obs_overlap = getenv("MCL_NO_OBS_OVERLAP") != nullptr;
     h->env_no_prep_fold = getenv("MCL_NO_PREP_FOLD") != nullptr;
     h->env_no_stale_layout = getenv("MCL_NO_STALE_LAYOUT") != nullptr;
@@ -1250,6 +1258,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     {   // The hand-written probe loops address their LDS window from a raw offset: k_rays_sweep / k_rays_cell / k_rays_quad
         // from kQLdsBase (their static LDS must end exactly there), k_rays_skip from 0 (it must have no static LDS).  A
         // toolchain that lays a kernel out differently takes that kernel out of choose_ray_mode's choices -- the engine then
@@ -1268,8 +1278,10 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
             };
             h->sweep_rec_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), qb) &&
                                      static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true>), qb) &&
-                                     static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, true, true>), 0, qb) &&
-                                     static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, true, true>), 0, qb);
+                                     static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true, true>), qb) &&
+                                     static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true, true>), qb) &&
+                                     static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, true, true, true>), 0, qb) &&
+                                     static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, true, true, true>), 0, qb);
         }
         h->cell_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), qb);
         h->quad_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), qb);

@@ -508,7 +508,139 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff)                                                                   \
         : MCL_SW_CLOBBERS)
 
-template <bool COUNT, bool GLOBAL = false, bool REC = false>
+// ---- TWO rays per lane (REC walks with an even number of slots): beams j and j + 1 of the lane's particle march in the same
+// trip loop.  The walk is bound by the latency of its dependent chain (mad -> address -> LDS read -> wait -> borrow -> exec ->
+// branch: ~150 cycles per trip and wave, eight waves per SIMD cover 8 x 20 issue cycles of it; SQ_WAIT_ANY = 70 % of the wave
+// cycles, profiles/r05_*), so a second, independent chain in the same wave runs in the shadow of the first
+// (tools/ubench/trip_rates.hip: 19.4 -> 15.7 SIMD cycles per ray and trip).  Ray A lives under exec, ray B under the lane mask
+// %[mb]; a ray that has ended is masked off (its samples-left register keeps its final value) while its sibling goes on; the
+// loop ends when no lane has a ray left.  Registers: v[42:43] / v[44:45] pending table entries; v46 / v48 direction of ray A
+// (v47 its LDS address, then cell byte), v50 / v52 of ray B (v49 address / byte); v51 / v53 samples left of A / B;
+// v[54:57] position of A, v[58:61] of B (before the trips: the two beams' offsets from the grid, FMA scratch).
+#define MCL_SW2_PROLOGUE(NEGX, NEGY)                                                                                            \
+        "ds_read2_b64 v[54:57], %[je] offset1:1\n\t"                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+        "v_add_f64 v[58:59], %[xs], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[46:47], " NEGX "v[54:55], %[ys], v[58:59]\n\t"                                                            \
+        "v_add_f64 v[58:59], %[ys], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[48:49], " NEGY "v[54:55], %[xs], v[58:59]\n\t"                                                            \
+        "v_mul_f64 v[58:59], %[rs], %[ys]\n\t"                                                                                 \
+        "v_mul_f64 v[60:61], %[rs], %[xs]\n\t"                                                                                 \
+        "v_fma_f64 %[xs], %[rc], %[xs], -v[58:59]\n\t"                                                                         \
+        "v_fma_f64 %[ys], %[rc], %[ys], v[60:61]\n\t"                                                                          \
+        "v_add_f64 v[58:59], %[xs], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[50:51], " NEGX "v[56:57], %[ys], v[58:59]\n\t"                                                            \
+        "v_add_f64 v[58:59], %[ys], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[52:53], " NEGY "v[56:57], %[xs], v[58:59]\n\t"                                                            \
+        "v_mul_f64 v[58:59], %[rs], %[ys]\n\t"                                                                                 \
+        "v_mul_f64 v[60:61], %[rs], %[xs]\n\t"                                                                                 \
+        "v_fma_f64 %[xs], %[rc], %[xs], -v[58:59]\n\t"                                                                         \
+        "v_fma_f64 %[ys], %[rc], %[ys], v[60:61]\n\t"                                                                          \
+        "v_add_u32 %[je], %[je], %[ince]\n\t"
+
+// one trip of both rays.  READ_A / READ_B: address + read of the cell byte (LDS window or global field); WAITALL: both bytes here
+#define MCL_SW2_TRIP(REMA, REMB, BYA, BYB, TAX, TAY, TBX, TBY, READ_A, READ_B, WAITALL, SWITCH_B, SWITCH_A)                     \
+        "v_mad_u64_u32 v[54:55], vcc, " BYA ", v46, " TAX "\n\t"                                                               \
+        "v_mad_u64_u32 v[56:57], vcc, " BYA ", v48, " TAY "\n\t"                                                               \
+        READ_A                                                                                                                 \
+        "v_min3_u32 %[g], %[g], v54, v56\n\t"                                                                                  \
+        SWITCH_B                                                                                                               \
+        "v_mad_u64_u32 v[58:59], vcc, " BYB ", v50, " TBX "\n\t"                                                               \
+        "v_mad_u64_u32 v[60:61], vcc, " BYB ", v52, " TBY "\n\t"                                                               \
+        READ_B                                                                                                                 \
+        "v_min3_u32 %[g], %[g], v58, v60\n\t"                                                                                  \
+        WAITALL                                                                                                                \
+        "v_sub_co_u32 v53, vcc, " REMB ", v49\n\t"                                                                             \
+        "s_andn2_b64 %[mb], exec, vcc\n\t"                                                                                     \
+        SWITCH_A                                                                                                               \
+        "v_sub_co_u32 v51, vcc, " REMA ", v47\n\t"                                                                             \
+        "s_andn2_b64 exec, exec, vcc\n\t"                                                                                      \
+        "s_or_b64 %[st], exec, %[mb]\n\t"                                                                                      \
+        "s_cbranch_scc0 2f\n\t"
+#define MCL_SW2_READ_A_LDS "v_lshl_or_b32 v47, v57, 8, v55\n\t" "ds_read_i8 v47, v47 offset:%[lb]\n\t"
+#define MCL_SW2_READ_B_LDS "v_lshl_or_b32 v49, v61, 8, v59\n\t" "ds_read_i8 v49, v49 offset:%[lb]\n\t"
+#define MCL_SW2_READ_A_GLB "v_mad_u32_u24 v47, v57, %[pitch], v55\n\t" "global_load_sbyte v47, v47, %[gbase]\n\t"
+#define MCL_SW2_READ_B_GLB "v_mad_u32_u24 v49, v61, %[pitch], v59\n\t" "global_load_sbyte v49, v49, %[gbase]\n\t"
+// (an odd number of slots: the walk's last pair has no ray B -- its mask starts empty and its table row is the all-zero one)
+#define MCL_SW2_TRIP_FIRST(RA, RB, W)                                                                                          \
+        "s_or_b32 %[cd], %[tc], %[even]\n\t"                                                                                   \
+        "s_cmp_eq_u32 %[cd], 0\n\t"                                                                                            \
+        "s_cselect_b64 %[mb], 0, -1\n\t"                                                                                       \
+        MCL_SW2_TRIP("%[rem0]", "%[rem0]", "%[s0]", "%[s0]", "%[p0x]", "%[p0y]", "%[p0x]", "%[p0y]", RA, RB, W,                 \
+                     "s_mov_b64 %[sa], exec\n\t" "s_mov_b64 exec, %[mb]\n\t", "s_mov_b64 exec, %[sa]\n\t")
+#define MCL_SW2_TRIP_NEXT(RA, RB, W)                                                                                           \
+        MCL_SW2_TRIP("v51", "v53", "v47", "v49", "v[54:55]", "v[56:57]", "v[58:59]", "v[60:61]", RA, RB, W,                      \
+                     "s_mov_b64 %[sa], exec\n\t" "s_mov_b64 exec, %[mb]\n\t", "s_mov_b64 exec, %[sa]\n\t")
+#define MCL_SW2_TRIPS(CDSET, RA, RB, W)                                                                                        \
+        MCL_SW2_TRIP_FIRST(RA, RB, W)                                                                                          \
+        CDSET                                                                                                                  \
+        "1:\n\t"                                                                                                               \
+        MCL_SW2_TRIP_NEXT(RA, RB, W)                                                                                           \
+        MCL_SW2_TRIP_NEXT(RA, RB, W)                                                                                           \
+        MCL_SW2_TRIP_NEXT(RA, RB, W)                                                                                           \
+        MCL_SW2_TRIP_NEXT(RA, RB, W)                                                                                           \
+        "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 1b\n\t"                                                                                                \
+        "s_mov_b32 %[expired], 1\n"                                                                                            \
+        "2:\n\t"                                                                                                               \
+        "s_mov_b64 exec, -1\n\t"                                                                                               \
+        "s_or_b32 %[cd], %[tc], %[even]\n\t"                                                                                   \
+        "s_cmp_eq_u32 %[cd], 0\n\t"                                                                                            \
+        "s_cbranch_scc0 4f\n\t"                                                                                                \
+        "v_mov_b32 v53, %[zrow]\n"                                                                                             \
+        "4:\n\t"
+#define MCL_SW2_EPILOGUE                                                                                                       \
+        "s_waitcnt vmcnt(0)\n\t" /* the previous pair's table entries landed */                                                \
+        "v_add_f64 %[acc], %[acc], v[42:43]\n\t"                                                                               \
+        "v_add_f64 %[acc], %[acc], v[44:45]\n\t"                                                                               \
+        "v_mad_i32_i24 v47, v51, %[st8], %[j8b]\n\t"                                                                           \
+        "v_mad_i32_i24 v49, v53, %[st8], %[j8b]\n\t"                                                                           \
+        "v_add_u32 %[j8b], %[j8b], %[ince]\n\t"                                                                                \
+        "global_load_dwordx2 v[42:43], v47, %[ltb]\n\t"                                                                        \
+        "global_load_dwordx2 v[44:45], v49, %[ltb] offset:8\n\t"                                                               \
+        "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 3b\n\t"                                                                                                \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[42:43]\n\t"                                                                               \
+        "v_add_f64 %[acc], %[acc], v[44:45]"
+#define MCL_SW2_CLOBBERS "memory", "vcc", "scc", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61"
+#define MCL_SW2_OUTPUTS [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xs] "+v"(xs), [ys] "+v"(ys),      \
+          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd), [mb] "=&s"(x2_mb), [sa] "=&s"(x2_sa), [st] "=&s"(x2_st)
+#define MCL_SW2_INPUTS [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e), [ince] "v"(inc16), [rc] "s"(a.rec_c), [rs] "s"(rec_s),   \
+          [ltb] "s"(a.Ltd), [st8] "s"(st8), [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [zrow] "s"(zrow), [even] "s"(x2_even)
+
+#define MCL_SW2_WALK(NEGX, NEGY)                                                                                               \
+    asm volatile(                                                                                                              \
+        "v_mov_b32 v47, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[42:43], v47, %[ltb]\n\t" /* 0.0 twice: the pattern of the steady state */                       \
+        "global_load_dwordx2 v[44:45], v47, %[ltb]\n\t"                                                                        \
+        "3:\n\t"                                                                                                               \
+        MCL_SW2_PROLOGUE(NEGX, NEGY)                                                                                           \
+        MCL_SW2_TRIPS("s_movk_i32 %[cd], 75\n\t", MCL_SW2_READ_A_LDS, MCL_SW2_READ_B_LDS, "s_waitcnt lgkmcnt(0)\n\t")           \
+        MCL_SW2_EPILOGUE                                                                                                       \
+        : MCL_SW2_OUTPUTS                                                                                                      \
+        : MCL_SW2_INPUTS, [lb] "n"(kQLdsBase)                                                                                  \
+        : MCL_SW2_CLOBBERS)
+
+#define MCL_SWG2_WALK(NEGX, NEGY)                                                                                              \
+    asm volatile(                                                                                                              \
+        "v_mov_b32 v47, %[zoff]\n\t"                                                                                           \
+        "global_load_dwordx2 v[42:43], v47, %[ltb]\n\t"                                                                        \
+        "global_load_dwordx2 v[44:45], v47, %[ltb]\n\t"                                                                        \
+        "3:\n\t"                                                                                                               \
+        MCL_SW2_PROLOGUE(NEGX, NEGY)                                                                                           \
+        MCL_SW2_TRIPS("s_mov_b32 %[cd], %[cdinit]\n\t", MCL_SW2_READ_A_GLB, MCL_SW2_READ_B_GLB, "s_waitcnt vmcnt(0)\n\t")       \
+        MCL_SW2_EPILOGUE                                                                                                       \
+        : MCL_SW2_OUTPUTS                                                                                                      \
+        : MCL_SW2_INPUTS, [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit4)                                      \
+        : MCL_SW2_CLOBBERS)
+
+// REC: the walk turns the beam direction instead of fetching it (MCL_SW_DIR_REC); PAIRS (with REC): two rays per lane (MCL_SW2_*).
+// Measured at 4M x 1081 (profiles/r05_experiments): REC -11 % everywhere; PAIRS on top of it -6 % in the global-field form and
+// -11 % on the uniform cloud of a first update (both wait for memory), +-0 on the tracking cloud in LDS windows and +2 % on the
+// levine stand-in (both bound by VALU issue by then): the host asks for PAIRS in the global-field form and for a freshly
+// initialised set.
+template <bool COUNT, bool GLOBAL = false, bool REC = false, bool PAIRS = false>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -763,9 +895,18 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 if (negy) ys = -ys;
                 const double rec_s = negy ? -a.rec_s : a.rec_s;           // wave-uniform
                 uint32_t je = ebase + ((uint32_t)((live ? jw : a.B) + a.beam_margin) << 3);
-                (void)j16; (void)inc16;
-                if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK_REC("", "-"); else MCL_SWG_WALK_REC("-", ""); }
-                else { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
+                (void)j16;
+                if constexpr (!PAIRS) {
+                    if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK_REC("", "-"); else MCL_SWG_WALK_REC("-", ""); }
+                    else { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
+                } else {
+                    // two rays per lane (MCL_SW2_*): ceil(walk_n / 2) pairs of slots
+                    const uint32_t x2_even = (walk_n & 1) ? 0u : 1u;
+                    tc = (uint32_t)((walk_n + 1) >> 1) - 1u;
+                    unsigned long long x2_mb, x2_sa, x2_st;
+                    if constexpr (GLOBAL) { if (negy) MCL_SWG2_WALK("", "-"); else MCL_SWG2_WALK("-", ""); }
+                    else { if (negy) MCL_SW2_WALK("", "-"); else MCL_SW2_WALK("-", ""); }
+                }
             } else {
                 if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK_TAB("-", "-"); else MCL_SWG_WALK_TAB("", ""); }
                 else { if (negy) MCL_SW_WALK_TAB("-", "-"); else MCL_SW_WALK_TAB("", ""); }

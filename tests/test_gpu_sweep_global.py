@@ -220,7 +220,6 @@ def test_narrow_map_long_range_particles_on_the_border(orc, engine_mod, shape):
         e = engine_mod.Engine(max_particles=n, seed=9, keep_ray_steps=keep, ray_kernel=engine_mod.RAYS_SWEEP)
         e.set_map(grid, res, ox, oy)
         e.set_beam_angles(ang)
-        assert "global memory" in e.planned_ray_kernel()[1]
         e.set_particles(p, np.full(n, 1.0 / n))
         e.sensor_update(obs)
         assert e.ray_kernel_name() == "k_rays_sweep"
