@@ -13,14 +13,14 @@ per-update host->device traffic is the 1081-float scan and the 3-double action o
 
 Rank 0 prints ONE JSON line.
 
-`roofline` names the bound that applies to the dominant kernel (k_rays_sweep): VALU issue.  Its inputs are the
-kernel's VALU instruction count (rocprofv3 PMC), the cycles one wave64 instruction of ITS instruction mix occupies a
-SIMD (tools/ubench/valu_rates.hip, measured on the box), the clock the kernel held (GRBM_GUI_ACTIVE) -- all read from
-profiles/rNN_roofline_inputs.json (the latest round's), which tools/roofline_inputs.py writes from the committed rocprofv3 /
-ubench outputs -- and the kernel duration measured live with HIP events on the engine's stream.  `roofline.algorithmic`
-keeps SURVEY.md §8(d)'s figure (per ray S-bar one-byte grid probes as the reference reads them, cpp:642, + one 4-byte
-table entry, cpp:576; per particle 32 B) priced against the HBM peak: it exceeds 1 because the kernel examines a
-tenth of those samples (same results, DESIGN.md §4.2) and is NOT a bound.
+`roofline` names the bound that applies to the dominant kernel (k_rays_sweep): VALU issue (a wave64 VALU instruction occupies
+its SIMD for one quad-cycle; 1024 SIMDs x 2.4 GHz).  `roofline.frac` is the USEFUL-WORK fraction -- the instructions the rays of
+the launch need with every lane busy (per ray and per probe trip, trips counted live) over the live kernel time (HIP events on
+the engine's stream); `roofline.valu.frac` is the ISSUE fraction, from the kernel's measured instruction count
+(profiles/rNN_roofline_inputs.json, which tools/roofline_inputs.py writes from the committed rocprofv3 PMC passes).
+`roofline.algorithmic` keeps SURVEY.md 8(d)'s figure (per ray S-bar one-byte grid probes as the reference reads them, cpp:642, +
+one 4-byte table entry, cpp:576; per particle 32 B) priced against the HBM peak: it exceeds 1 because the kernel examines a
+tenth of those samples (same results, DESIGN.md 4.2) and is NOT a bound.
 `cpu_baseline` times the CPU oracle's as-reference step (same materialised arrays and the same
 `omp parallel for schedule(dynamic)` ray loop as cpp:593) on this box's host cores.
 """
@@ -130,34 +130,47 @@ def _sha16(path):
         return None
 
 
-def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_live=None):
-    """VALU-issue bound of the dominant kernel from the committed profile inputs + the live kernel time.
+# VALU instructions of k_rays_sweep's walk per ray outside the trips / per trip, by the form that ran (csrc/mcl_rays_sweep.h;
+# tools/roofline_inputs.py checks the trip against the shipped binary):
+#   fetched directions (TAB): 4 FMA + index add | table: add, mad, add                                      =  8 per ray
+#   turned directions (REC):  4 (integers) + 4 (turn) + index add | table: add, mad, add                    = 12 per ray
+#   two rays per lane (REC + PAIRS): 16 + index add | 2 add, 2 mad, add per PAIR                            = 11 per ray
+#   trip: 2 v_mad_u64_u32, address, v_min3_u32, v_sub_co_u32                                                =  5 per trip
+WALK_VALU = {"tab": (8, 5), "rec": (12, 5), "pairs": (11, 5)}
 
-    gfx950 issues a wave64 instruction of the simple classes (v_add/v_sub/v_and/v_or/v_lshrrev/v_mov, fp32 add/mul/fma) in
-    2 cycles and everything else the kernel uses (v_mad_*24, 3-operand integer ops, compares, conversions, all fp64) in 4
-    (profiles/r02_op_rates.txt).  With I = VALU instructions and T = probe trips per launch (SQ_INSTS_VALU, SQ_INSTS_LDS:
-    one ds_read per trip), a trip is 5 four-cycle + 2 two-cycle instructions and the rest of the stream is 9/11
-    four-cycle (mcl_rays_sweep.h), so the launch needs at least
-        cycles = 4 I - 2 (2 T + (2/11) (I - 7 T))
-    SIMD issue cycles; the chip offers SIMDS x clock of them per second.  `frac` prices that against the MAXIMUM clock,
-    so it cannot exceed 1; `valu.at_measured_mix_rate` is the same with the rate tools/ubench/valu_rates.hip measures
-    for this exact instruction sequence (two-cycle instructions next to four-cycle ones do not reach 2) and the clock the
-    profiled run held: the kernel sits at ~1.0 of that."""
-    alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per launch (one GPU's shard), SURVEY §8(d)
+
+def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_live=None, variant=None):
+    """The bound of the dominant kernel: VALU issue.  A wave64 VALU instruction occupies its SIMD for one quad-cycle whatever its
+    kind (profiles/r05_pmc_sq2.csv: SQ_ACTIVE_INST_VALU, in quad-cycles, equals SQ_INSTS_VALU); the chip issues on 1024 SIMDs at
+    up to 2.4 GHz.
+
+    `frac` is the USEFUL-WORK fraction: what the rays of this launch need with all 64 lanes busy -- per ray the instructions of the
+    walk outside the trips and five per probe trip, trips per ray counted live by an untimed update -- priced at 4 cycles each
+    against 1024 SIMDs x 2.4 GHz, over the live kernel time.  The numerator does not grow with the kernel's own instruction count:
+    idle lanes in the lock-step trips (a wave makes 4.5 trips for a per-lane mean of 3.4), per-chunk set-up, window loads,
+    barriers and a clock below the maximum all lower it.
+    `valu.frac` is the ISSUE fraction: 4 cycles x the kernel's measured VALU instruction count (SQ_INSTS_VALU, a profile constant
+    of the default workload) over the same denominator -- how close the kernel as written is to the issue limit (the rest is waves
+    parked in s_waitcnt: SQ_WAIT_ANY).
+    `algorithmic` keeps SURVEY.md 8(d)'s bytes-over-HBM figure; it is not a bound (see the module docstring)."""
+    alg_bytes = n * B * (sbar * 1.0 + 4.0) + n * 32.0       # per launch (one GPU's shard), SURVEY 8(d)
     alg = {"bytes_per_launch": alg_bytes, "s_bar_probes_per_ray": sbar, "achieved": alg_bytes / (k_ms * 1e-3) / 1e9,
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "note": "SURVEY 8(d) algorithmic bytes / kernel time / 8 TB/s: not a bound (the kernel skips ~90 % of the priced samples)"}
-    block = {"bound": "valu", "kernel": kernel_name, "kernel_ms": k_ms, "algorithmic": alg, "traffic": None, "useful": None}
-    # USEFUL work, live: what the rays of this launch need with all 64 lanes busy -- per ray 11 VALU instructions outside the
-    # probe loop (9 four-cycle + 2 two-cycle: rotation of the beam direction, table offset, sums) and 7 per probe trip (5 + 2:
-    # MCL_SW_TRIP) -- priced at the class rates against 1024 SIMDs x 2.4 GHz.  Unlike `frac` the numerator does not grow with
-    # the kernel's own instruction count: idle lanes in the probe loop, per-chunk set-up, window loads and barriers all lower it.
+    block = {"bound": "valu", "kernel": kernel_name, "kernel_ms": k_ms, "achieved": None, "peak": SIMDS * MAX_CLOCK_GHZ,
+             "unit": "G SIMD issue cycles/s", "frac": None, "algorithmic": alg, "traffic": None, "useful": None, "valu": None}
+    if variant is not None:
+        block["kernel_form"] = variant
     if trips_live is not None and kernel_name == "k_rays_sweep":
-        per_ray_cycles = (9 * 4 + 2 * 2) + (5 * 4 + 2 * 2) * trips_live
-        useful_ms = n * B / 64.0 * per_ray_cycles / (SIMDS * MAX_CLOCK_GHZ * 1e6)
+        form = "tab" if not (variant or {}).get("turned_directions") else ("pairs" if (variant or {}).get("pairs") else "rec")
+        per_ray, per_trip = WALK_VALU[form]
+        insts_per_ray = per_ray + per_trip * trips_live
+        useful_ms = n * B / 64.0 * insts_per_ray * 4.0 / (SIMDS * MAX_CLOCK_GHZ * 1e6)
         block["useful"] = {"frac": useful_ms / k_ms, "floor_ms": useful_ms, "rays": n * B, "probe_trips_per_ray": trips_live,
-                           "valu_per_ray": 11 + 7 * trips_live, "issue_cycles_per_ray": per_ray_cycles,
-                           "note": "rays x (11 + 7 x live trips per ray) VALU at the class rates / 64 lanes / (1024 SIMDs x 2.4 GHz) / live kernel ms"}
+                           "valu_per_ray": insts_per_ray, "issue_cycles_per_ray": 4.0 * insts_per_ray, "form": form,
+                           "note": f"rays x ({per_ray} + {per_trip} x live trips per ray) VALU x 4 cycles / 64 lanes / (1024 SIMDs x 2.4 GHz) / live kernel ms"}
+        block["frac"] = useful_ms / k_ms
+        block["achieved"] = n * B / 64.0 * insts_per_ray * 4.0 / (k_ms * 1e-3) / 1e9
     inp = None
     if os.path.exists(ROOFLINE_INPUTS):
         try:
@@ -168,25 +181,20 @@ def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_
     # or cloud executes a different number of probe trips, so nothing is priced for it
     if inp and profiled_workload and inp.get("kernel") == kernel_name and inp.get("particles") == n and inp.get("beams") == B:
         I, T = inp["valu_insts_per_launch"], inp["lds_insts_per_launch"]
-        cycles = 4.0 * I - 2.0 * (2.0 * T + (2.0 / 11.0) * (I - 7.0 * T))
+        cycles = 4.0 * I * inp.get("quad_cycles_per_valu_inst", 1.0)
         floor_ms = cycles / (SIMDS * MAX_CLOCK_GHZ * 1e6)
-        mix_floor_ms = I * inp["cycles_per_valu_inst"] / (SIMDS * inp["clock_ghz"] * 1e6)
-        block.update({"achieved": cycles / (k_ms * 1e-3) / 1e9, "peak": SIMDS * MAX_CLOCK_GHZ, "unit": "G SIMD issue cycles/s",
-                      "frac": floor_ms / k_ms,
-                      "valu": {"insts_per_launch": I, "probe_trips_per_launch": T, "issue_cycles_per_launch": cycles,
-                               "cycles_per_inst": cycles / I, "simds": SIMDS, "clock_ghz": MAX_CLOCK_GHZ, "floor_ms": floor_ms,
-                               "frac": floor_ms / k_ms,
-                               "at_measured_mix_rate": {"cycles_per_inst": inp["cycles_per_valu_inst"], "clock_ghz": inp["clock_ghz"],
-                                                        "floor_ms": mix_floor_ms, "kernel_ms_while_profiled": inp["kernel_ms_while_profiled"],
-                                                        "frac": mix_floor_ms / inp["kernel_ms_while_profiled"]},
-                               "source": os.path.relpath(ROOFLINE_INPUTS, ROOT), "source_sha256_16": _sha16(ROOFLINE_INPUTS),
-                               "note": "insts_per_launch and probe_trips_per_launch are PROFILE CONSTANTS (rocprofv3 PMC passes of this "
-                                       "workload, committed under profiles/); only kernel_ms is measured by this run"},
-                      "traffic": inp.get("hbm_bytes_per_launch"),
-                      "traffic_source": inp.get("hbm_bytes_source")})
+        block["valu"] = {"insts_per_launch": I, "lds_insts_per_launch": T, "issue_cycles_per_launch": cycles, "simds": SIMDS,
+                         "clock_ghz": MAX_CLOCK_GHZ, "floor_ms": floor_ms, "frac": floor_ms / k_ms,
+                         "quad_cycles_per_valu_inst": inp.get("quad_cycles_per_valu_inst"),
+                         "wave_cycles_parked_frac": inp.get("wait_any_frac"), "clock_ghz_while_profiled": inp.get("clock_ghz"),
+                         "kernel_ms_while_profiled": inp.get("kernel_ms_while_profiled"),
+                         "source": os.path.relpath(ROOFLINE_INPUTS, ROOT), "source_sha256_16": _sha16(ROOFLINE_INPUTS),
+                         "note": "insts_per_launch is a PROFILE CONSTANT (rocprofv3 PMC passes of this workload, committed under "
+                                 "profiles/); only kernel_ms is measured by this run"}
+        block["traffic"] = inp.get("hbm_bytes_per_launch")
+        block["traffic_source"] = inp.get("hbm_bytes_source")
     else:
-        block.update({"achieved": None, "peak": SIMDS * MAX_CLOCK_GHZ, "unit": "G SIMD issue cycles/s", "frac": None,
-                      "note": "no profile inputs for this kernel / size / workload under profiles/: VALU bound not priced"})
+        block["note"] = "no profile inputs for this kernel / size / workload under profiles/: the issue fraction is not priced"
     return block
 
 
@@ -386,6 +394,7 @@ def main():
     counters = e.counters()
     exit_code = 0
     kernel_name = e.ray_kernel_name()
+    kernel_variant = e.ray_kernel_variant() if kernel_name == "k_rays_sweep" else None      # (of the last TIMED update)
 
     # ---- after the timed region: the state the last timed update left, then ONE more untimed update (probe counter on) whose
     #      resample indices the oracle checks.  A sharded run gathers every rank's log-weights and children's parents on rank 0
@@ -418,6 +427,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(m, ang, scan, true_pose, big=args.cpu_baseline_256k)
         parity, sbar_err = None, None
+        checker_failed = False
         orc = None
         try:
             # the oracle is test infrastructure: a box without it (no gcc, no oracle/) still gets its line, marked unchecked
@@ -426,33 +436,38 @@ def main():
         except (ImportError, OSError, subprocess.CalledProcessError) as ex:
             orc, sbar_err = None, repr(ex)
         if orc is not None:
-            # The oracle as the CHECKER of the run that was just timed (never inside the timed region): the log-weights the
-            # last timed update left for 4000 sampled particles of rank 0 against orc_eng_log_weights on those particles (which
-            # also gives S-bar, the reference's samples per ray, cpp:622-647), then the resample indices of the untimed update
-            # above -- all children of all ranks -- against the oracle's exact-CDF draw from the weights the timed update left.
-            # An oracle error or a mismatch from here on fails the run.
-            om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
-            L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
-            oi = orc.obs_index(scan, om)
-            pick = np.random.default_rng(7).choice(n, size=min(4000, n), replace=False)
-            logw_o, _, probes_o = orc.eng_log_weights(om, np.ascontiguousarray(pt_last[:, pick]), ang, oi, L)
-            sbar_timed = probes_o / float(pick.size * B)
-            _, _, probes_f = orc.eng_log_weights(om, sample_first, ang, oi, L)
-            sbar_first = probes_f / float(sample_first.shape[1] * B)
-            parity = {"n": int(pick.size), "logw_mismatches": int(np.count_nonzero(lw_last[pick] != logw_o))}
-            if idx_all is not None:
-                _, q_prev, _ = orc.eng_weights_from_log(lw_all)          # fixed-point weights of the WHOLE set (global maximum)
-                if mode == engine.RESAMPLE_MULTINOMIAL:
-                    want = orc.eng_resample_indices(q_prev, 0, k53=orc.eng_philox_k53(42, n_updates, 0, n_total))
-                else:
-                    want = orc.eng_resample_indices(q_prev, 1, k0=orc.eng_philox_k0(42, n_updates))
-                parity.update({"idx_n": int(n_total), "idx_mismatches": int(np.count_nonzero(idx_all != want)),
-                               "idx_scope": "all children of all ranks (global parent indices)" if world > 1 else "all children"})
-                del q_prev, want
+            try:
+                # The oracle as the CHECKER of the run that was just timed (never inside the timed region): the log-weights the
+                # last timed update left for 4000 sampled particles of rank 0 against orc_eng_log_weights on those particles (which
+                # also gives S-bar, the reference's samples per ray, cpp:622-647), then the resample indices of the untimed update
+                # above -- all children of all ranks -- against the oracle's exact-CDF draw from the weights the timed update left.
+                # An oracle error or a mismatch from here on fails the run.
+                om = orc.OracleMap(m.data, m.resolution, m.origin_x, m.origin_y)
+                L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+                oi = orc.obs_index(scan, om)
+                pick = np.random.default_rng(7).choice(n, size=min(4000, n), replace=False)
+                logw_o, _, probes_o = orc.eng_log_weights(om, np.ascontiguousarray(pt_last[:, pick]), ang, oi, L)
+                sbar_timed = probes_o / float(pick.size * B)
+                _, _, probes_f = orc.eng_log_weights(om, sample_first, ang, oi, L)
+                sbar_first = probes_f / float(sample_first.shape[1] * B)
+                parity = {"n": int(pick.size), "logw_mismatches": int(np.count_nonzero(lw_last[pick] != logw_o))}
+                if idx_all is not None:
+                    _, q_prev, _ = orc.eng_weights_from_log(lw_all)          # fixed-point weights of the WHOLE set (global maximum)
+                    if mode == engine.RESAMPLE_MULTINOMIAL:
+                        want = orc.eng_resample_indices(q_prev, 0, k53=orc.eng_philox_k53(42, n_updates, 0, n_total))
+                    else:
+                        want = orc.eng_resample_indices(q_prev, 1, k0=orc.eng_philox_k0(42, n_updates))
+                    parity.update({"idx_n": int(n_total), "idx_mismatches": int(np.count_nonzero(idx_all != want)),
+                                   "idx_scope": "all children of all ranks (global parent indices)" if world > 1 else "all children"})
+                    del q_prev, want
+            except Exception as ex:                  # noqa: BLE001 -- the checker failed: the line still goes out, marked, and the run fails
+                parity = {"error": repr(ex)}
+                checker_failed = True
         del pt_last, lw_all, idx_all
         k_ms = float(np.mean(ray_ms))
         roof = roofline_block(kernel_name, k_ms, n, B, sbar_timed if sbar_timed is not None else 43.4,
-                              profiled_workload=(args.map == "spielberg" and args.regime == "tracking"), trips_live=probes_live)
+                              profiled_workload=(args.map == "spielberg" and args.regime == "tracking"), trips_live=probes_live,
+                              variant=kernel_variant)
         # which kernel class AUTO gave this map / scan / size, and why, when it is not the fast windowed kernel
         roof["kernel_class_planned"] = planned_kernel
         if kernel_name != "k_rays_sweep":
@@ -491,11 +506,14 @@ def main():
             # stay in device memory; MCL_DIST_SYNC=1: a wait per exchanged value)
             line["host_waits_per_update"] = sf.host_waits
             # who runs the collectives of an update: the engine itself (mcl_comm_*: RCCL on its own stream, one native call per
-            # update) or dist.py through torch.distributed (gloo rehearsals, MCL_DIST_NATIVE=0)
+            # update: MCL_DIST_NATIVE=1) or dist.py through torch.distributed (the default)
             line["collectives"] = "engine (RCCL on the engine's stream)" if sf.native else f"torch.distributed ({args.backend})"
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-        if parity and (parity["logw_mismatches"] or parity.get("idx_mismatches", 0)):
+        if checker_failed:
+            sys.stderr.write(f"bench.py: THE PARITY CHECKER FAILED {parity}\n")
+            exit_code = 4
+        elif parity and (parity["logw_mismatches"] or parity.get("idx_mismatches", 0)):
             sys.stderr.write(f"bench.py: PARITY CHECK FAILED {parity}\n")
             exit_code = 3
     if dist is not None:

@@ -91,6 +91,7 @@ struct mcl_engine {
     int ltd_cols = 0;
     bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
+    int last_sweep_global = 0, last_sweep_rec = 0, last_sweep_pairs = 0;    // the form of k_rays_sweep the last ray stage ran
     int env_sweep_pairs = -1;           // MCL_SWEEP_PAIRS: -1 the engine decides, 0 / 1 forced (A/B measurements)
     bool sweep_rec_layout_ok = false;   // the same for the <.., REC> instantiations (LDS form: window + offset table; global form: the table)
     bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
@@ -927,6 +928,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // the tracking cloud gains nothing and the levine stand-in loses 2 %); MCL_SWEEP_PAIRS=0 / 1 overrides
         const bool sweep_pairs = sweep_rec && (h->env_sweep_pairs >= 0 ? h->env_sweep_pairs != 0 : (sweep_glob || a.far_windowed != 0));
         size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwSide * mcl::kSwSide) + (sweep_rec ? (size_t)h->ltd_cols * 8 : 0) : (size_t)h->qside * h->qside;
+        h->last_sweep_global = sweep_glob ? 1 : 0; h->last_sweep_rec = sweep_rec ? 1 : 0; h->last_sweep_pairs = (sweep_rec && (sweep_glob || sweep_pairs)) ? 1 : 0;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();
@@ -2205,6 +2207,13 @@ int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel)
 {
     if (!h || !kernel) return MCL_ERR_INVALID_ARG;
     *kernel = h->last_mode;
+    return MCL_OK;
+}
+
+int mcl_get_ray_kernel_variant(const mcl_engine_t *h, int32_t out[3])
+{
+    if (!h || !out) return MCL_ERR_INVALID_ARG;
+    out[0] = h->last_sweep_global; out[1] = h->last_sweep_rec; out[2] = h->last_sweep_pairs;
     return MCL_OK;
 }
 

@@ -42,7 +42,7 @@ EXPORTS = [
     "mcl_stream_wait_external", "mcl_external_wait_stream", "mcl_export_compact_async", "mcl_stage_resample_compact_async",
     "mcl_stage_rays_async", "mcl_stage_weights_async", "mcl_stage_complete", "mcl_stage_keep",
     "mcl_comm_available", "mcl_comm_unique_id", "mcl_comm_create", "mcl_comm_destroy", "mcl_comm_update", "mcl_comm_stats", "mcl_comm_set_lists", "mcl_comm_get_vector", "mcl_comm_last_exchange", "mcl_comm_selftest",
-    "mcl_host_sweep_global_layout",
+    "mcl_host_sweep_global_layout", "mcl_get_ray_kernel_variant",
 ]
 
 
@@ -368,6 +368,12 @@ class Engine:
         v = C.c_int32()
         self._chk(self.lib.mcl_get_ray_kernel_id(self._h, C.byref(v)), "mcl_get_ray_kernel_id")
         return {1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}.get(v.value, "?")
+
+    def ray_kernel_variant(self):
+        """Form of k_rays_sweep the last ray stage ran: dict(global_fields, turned_directions, pairs)."""
+        v = (C.c_int32 * 3)()
+        self._chk(self.lib.mcl_get_ray_kernel_variant(self._h, v), "mcl_get_ray_kernel_variant")
+        return dict(global_fields=bool(v[0]), turned_directions=bool(v[1]), pairs=bool(v[2]))
 
     RAY_KERNEL_NAMES = {0: None, 1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}
 

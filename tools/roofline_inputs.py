@@ -3,8 +3,9 @@
 
   * the dominant kernel's VALU instruction count and the clock it held -- rocprofv3 --pmc passes of the bench workload
     (counter_collection.csv: SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same dispatch);
-  * the cycles one wave64 VALU instruction of the kernel's own instruction mix occupies a SIMD -- the
-    "k_rays_sweep whole beam" row at 8 waves per SIMD of tools/ubench/valu_rates.hip's output;
+  * the quad-cycles one wave64 VALU instruction of the kernel occupies a SIMD -- SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the same
+    passes (1.0: four cycles whatever the kind) -- and the share of the wave-cycles the waves are parked in s_waitcnt / barriers
+    (SQ_WAIT_ANY / SQ_WAVE_CYCLES);
   * memory-side traffic per launch -- FETCH_SIZE / WRITE_SIZE passes (KB; FETCH_SIZE doubled as the MI355X guide
     prescribes for gfx950, which counts 128-byte read requests at 64 bytes).
 
@@ -25,7 +26,8 @@ def counters(path):
     v = defaultdict(list)
     for r in csv.DictReader(open(path)):
         # (<true, ..> = the probe-counting build of bench.py's untimed update; <.., true> = the global-field form of long-range maps)
-        if KERNEL in r["Kernel_Name"] and "sweep<true" not in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]:
+        # (the timed updates of the default workload run <false, false, REC, false>: LDS windows, one ray per lane)
+        if KERNEL in r["Kernel_Name"] and "sweep<true" not in r["Kernel_Name"] and "sweep<false, true" not in r["Kernel_Name"]:
             v[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return v
 
@@ -42,17 +44,15 @@ gui, dur_ns = steady(b["GRBM_GUI_ACTIVE"])
 clock_ghz = gui / 8.0 / dur_ns
 fetch_kb, _ = steady(f["FETCH_SIZE"])
 write_kb, _ = steady(w["WRITE_SIZE"])
-cpi = None
-for line in open(ub):
-    if "k_rays_sweep whole beam" in line and "W=8" in line:
-        cpi = float(re.search(r"([0-9.]+) \(wall x clock\)", line).group(1))
-assert cpi, "ubench row not found"
+active, _ = steady(b["SQ_ACTIVE_INST_VALU"]) if b.get("SQ_ACTIVE_INST_VALU") else (None, None)
+wait_any, _ = steady(b["SQ_WAIT_ANY"]) if b.get("SQ_WAIT_ANY") else (None, None)
+wave_cycles, _ = steady(a["SQ_WAVE_CYCLES"]) if a.get("SQ_WAVE_CYCLES") else (None, None)
 
 
 def trip_mix_from_disassembly():
     """The probe trip of the beam walk as the shipped library contains it: opcode sequence of the loop body between the two
     `s_cbranch_execz` of MCL_SW_WALK, classified by the issue classes of profiles/*_op_rates.txt.  bench.py's VALU bound
-    assumes 5 four-cycle + 2 two-cycle VALU instructions per trip; this records what the binary really has."""
+    assumes 5 VALU instructions per trip; this records what the binary really has."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,19 +62,19 @@ def trip_mix_from_disassembly():
     txt = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_meta.py"), lib, "--disasm", "k_rays_sweepILb0"],
                          capture_output=True, text=True).stdout
     ops = [re.sub(r"_e(32|64)$", "", l.split()[0]) for l in txt.splitlines() if l.startswith("\t")]
-    two = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_mov_b32", "v_lshrrev_b32", "v_ashrrev_i32"}
-    want = ["v_mad_u32_u24", "v_mad_u32_u24", "v_perm_b32", "ds_read_i8", "v_and_b32", "v_and_b32", "v_min3_u32", "s_waitcnt", "v_sub_co_u32", "s_andn2_b64"]
+    want = ["v_mad_u64_u32", "v_mad_u64_u32", "v_lshl_or_b32", "ds_read_i8", "v_min3_u32", "s_waitcnt", "v_sub_co_u32", "s_andn2_b64"]
     hits = [i for i in range(len(ops) - len(want)) if ops[i:i + len(want)] == want]
     if not hits:
         return {"verified": False}
     valu = [o for o in want if o.startswith("v_")]
-    return {"verified": True, "occurrences": len(hits), "valu_per_trip": len(valu), "two_cycle": sum(o in two for o in valu),
-            "four_cycle": sum(o not in two for o in valu), "sequence": want}
+    return {"verified": True, "occurrences": len(hits), "valu_per_trip": len(valu), "sequence": want}
 
 
 out = {
     "kernel": KERNEL, "particles": int(n), "beams": int(B),
-    "valu_insts_per_launch": insts, "lds_insts_per_launch": lds, "cycles_per_valu_inst": cpi, "simds": 1024, "clock_ghz": round(clock_ghz, 4),
+    "valu_insts_per_launch": insts, "lds_insts_per_launch": lds, "simds": 1024, "clock_ghz": round(clock_ghz, 4),
+    "quad_cycles_per_valu_inst": (active / insts) if active else None,
+    "wait_any_frac": (wait_any / wave_cycles) if wait_any and wave_cycles else None,
     "kernel_ms_while_profiled": dur_ns / 1e6,
     "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
     "hbm_bytes_source": f"profiles/{tag}_pmc_*.csv: 2 x FETCH_SIZE + WRITE_SIZE (KB) of {KERNEL}, steady-state launches; "
@@ -83,7 +83,7 @@ out = {
     "probe_trip_in_binary": trip_mix_from_disassembly(),
     "sources": {"SQ_INSTS_VALU": f"profiles/{tag}_pmc_sq.csv", "GRBM_GUI_ACTIVE": f"profiles/{tag}_pmc_sq2.csv",
                 "FETCH_SIZE": f"profiles/{tag}_pmc_fetch.csv", "WRITE_SIZE": f"profiles/{tag}_pmc_write.csv",
-                "cycles_per_valu_inst": f"profiles/{tag}_valu_rates.txt, row 'k_rays_sweep whole beam', W=8, wall x clock"},
+                "SQ_ACTIVE_INST_VALU, SQ_WAIT_ANY": f"profiles/{tag}_pmc_sq2.csv", "SQ_WAVE_CYCLES": f"profiles/{tag}_pmc_sq.csv"},
 }
 json.dump(out, open(f"{outdir}/{tag}_roofline_inputs.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
