@@ -901,7 +901,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
             a.beam_csx = h->sweep_global ? h->d_beam_csxg : h->d_beam_csx; a.beam_pad = h->beam_pad; a.beam_margin = h->beam_margin;
-            a.beam_csi = h->d_beam_csi; a.beam_err = h->d_beam_err; a.rec_c = h->rec_c; a.rec_s = h->rec_s;
+            a.beam_csi = h->d_beam_csi; a.beam_err = h->d_beam_err; a.rec_k = 2.0 * h->rec_c;
             a.distg = h->d_distg; a.distg_stride = h->distg_stride; a.distg_pitch = h->distg_pitch;
             a.items = h->d_items; a.centres = h->d_centres; a.nitems = 0; a.nitems_ptr = h->d_nitems; a.unit_sums = h->d_unit_sums; a.unit_begin = h->d_unit_begin; a.slot_space = 1;
             if (!h->d_far_list) {

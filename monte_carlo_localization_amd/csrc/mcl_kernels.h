@@ -710,7 +710,7 @@ struct RayArgs {
     int beam_pad, beam_margin;     // beams of a full wedge up to which a scan-edge lane is padded with virtual beams (0: never); see k_rays_sweep
     const double2 *beam_csi;       // k_rays_sweep<.., REC>: (cos, sin) of the GRID angle a0 + j inc of every table column (entry j + beam_margin)
     const double *beam_err;        //   and the beam's own offset from it, a_j - (a0 + j inc) (0 for virtual beams and padding): ltd_cols entries
-    double rec_c, rec_s;           //   cos / sin of the grid increment
+    double rec_k;                  //   2 cos(inc): the three-term recurrence of the turned direction (MCL_SW_STEP_REC)
     const float *beam_angle;       // float angles (MARCH path uses theta + (double)angle)
     double beam_a0, beam_inv_inc;  // first angle and beams per radian (k_rays_cell's guess of a wedge's first beam)
     const float *Lt;               // (P+1) x bpad

@@ -339,26 +339,23 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "global_load_dwordx4 v[40:43], %[j16], %[csb]\n\t" /* next beam's direction */
 // REC (an evenly spaced scan, mcl_set_beam_angles: every angle within 2e-6 rad of the grid a0 + j inc -- any real lidar's): no
 // gather.  The 16-byte gather of TAB costs the ray stage a tenth of its time (the texture path takes 64 addresses and 1 KB per
-// ray; timing-only variants in profiles/r05_experiments).  Here the lane carries the scaled, mirrored direction of the GRID angle
-// of its current beam as two fp64 values (xs, ys) and turns them by the grid increment per beam,
-//   xs' = c xs - nu s ys,  ys' = c ys + nu s xs        (c, s = cos / sin of the increment; nu = -1 in the quadrants mirrored in one axis)
-// (four fp64 instructions; the error of 90 such steps is 2^-13 unit), and the beam's own offset from the grid e_j = a_j - (a0 + j inc)
-// -- the float rounding of its angle, a few 1e-8 rad, 8 bytes per beam in LDS behind the window -- enters to first order where the
-// integers are made:  Xx = xs - nu e ys + (magic + 1),  Xy = ys + nu e xs + (magic + 1)   (the second-order term e^2 / 2 is below
-// 1e-2 unit).  Same two roundings, same bound as TAB.  v[40:41] = e_j, read one beam ahead.
-// NEGX = "-" / NEGY = "" normally, "" / "-" where nu = -1.
-#define MCL_SW_DIR_REC(NEGX, NEGY)                                                                                              \
-        "s_waitcnt lgkmcnt(0)\n\t" /* e_j landed (trivially: the previous beam's trips waited for later reads) */              \
-        "v_add_f64 v[48:49], %[xs], %[magic1]\n\t"                                                                             \
-        "v_fma_f64 v[44:45], " NEGX "v[40:41], %[ys], v[48:49]\n\t"                                                            \
-        "v_add_f64 v[48:49], %[ys], %[magic1]\n\t"                                                                             \
-        "v_fma_f64 v[46:47], " NEGY "v[40:41], %[xs], v[48:49]\n\t"                                                            \
-        "v_mul_f64 v[42:43], %[rs], %[ys]\n\t"                                                                                 \
-        "v_mul_f64 v[48:49], %[rs], %[xs]\n\t"                                                                                 \
-        "v_fma_f64 %[xs], %[rc], %[xs], -v[42:43]\n\t"                                                                         \
-        "v_fma_f64 %[ys], %[rc], %[ys], v[48:49]\n\t"                                                                          \
-        "v_add_u32 %[je], %[je], %[ince]\n\t"                                                                                  \
-        "ds_read_b64 v[40:41], %[je]\n\t" /* next beam's offset from the grid */
+// ray; timing-only variants in profiles/r05_experiments).  Here the lane carries the scaled, mirrored directions of the GRID
+// angles of TWO consecutive beams as fp64 pairs (xa, ya), (xb, yb) and steps them with the three-term recurrence of a rotation,
+//   d(j + 2) = K d(j + 1) - d(j),   K = 2 cos(inc)
+// -- one v_fma_f64 per component and beam, the same in every mirrored frame (it is linear in each component); 90 steps leave an
+// error of 2^-9 unit -- and the beam's own offset from the grid e_j = a_j - (a0 + j inc) -- the float rounding of its angle, a
+// few 1e-8 rad, 8 bytes per beam in LDS behind the window -- enters to first order where the integers are made:
+//   Xx = x - nu e y + (magic + 1),  Xy = y + nu e x + (magic + 1)     (nu = -1 in the quadrants mirrored in one axis)
+// (the second-order term e^2 / 2 is below 1e-2 unit).  Same two roundings, same bound as TAB.  Six VALU per beam (TAB: four and
+// the gather).  NEGX = "-" / NEGY = "" normally, "" / "-" where nu = -1.  E = the register pair holding e_j.
+#define MCL_SW_INTS_REC(NEGX, NEGY, E, XS, YS)                                                                                  \
+        "v_add_f64 v[48:49], " XS ", %[magic1]\n\t"                                                                            \
+        "v_fma_f64 v[44:45], " NEGX E ", " YS ", v[48:49]\n\t"                                                                  \
+        "v_add_f64 v[48:49], " YS ", %[magic1]\n\t"                                                                            \
+        "v_fma_f64 v[46:47], " NEGY E ", " XS ", v[48:49]\n\t"
+#define MCL_SW_STEP_REC(XS, YS, XO, YO) /* (XS, YS) two beams on: K * other - self */                                           \
+        "v_fma_f64 " XS ", %[rk], " XO ", -" XS "\n\t"                                                                          \
+        "v_fma_f64 " YS ", %[rk], " YO ", -" YS "\n\t"
 
 // ---- the trips of one ray: the first, then six per turn of a loop -- a ray makes 3.4, a wave 4.5 -- so that the walk sees not-taken
 // exit branches only (the countdown and its taken branch cost a wave ~20 cycles per trip in a chain that is latency-bound,
@@ -401,6 +398,26 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 3b\n\t"                                                                                                \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]"
+// (REC: two beams per turn of the loop: the first beam's tail leaves the loop when it was the walk's last; the table columns of
+//  the two are 8 bytes apart, the column offset moves once per turn)
+#define MCL_SW_TAIL_A                                                                                                          \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
+        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
+        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
+        "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
+        "s_cbranch_scc1 5f\n\t"
+#define MCL_SW_TAIL_B                                                                                                          \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
+        "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
+        "v_add_u32 %[j8b], %[j8b], %[ince]\n\t"                                                                                \
+        "global_load_dwordx2 v[50:51], v48, %[ltb] offset:8\n\t"                                                               \
+        "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 3b\n"                                                                                                  \
+        "5:\n\t"                                                                                                               \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                               \
+        "v_add_f64 %[acc], %[acc], v[50:51]"
 #define MCL_SW_CLOBBERS "memory", "vcc", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v57"
 
 #define MCL_SW_WALK_TAB(NEGA, NEGB)                                                                                            \
@@ -421,17 +438,25 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
 
 #define MCL_SW_WALK_REC(NEGX, NEGY)                                                                                            \
     asm volatile(                                                                                                              \
-        "ds_read_b64 v[40:41], %[je]\n\t"                                                                                      \
+        "ds_read2_b64 v[40:43], %[je] offset1:1\n\t" /* offsets of the first two beams; the next two are read a turn ahead */  \
         "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0 */                                                              \
         "3:\n\t"                                                                                                               \
-        MCL_SW_DIR_REC(NEGX, NEGY)                                                                                             \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+        MCL_SW_INTS_REC(NEGX, NEGY, "v[40:41]", "%[xa]", "%[ya]")                                                              \
         MCL_SW_TRIPS_LDS                                                                                                       \
-        MCL_SW_TAIL("s_waitcnt vmcnt(0)\n\t")                                                                                  \
-        : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xs] "+v"(xs), [ys] "+v"(ys),                  \
-          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
+        MCL_SW_TAIL_A                                                                                                          \
+        MCL_SW_STEP_REC("%[xa]", "%[ya]", "%[xb]", "%[yb]")                                                                    \
+        MCL_SW_INTS_REC(NEGX, NEGY, "v[42:43]", "%[xb]", "%[yb]")                                                              \
+        "v_add_u32 %[je], %[je], %[ince]\n\t"                                                                                  \
+        "ds_read2_b64 v[40:43], %[je] offset1:1\n\t"                                                                           \
+        MCL_SW_TRIPS_LDS                                                                                                       \
+        MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
+        MCL_SW_TAIL_B                                                                                                          \
+        : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xa] "+v"(xa), [ya] "+v"(ya), [xb] "+v"(xb),   \
+          [yb] "+v"(yb), [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                \
         : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
-          [ince] "v"(inc8), [inc8] "v"(inc8), [rc] "s"(a.rec_c), [rs] "s"(rec_s), [ltb] "s"(a.Ltd), [st8] "s"(st8),             \
+          [ince] "v"(inc16), [rk] "s"(a.rec_k), [ltb] "s"(a.Ltd), [st8] "s"(st8),                                               \
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
         : MCL_SW_CLOBBERS)
 
@@ -491,23 +516,6 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff)                                                                   \
         : MCL_SW_CLOBBERS)
 
-#define MCL_SWG_WALK_REC(NEGX, NEGY)                                                                                           \
-    asm volatile(                                                                                                              \
-        "ds_read_b64 v[40:41], %[je]\n\t"                                                                                      \
-        "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
-        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
-        "3:\n\t"                                                                                                               \
-        MCL_SW_DIR_REC(NEGX, NEGY)                                                                                             \
-        MCL_SW_TRIPS_GLB                                                                                                       \
-        MCL_SW_TAIL("s_waitcnt vmcnt(0)\n\t")                                                                                  \
-        : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xs] "+v"(xs), [ys] "+v"(ys),                  \
-          [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
-        : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
-          [ince] "v"(inc8), [inc8] "v"(inc8), [rc] "s"(a.rec_c), [rs] "s"(rec_s), [ltb] "s"(a.Ltd), [st8] "s"(st8),             \
-          [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit4),                                                     \
-          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff)                                                                   \
-        : MCL_SW_CLOBBERS)
-
 // ---- TWO rays per lane (REC walks with an even number of slots): beams j and j + 1 of the lane's particle march in the same
 // trip loop.  The walk is bound by the latency of its dependent chain (mad -> address -> LDS read -> wait -> borrow -> exec ->
 // branch: ~150 cycles per trip and wave, eight waves per SIMD cover 8 x 20 issue cycles of it; SQ_WAIT_ANY = 70 % of the wave
@@ -520,22 +528,16 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
 #define MCL_SW2_PROLOGUE(NEGX, NEGY)                                                                                            \
         "ds_read2_b64 v[54:57], %[je] offset1:1\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
-        "v_add_f64 v[58:59], %[xs], %[magic1]\n\t"                                                                             \
-        "v_fma_f64 v[46:47], " NEGX "v[54:55], %[ys], v[58:59]\n\t"                                                            \
-        "v_add_f64 v[58:59], %[ys], %[magic1]\n\t"                                                                             \
-        "v_fma_f64 v[48:49], " NEGY "v[54:55], %[xs], v[58:59]\n\t"                                                            \
-        "v_mul_f64 v[58:59], %[rs], %[ys]\n\t"                                                                                 \
-        "v_mul_f64 v[60:61], %[rs], %[xs]\n\t"                                                                                 \
-        "v_fma_f64 %[xs], %[rc], %[xs], -v[58:59]\n\t"                                                                         \
-        "v_fma_f64 %[ys], %[rc], %[ys], v[60:61]\n\t"                                                                          \
-        "v_add_f64 v[58:59], %[xs], %[magic1]\n\t"                                                                             \
-        "v_fma_f64 v[50:51], " NEGX "v[56:57], %[ys], v[58:59]\n\t"                                                            \
-        "v_add_f64 v[58:59], %[ys], %[magic1]\n\t"                                                                             \
-        "v_fma_f64 v[52:53], " NEGY "v[56:57], %[xs], v[58:59]\n\t"                                                            \
-        "v_mul_f64 v[58:59], %[rs], %[ys]\n\t"                                                                                 \
-        "v_mul_f64 v[60:61], %[rs], %[xs]\n\t"                                                                                 \
-        "v_fma_f64 %[xs], %[rc], %[xs], -v[58:59]\n\t"                                                                         \
-        "v_fma_f64 %[ys], %[rc], %[ys], v[60:61]\n\t"                                                                          \
+        "v_add_f64 v[58:59], %[xa], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[46:47], " NEGX "v[54:55], %[ya], v[58:59]\n\t"                                                            \
+        "v_add_f64 v[58:59], %[ya], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[48:49], " NEGY "v[54:55], %[xa], v[58:59]\n\t"                                                            \
+        "v_add_f64 v[58:59], %[xb], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[50:51], " NEGX "v[56:57], %[yb], v[58:59]\n\t"                                                            \
+        "v_add_f64 v[58:59], %[yb], %[magic1]\n\t"                                                                             \
+        "v_fma_f64 v[52:53], " NEGY "v[56:57], %[xb], v[58:59]\n\t"                                                            \
+        MCL_SW_STEP_REC("%[xa]", "%[ya]", "%[xb]", "%[yb]")                                                                    \
+        MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
         "v_add_u32 %[je], %[je], %[ince]\n\t"
 
 // one trip of both rays.  READ_A / READ_B: address + read of the cell byte (LDS window or global field); WAITALL: both bytes here
@@ -604,9 +606,10 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "v_add_f64 %[acc], %[acc], v[42:43]\n\t"                                                                               \
         "v_add_f64 %[acc], %[acc], v[44:45]"
 #define MCL_SW2_CLOBBERS "memory", "vcc", "scc", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61"
-#define MCL_SW2_OUTPUTS [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xs] "+v"(xs), [ys] "+v"(ys),      \
+#define MCL_SW2_OUTPUTS [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xa] "+v"(xa), [ya] "+v"(ya),      \
+          [xb] "+v"(xb), [yb] "+v"(yb),                                                                                        \
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd), [mb] "=&s"(x2_mb), [sa] "=&s"(x2_sa), [st] "=&s"(x2_st)
-#define MCL_SW2_INPUTS [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e), [ince] "v"(inc16), [rc] "s"(a.rec_c), [rs] "s"(rec_s),   \
+#define MCL_SW2_INPUTS [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e), [ince] "v"(inc16), [rk] "s"(a.rec_k),   \
           [ltb] "s"(a.Ltd), [st8] "s"(st8), [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [zrow] "s"(zrow), [even] "s"(x2_even)
 
 #define MCL_SW2_WALK(NEGX, NEGY)                                                                                               \
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         : MCL_SW2_INPUTS, [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit4)                                      \
         : MCL_SW2_CLOBBERS)
 
-// REC: the walk turns the beam direction instead of fetching it (MCL_SW_DIR_REC); PAIRS (with REC): two rays per lane (MCL_SW2_*).
+// REC: the walk turns the beam direction instead of fetching it (MCL_SW_INTS_REC, MCL_SW_STEP_REC); PAIRS (with REC): two rays per lane (MCL_SW2_*).
 // Measured at 4M x 1081 (profiles/r05_experiments): REC -11 % everywhere; PAIRS on top of it -6 % in the global-field form and
 // -11 % on the uniform cloud of a first update (both wait for memory), +-0 on the tracking cloud in LDS windows and +2 % on the
 // levine stand-in (both bound by VALU issue by then): the host asks for PAIRS in the global-field form and for a freshly
@@ -889,16 +892,16 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
             if constexpr (REC) {
-                // the direction of the GRID angle of the walk's first beam, scaled and mirrored like aq / bq (see MCL_SW_DIR_REC)
-                const double2 ci = a.beam_csi[(live ? jw : a.B) + a.beam_margin];
-                double xs = __builtin_fma(aq, ci.x, -(bq * ci.y)), ys = __builtin_fma(bq, ci.x, aq * ci.y);
-                if (negy) ys = -ys;
-                const double rec_s = negy ? -a.rec_s : a.rec_s;           // wave-uniform
+                // the directions of the GRID angles of the walk's first two beams, scaled and mirrored like aq / bq (MCL_SW_INTS_REC)
+                const double2 ci = a.beam_csi[(live ? jw : a.B) + a.beam_margin], cj = a.beam_csi[(live ? jw : a.B) + a.beam_margin + 1];
+                double xa = __builtin_fma(aq, ci.x, -(bq * ci.y)), ya = __builtin_fma(bq, ci.x, aq * ci.y);
+                double xb = __builtin_fma(aq, cj.x, -(bq * cj.y)), yb = __builtin_fma(bq, cj.x, aq * cj.y);
+                if (negy) { ya = -ya; yb = -yb; }
                 uint32_t je = ebase + ((uint32_t)((live ? jw : a.B) + a.beam_margin) << 3);
                 (void)j16;
                 if constexpr (!PAIRS) {
-                    if constexpr (GLOBAL) { if (negy) MCL_SWG_WALK_REC("", "-"); else MCL_SWG_WALK_REC("-", ""); }
-                    else { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
+                    static_assert(PAIRS || !GLOBAL || !REC, "the global-field form walks pairs when it turns the directions");
+                    if constexpr (!GLOBAL) { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
                 } else {
                     // two rays per lane (MCL_SW2_*): ceil(walk_n / 2) pairs of slots
                     const uint32_t x2_even = (walk_n & 1) ? 0u : 1u;
