@@ -21,242 +21,20 @@
 #include <string>
 #include <vector>
 
+#include "mcl_engine_internal.h"
 #include "mcl_kernels.h"
 
 namespace {
 
 thread_local std::string g_create_error;
 
-enum { EV_START = 0, EV_RESAMPLE, EV_QUERY, EV_RAYS, EV_SENSOR, EV_K0, EV_K1, EV_COUNT };   // K0..K1 bracket the dominant kernel
-
 }  // namespace
 
 static_assert(MCL_WEDGES == mcl::kWedges || MCL_KWEDGES != 16, "include/mcl_hip_engine.h and csrc/mcl_wedge.h disagree");
 
-constexpr unsigned long long kExactCap = 1ull << 16;   // level-3 rays per launch handled by k_rays_exact (more: inline)
-// d_result / h_result: [0..7] scalars, [8..11] counters, [12] work-list overflow flag, [13] work counter, [14] level-3 list
-// length, [15] far-list length (and the staging word of a global maximum), [16] length of the compact parent list
-constexpr int kResultWords = 17;
-constexpr int kResultStage = 40;             // h_result word that stages a host value on its way to the device
-constexpr int kResultStamp = 32;             // h_result word a small update's last kernel stamps (the host polls it)
-
-struct mcl_comm;
-static void comm_free(struct mcl_comm *c);
-static void comm_forget(struct mcl_comm *c);
-struct mcl_engine {
-    mcl_config_t cfg{};
-    int num_cu = 256;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // the per-update observation tables are built here, beside the resampling and ordering kernels
-    hipEvent_t ev_obs = nullptr;        // ... and the ray stage waits for this
-    hipEvent_t ev[EV_COUNT]{};
-    std::string err;
-
-    // map
-    bool have_map = false;
-    int W = 0, H = 0, P = 0, Wp = 0, Hp = 0, Wps = 0, tw_cells = 0;
-    double res = 0, ox = 0, oy = 0;
-    std::vector<double> table;          // (P+1)^2 column-major (d*(P+1)+r)
-    int8_t *d_grid = nullptr;
-    uint8_t *d_dist = nullptr;
-    uint8_t *d_dist4 = nullptr;         // nibble-packed copy of d_dist (k_rays_skip's LDS window is a straight copy of it)
-    uint8_t *d_distq[4]{};              // directional skip fields, one per quadrant (k_rays_quad / k_rays_far)
-    float *d_L = nullptr;               // [r_obs][d]
-    double *d_table = nullptr;          // double table (product mode)
-
-    // beams
-    int B = 0, bpad = 0;
-    std::vector<float> angles;
-    float *d_angle = nullptr;
-    double2 *d_beam_cs = nullptr;
-    double2 *d_beam_csx = nullptr;      // k_rays_sweep's copy with virtual beams either side (set_beam_angles)
-    double2 *d_beam_csxg = nullptr;     // the same for the global-field form: a virtual beam repeats the first / last REAL beam
-    // k_rays_sweep<.., REC> (an evenly spaced scan): directions of the grid angles a0 + j inc, every beam's offset from its grid angle
-    // (one entry per table column), cos / sin of the increment; rec_ok: the scan qualifies
-    double2 *d_beam_csi = nullptr;
-    double *d_beam_err = nullptr;
-    double rec_c = 1.0, rec_s = 0.0;
-    bool rec_ok = false;
-    int beam_pad = 0, beam_margin = 0;
-    int32_t *d_obs_idx = nullptr;
-    float *d_obs = nullptr;
-    float *h_obs = nullptr;             // pinned staging for the per-update scan
-    uint32_t *d_free = nullptr;         // linear indices of free cells (data == 0), row-major, cpp:199-213
-    uint64_t n_free = 0;
-    uint32_t init_idx = 0;
-    float *d_Lt = nullptr;
-    size_t lt_capacity = 0;
-    double *d_Ltd = nullptr;            // k_rays_sweep's fp64 table (mcl_rays_sweep.h), built per update when that kernel runs
-    size_t ltd_capacity = 0;
-    int ltd_cols = 0;
-    bool ltd_ready = false;             // d_Ltd holds the table of the observation in d_obs_idx (cleared when a new scan is staged)
-    bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
-    int last_sweep_global = 0, last_sweep_rec = 0, last_sweep_pairs = 0;    // the form of k_rays_sweep the last ray stage ran
-    int env_sweep_pairs = -1;           // MCL_SWEEP_PAIRS: -1 the engine decides, 0 / 1 forced (A/B measurements)
-    bool sweep_rec_layout_ok = false;   // the same for the <.., REC> instantiations (LDS form: window + offset table; global form: the table)
-    bool quad_layout_ok = false, cell_layout_ok = false;   // the same for k_rays_quad / k_rays_cell
-    bool skip_layout_ok = false;        // k_rays_skip has no static LDS (its window is addressed from LDS offset 0)
-    // k_rays_sweep on the wedge fields in GLOBAL memory (ranges a 256-cell LDS window cannot hold; MCL_SWEEP_GLOBAL=1 forces it)
-    uint8_t *d_distg = nullptr;         // kWedges mirrored fields with a two-cell stop ring and a tail of stop rows each (k_ring_field)
-    int distg_pitch = 0;                // row pitch
-    size_t distg_stride = 0;            // bytes per field, tail included
-    const char *distg_why_not = nullptr;     // why the global-field form of k_rays_sweep is not available for this map, if it is not
-    bool sweep_global = false;          // this map takes the global-field variant (decided at mcl_set_map)
-    bool env_sweep_global = false;
-    int env_sw_split16 = -1;            // MCL_SW_SPLIT16=0/1 forces RayArgs::split16 (default: by size)
-    bool env_no_obs_overlap = false;    // MCL_NO_OBS_OVERLAP: the observation tables are built on the main stream, after the resampling kernel
-    bool env_no_prep_fold = false;      // MCL_NO_PREP_FOLD: k_prep_small stays a launch of its own
-    // the few words the ray stage wants cleared (k_prep_small's job): what the last windowed launch passed, so that the NEXT
-    // update's resampling kernel can do it (prep_folded: it did, with exactly prep_cache)
-    mcl::PrepClear prep_cache{};
-    bool prep_cache_valid = false, prep_folded = false;
-    int64_t prep_cache_n = 0;
-    bool max_partials_ready = false;    // k_combine_logw left the per-workgroup maxima of d_logw in d_part
-    int4 *d_items = nullptr;            // k_rays_sweep's work items (guided schedule), planned on the device every update
-    int4 *d_centres = nullptr;          // per run of units: window centre, first unit, units (k_sweep_plan)
-    size_t items_capacity = 0;
-    int *d_nitems = nullptr;            // number of work items (written by k_sweep_plan)
-    int64_t plan_n = 0;
-    double4 *d_unit_sums = nullptr;     // per unit of the sorted order: (sum px, sum py, count, -), bounding box
-    uint32_t *d_unit_begin = nullptr;   // first slot of every unit + one (k_unit_table)
-    int *d_nunits = nullptr;            // number of units of this update's sorted order
-    size_t unit_sums_capacity = 0;
-    // environment knobs, read once at mcl_create (0 / negative = default)
-    int64_t env_cell_min = 0, env_cell_slice = 0;
-    int env_qslices_per_cu = 0, env_qside = 0, env_sweep_g = 0;
-    std::string env_debug_wg;
-
-    // particles
-    int64_t cap = 0, N = 0;
-    bool have_particles = false;
-    double *d_x[2]{}, *d_y[2]{}, *d_th[2]{};
-    int cur = 0;
-    double *d_w = nullptr, *d_logw = nullptr, *d_tmp = nullptr;   // tmp: cap*3 doubles
-    double *d_carry[2]{};               // logw - max of the last update (adaptive resampling: what a kept particle carries)
-    int carry_idx = 0;                  // d_carry[carry_idx] is current; k_weights writes the other one
-    bool carry_valid = false, carry_pending = false;
-    bool resampled_last = true;
-    // hipGraph of the update's tail (observation upload ... result read-back) for the k_rays_skip path, one per particle buffer
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-    bool graph_warm = false;            // a regular update has run since the sizes / map / beams last changed
-    bool capturing = false;
-    double *d_logw_acc = nullptr;       // k_rays_quad/far/fix accumulate here with atomics; k_gather_logw copies to d_logw
-    uint64_t *d_q = nullptr, *d_cdf = nullptr, *d_blocktot = nullptr;
-    uint32_t *d_bm = nullptr;           // mcl_stage_distinct_parents: bitmap over the global particle indices, its popcounts and their prefix
-    uint64_t *d_bm_pop = nullptr, *d_bm_pref = nullptr;
-    size_t bm_capacity = 0;
-    // compact list of the particles with a non-zero fixed-point weight, written by the scan of d_q (mcl::CompactOut)
-    uint32_t *d_blockcnt = nullptr;     // per scan tile (blocktot_capacity entries)
-    uint64_t *d_ccdf = nullptr, *d_ctop = nullptr;
-    uint32_t *d_cidx = nullptr;
-    double4 *d_crec = nullptr;
-    int64_t compact_cap = 0;            // room in the list (cap / 4, at least 4096)
-    int64_t compact_n = -1;             // entries of the list that describes d_cdf / the current particles; -1: none
-    bool compact_pending = false;       // the last scan wrote a list; its length arrives with the next result read-back
-    bool compact_used = false;          // the last resampling drew from a compact list
-    uint64_t *d_gcdf = nullptr, *d_gtop = nullptr;   // merged CDF of the shards' gathered lists (mcl_stage_resample_compact)
-    size_t gcdf_capacity = 0;
-    int env_no_compact = 0;
-    uint64_t *d_leaders = nullptr;      // last CDF entry of every 16-entry group of the array d_blocktot describes
-    size_t leaders_capacity = 0;
-    double4 *d_pack[2]{};               // (x, y, theta, -) records of buffer 0/1, written by k_resample_motion
-    bool pack_valid[2] = {false, false};
-    int32_t *d_idx = nullptr;
-    uint8_t *d_steps = nullptr;
-    size_t steps_capacity = 0, blocktot_capacity = 0;
-    const uint64_t *blocktot_for = nullptr;   // which CDF array d_blocktot currently describes
-    int64_t blocktot_n = 0;
-    double *d_part = nullptr;           // kRedBlocks * 8: per-workgroup partial sums (k_weights)
-    double *d_maxpart = nullptr;        // kRedBlocks: per-workgroup maxima of d_logw (k_combine_logw / k_reduce_max)
-    bool sums_pending = false;          // k_weights left partial sums that the next scan's spine turns into scalars[1..7]
-    double *d_scalars = nullptr;        // 8
-    unsigned long long *d_counters = nullptr;  // 4
-    double *d_inject = nullptr;         // cap*4 (normals + uniforms)
-    double4 *d_pc = nullptr;            // cap: per-particle constants for k_rays_skip / k_rays_quad
-    short4 *d_qr = nullptr;             // cap: per-particle quadrant ranges (k_rays_quad)
-    bool quad_ok = false;               // beam angles monotone over less than a full turn
-    int qside = 0;                      // k_rays_quad window side (0: not usable for this map)
-    unsigned long long *d_fix_list = nullptr, *d_fix_count = nullptr, *d_fix_over = nullptr;
-    unsigned long long *d_exact_list = nullptr;   // level-3 rays for k_rays_exact; its counter is word 14 of d_result
-    unsigned long long fix_cap = 0, fix_alloc = 0;
-    size_t fix_count_alloc = 0;
-    int fix_segments = 0;
-    uint8_t *d_far = nullptr;           // cap * 4 flags
-    uint32_t *d_far_list = nullptr;     // k_rays_sweep: slots with a flagged quadrant (cap entries, allocated on first use)
-    uint32_t *d_far_sorted = nullptr, *d_far_cnt = nullptr;   // the same in ascending order (k_far_*), per-2048-slot counts
-    // cell sort for k_rays_cell
-    double4 *d_pcs = nullptr;           // cap: pc in sorted order
-    double *d_ths = nullptr;            // cap: heading in sorted order
-    uint8_t *d_distw = nullptr;         // kWedges wedge fields for k_rays_cell, each Hp x Wps bytes
-    uint32_t *d_perm = nullptr, *d_skey = nullptr, *d_srank = nullptr;   // cap each
-    uint32_t *d_skey2 = nullptr, *d_sval2 = nullptr;   // MCL_SORT=radix: sorted keys / indices
-    void *d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    int env_sort_radix = -1;           // MCL_SORT=radix / hist forces one ordering path; default: by size
-    uint32_t *d_tile_used = nullptr;    // one mark per kHistTile buckets of the sort histogram: touched by this update's sort
-    uint32_t *d_hist = nullptr, *d_histpart = nullptr;                   // kSortBuckets, kSortBuckets / kHistTile
-    int *d_bbox = nullptr;              // 7: bounding box, occupied tiles, numbering in use, window play
-    uint32_t *d_cut_start = nullptr, *d_cut_end = nullptr;   // kSwMaxCuts each: where the buckets of a sparse set start / end in the radix-sorted order (zero between sorts)
-    bool env_no_bucket_cuts = false;    // MCL_NO_BUCKET_CUTS: units on the plain grid of 1024 slots, sparse sets ordered by whole tiles (rounds 2-3 before the cuts)
-    int *d_tilemap = nullptr, *d_tilemark = nullptr;   // kSortMaxTiles each: tile of the map -> compact id; marks of the occupied tiles (zero between sorts)
-    // The ordering layout (bounding box, occupied tiles) of an update's children is made on the second stream right after the
-    // resampling kernel and used by the NEXT update, whose resampling kernel then writes the sort keys itself: d_bbox / d_tilemap are
-    // the layout in use, *_nx the one being made; swapped at the end of an update.  layout_valid: d_bbox describes the previous
-    // update's children of this configuration (cleared by graph_reset: map, beams, particles set from outside).
-    int *d_bbox_nx = nullptr, *d_tilemap_nx = nullptr, *d_tilemark_nx = nullptr;
-    hipEvent_t ev_children = nullptr, ev_layout = nullptr;
-    hipEvent_t ev_ext_in = nullptr, ev_ext_out = nullptr;   // ordering against a caller's stream (mcl_stream_wait_external / mcl_external_wait_stream)
-    bool stage_async_rays = false, stage_async_weights = false;
-    bool stage_kept = false;            // the staged flow's last children are the previous particles themselves (mcl_stage_keep)
-    struct mcl_comm *comm = nullptr;    // RCCL communicator of a sharded set (mcl_comm_create), or null
-    unsigned long long list_epoch = 0;  // counts the rewrites of the compact list (a gathered copy of an older one is stale)
-    bool layout_valid = false, layout_pending = false;
-    int64_t layout_n = 0;
-    // Stage events BOUND TO DISPATCHES: the stop event of hipExtLaunchKernelGGL costs nothing, a hipEventRecord between two kernels
-    // of a stream ~3 us of pipeline (tools/ubench/event_cost.hip; elapsed times across different launches are valid).  Set by the
-    // launch that bound the event, cleared by the code that would otherwise record it.
-    bool ev_resample_bound = false, ev_rays_bound = false, ev_sensor_bound = false, ev_query_skipped = false;
-    bool bind_sensor_event = false;     // the next scan of the engine's own weights binds EV_SENSOR to its last kernel
-    bool layout_wanted = false;         // the resampling kernel left children to make the next layout of (layout_mark -> next_layout_launch)
-    bool layout_stale_used = false;     // this update orders by the previous update's layout (do_update -> launch_rays)
-    bool keys_done = false;             // ... and its resampling kernel wrote the (key, index) pairs
-    bool env_no_stale_layout = false;   // MCL_NO_STALE_LAYOUT: every update makes its own layout first (rounds 1-3)
-    bool env_comm_no_lists = false;     // MCL_COMM_NO_LISTS: mcl_comm_update takes the dense exchange on every update
-    bool env_comm_no_pregather = false; // MCL_COMM_NO_PREGATHER: mcl_comm_update gathers the lists when it starts, not when the previous one ends
-    mcl::PrepClear prep_passed{};       // what the resampling kernel was given to clear (prep_folded)
-    double2 *d_slice_mean = nullptr;    // one per slice of the sorted order
-    size_t slice_mean_capacity = 0;
-    bool last_quad = false;             // the last ray stage ran k_rays_quad (overflow check pending)
-    int last_mode = 0;                  // 1 march, 2 skip, 3 quad, 4 cell, 5 sweep
-    unsigned long long result_seq = 0;  // stamps the result block a small update writes to pinned memory (h_result[kResultStamp])
-    int env_tiny_poll = 1;
-    bool far_fresh = true;              // no ray stage has seen the current particle set yet (set / initialised since the last one)
-    bool pc_ready = false;              // d_pc already holds the constants of the current particles (written by k_resample_motion)
-    int reserved_cus = 0;               // CUs k_rays_quad's persistent grid leaves free (for RCCL kernels running beside it)
-    unsigned long long *d_result = nullptr;   // [0..7] scalars, [8..11] counters, [12..13] overflow flag + work counter: one D2H copy
-    unsigned long long *h_result = nullptr;   // pinned mirror of d_result
-    double h_scalars[8]{};
-    uint64_t q_total = 0;
-    double global_sums[5]{};            // sum w, wx, wy, wsin, wcos actually used for outputs
-    bool have_idx = false, have_steps = false, have_logw = false;
-    uint32_t update_idx = 0;
-    double timings[6]{};
-    double ray_ms = 0;
-    bool ray_ms_is_graph_tail = false;  // ray_ms is the whole captured tail of a small update, not one kernel
-    unsigned long long h_counters[4]{};
-    unsigned long long h_fix_count = 0;
-};
 
 namespace {
 
-#define HIPCHK(h, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
-            return MCL_ERR_HIP;                                                                  \
-        }                                                                                        \
-    } while (0)
 
 int fail(mcl_engine *h, int code, const char *msg)
 {
@@ -629,9 +407,15 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
     const char *no_windows = nullptr;                        // why the windowed kernels (quad / cell / sweep) are out, if they are
     if (!h->quad_ok) no_windows = "beam angles are not monotone over less than a turn (or more than 16383 beams): the windowed kernels need contiguous beam ranges per direction wedge";
     else if (h->qside <= 0) no_windows = "MAX_RANGE_PX leaves less than 32 cells of play in a 280-cell byte window: the windowed kernels cannot hold a ray";
-    const bool windows_ok = no_windows == nullptr;           // monotone beams over less than a turn, room for a byte window
+    [[maybe_unused]] const bool windows_ok = no_windows == nullptr;           // monotone beams over less than a turn, room for a byte window
+#ifdef MCL_LEGACY_RAY_KERNELS
     if (rk == MCL_RAYS_QUAD) { w = windows_ok && h->quad_layout_ok ? "configured: MCL_RAYS_QUAD" : (no_windows ? no_windows : "k_rays_quad's LDS layout check failed"); return windows_ok && h->quad_layout_ok ? 3 : 0; }
     if (rk == MCL_RAYS_CELL) { w = windows_ok && h->cell_layout_ok ? "configured: MCL_RAYS_CELL" : (no_windows ? no_windows : "k_rays_cell's LDS layout check failed"); return windows_ok && h->cell_layout_ok ? 4 : 0; }
+#else
+    // k_rays_quad / k_rays_cell, the predecessors of k_rays_sweep, are not part of this library (csrc/mcl_rays_legacy.h, a build
+    // flag; the tests load libmcl_hip_engine_legacy.so for them)
+    if (rk == MCL_RAYS_QUAD || rk == MCL_RAYS_CELL) { w = "MCL_RAYS_QUAD / MCL_RAYS_CELL are not built into this library (build flag MCL_LEGACY_RAY_KERNELS)"; return 0; }
+#endif
     // its windows are 256 cells wide (mcl_rays_sweep.h) and addressed from a raw LDS offset checked at mcl_create
     // ... or, for ranges beyond that, probes the same wedge fields in global memory
     const char *no_sweep = h->quad_ok ? nullptr : no_windows;
@@ -653,7 +437,9 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
                             : "AUTO: at least 65536 particles and 2^23 rays, monotone beams, MAX_RANGE_PX <= 243";
         return 5;
     }
+#ifdef MCL_LEGACY_RAY_KERNELS
     if (big && windows_ok && h->cell_layout_ok) { w = no_sweep; return 4; }
+#endif
     if (!h->skip_layout_ok) { w = "k_rays_skip's LDS layout check failed at mcl_create: literal march"; return 1; }
     w = !big ? "AUTO: fewer than 65536 particles or 2^23 rays: the self-contained k_rays_skip is the quickest" : no_sweep;
     return 2;
@@ -943,8 +729,10 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             else if (sweep && sweep_rec && sweep_pairs) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+#ifdef MCL_LEGACY_RAY_KERNELS
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<true>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<true>), qg, b, qlds, h->stream, a);
+#endif
             if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             if (sweep && a.far_windowed) { const int rcw = launch_far_windowed(h, a, n, true); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<true>), gfar, b, 0, h->stream, a);
@@ -956,8 +744,10 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             else if (sweep && sweep_rec && sweep_pairs) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+#ifdef MCL_LEGACY_RAY_KERNELS
             else if (cell) hipLaunchKernelGGL((mcl::k_rays_cell<false>), qg, b, qlds, h->stream, a);
             else hipLaunchKernelGGL((mcl::k_rays_quad<false>), qg, b, qlds, h->stream, a);
+#endif
             if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K1], h->stream));
             if (sweep && a.far_windowed) { const int rcw = launch_far_windowed(h, a, n, false); if (rcw) return rcw; }
             hipLaunchKernelGGL((mcl::k_rays_far<false>), gfar, b, 0, h->stream, a);
@@ -1250,10 +1040,12 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_skip<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef MCL_LEGACY_RAY_KERNELS
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+#endif
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_tiny_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_sweep_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -1285,8 +1077,10 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
                                      static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, true, true, true>), 0, qb) &&
                                      static_lds_fits(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, true, true, true>), 0, qb);
         }
+#ifdef MCL_LEGACY_RAY_KERNELS
         h->cell_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), qb);
         h->quad_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<false>), qb) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_quad<true>), qb);
+#endif
         h->skip_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true>), 0) &&
                             static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, false, true>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<1, true, true>), 0) &&
                             static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<2, false>), 0) && static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_skip<3, false>), 0) &&
@@ -2424,21 +2218,6 @@ int mcl_get_host_scalars(const mcl_engine_t *h, double out[8])
     return MCL_OK;
 }
 
-// Where the parents of a staged resample come from.
-struct ParentSource {
-    const double *px = nullptr, *py = nullptr, *pth = nullptr;     // gathered columns, n_parents entries each
-    const void *records = nullptr;                                  // gathered (or compacted) packed records
-    const double4 *rank_records[mcl::kMaxShards] = {};              // one record array per shard (peer pointers, same process)
-    int64_t n_per_rank = 0;
-    int self_rank = 0;
-    unsigned long long *remote_count = nullptr;
-    const unsigned char *cchunks = nullptr;                         // the shards' compact lists, gathered as chunks
-    int64_t cchunk_entries = 0;
-    const uint64_t *gcdf = nullptr, *gtop = nullptr;                // their merged CDF (k_compact_merge)
-    const int32_t *idx_in = nullptr;                                // parents decided by an earlier index-only pass (into `records`)
-    int32_t *idx_only_out = nullptr;                                // index-only pass: parents go here, nothing else happens
-    bool keep = false;                                              // adaptive resampling kept the set: every particle is its own parent (motion only)
-};
 
 // Launches the staged resample (+ motion) on the engine's stream; no synchronisation.  An index-only pass leaves the
 // engine untouched; otherwise the children land in the other particle buffer, which becomes current.
@@ -2887,589 +2666,6 @@ int mcl_stage_complete(mcl_engine_t *h, const double global_sums[5], int32_t *re
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// One process per GPU, the exchange in native code: the engine holds an RCCL communicator and one call runs a whole sharded
-// update -- the three collectives of an update (all-gather of the compact parent lists, all-reduce MAX of one double,
-// all-reduce SUM of 5 + 3 G + 1 doubles) are enqueued on the ENGINE'S OWN STREAM between its kernels: no second stream, no
-// event hop, no interpreter between the stages; the host waits once, for the summed vector.  RCCL is taken from the process
-// at run time (dlopen: the library a torch process already carries, else the ROCm one): the engine does not link it, and a
-// host without RCCL keeps every other entry point.  The rendezvous (128-byte id from rank 0 to every rank) is the host's.
-// ---------------------------------------------------------------------------------------------
-// The few RCCL types and enumerators the entry points below need, declared here: the library is taken with dlopen at run time
-// and must build on a ROCm tree without the RCCL development headers (values as in rccl/rccl.h: they are RCCL's / NCCL's ABI).
-extern "C" {
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclChar = 0, ncclUint64 = 5, ncclDouble = 8 } ncclDataType_t;
-typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
-}
-
-struct RcclApi {
-    void *lib = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    std::string why;
-};
-
-static RcclApi &rccl_api()
-{
-    static RcclApi api;
-    if (api.lib || !api.why.empty()) return api;
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *nm : names) {
-        api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already has (a torch process: torch's)
-        if (api.lib) break;
-    }
-    for (const char *nm : names) {
-        if (api.lib) break;
-        api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    }
-    if (!api.lib) { api.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return api; }
-    auto sym = [&](const char *n) { void *p = dlsym(api.lib, n); if (!p && api.why.empty()) api.why = std::string("RCCL symbol missing: ") + n; return p; };
-    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
-    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
-    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
-    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!api.why.empty()) api.lib = nullptr;
-    return api;
-}
-
-struct mcl_comm {
-    ncclComm_t comm = nullptr;
-    int n_ranks = 0, rank = 0;
-    unsigned char *d_chunk_local = nullptr, *d_chunk_all = nullptr;     // the lists: this shard's chunk, every shard's
-    size_t chunk_capacity = 0;                                           // entries per chunk the buffers hold
-    double *d_red = nullptr;                                             // [0] MAX exchange | [1 .. k] SUM exchange | [1 + k] error word (ranks that failed)
-    double *h_red = nullptr;                                             // pinned copy of it
-    uint64_t bytes_received = 0, bytes_payload = 0;                      // of the last update's list exchange
-    int host_waits = 0;
-    // dense exchange (an update without lists: the first after the particles were set): every shard's fixed-point weights,
-    // their global CDF and every shard's packed records; allocated when first needed
-    uint64_t *d_qall = nullptr, *d_cdfall = nullptr;
-    double4 *d_recall = nullptr;
-    size_t dense_capacity = 0;                                           // particles (all shards) the three arrays hold
-    bool last_dense = false, last_kept = false;
-    bool vec_valid = false;                                              // vec holds the sums of an update of the current particle set
-    uint64_t dense_weights_bytes = 0, dense_records_bytes = 0;
-    // what the shards' lists look like (the previous update's summed vector, or mcl_comm_set_lists after a dense update)
-    bool lists_known = false;
-    int64_t counts[mcl::kMaxShards] = {};
-    uint64_t totals[mcl::kMaxShards] = {};
-    double vec[5 + 3 * mcl::kMaxShards + 2] = {};                        // the last summed vector
-    // failure protocol (mcl_comm_update): how long a host wait may last before the communicator is aborted; the update count;
-    // MCL_COMM_FAIL = "<rank>:<update>:<stage>" (test switch: that rank reports a failure / stalls before that stage of that update)
-    double timeout_ms = 30000.0;
-    bool dead = false;                                                   // aborted (a wait ran out, or a collective call failed): create again
-    unsigned long long updates = 0;
-    int fail_rank = -1; long long fail_update = -1; std::string fail_stage;
-    // the lists of the NEXT update, gathered right after this update's sums (beside whatever the host does between updates)
-    bool gathered = false;
-    unsigned long long gathered_epoch = 0;
-    unsigned long long gathered_epoch_all = 0;                           // the update (count) after which EVERY rank pre-gathered the lists
-    int64_t gathered_entries = 0;
-    int64_t gathered_counts[mcl::kMaxShards] = {};
-};
-
-static void comm_forget(mcl_comm *c)
-{
-    if (!c) return;
-    c->lists_known = false;
-    c->gathered = false;
-    c->gathered_entries = 0;
-    c->vec_valid = false;
-}
-
-static void comm_free(mcl_comm *c)
-{
-    if (!c) return;
-    if (c->comm && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(c->comm);        // (an aborted communicator is gone already: comm == nullptr)
-    if (c->d_chunk_local) (void)hipFree(c->d_chunk_local);
-    if (c->d_chunk_all) (void)hipFree(c->d_chunk_all);
-    if (c->d_red) (void)hipFree(c->d_red);
-    if (c->h_red) (void)hipHostFree(c->h_red);
-    if (c->d_qall) (void)hipFree(c->d_qall);
-    if (c->d_cdfall) (void)hipFree(c->d_cdfall);
-    if (c->d_recall) (void)hipFree(c->d_recall);
-    delete c;
-}
-
-// ---- failure protocol of a sharded update --------------------------------------------------------------------------------------
-// A rank that fails must not hang its peers (the reference's error model is log-and-skip-a-tick, cpp:236-240, 680, 756; a node
-// blocked inside a collective for ever is not that).  Two layers:
-//   * SOFT failure -- anything a rank finds wrong locally while its communicator still works (an engine stage that fails, list
-//     state that does not match the exchange, MCL_COMM_FAIL): the rank stops its local work but STILL ISSUES EVERY COLLECTIVE of
-//     the update, with the sizes every rank derives from the shared numbers, and raises the ERROR WORD that rides behind the
-//     summed vector (one more double of the SUM all-reduce: the number of ranks that failed).  Every rank then returns from the
-//     same update: the failing ones with their own status and message, the others with MCL_ERR_PEER.  The communicator stays
-//     usable; the particle set must be set or initialised again on every rank (as after MCL_ERR_HIP from mcl_update), and the
-//     next update is a dense one.
-//   * HARD failure -- a collective call that fails, or a host wait that lasts longer than MCL_COMM_TIMEOUT_MS (default 30 000;
-//     a peer that died or never arrived): the communicator is ABORTED (ncclCommAbort: the collective kernels in flight end), the
-//     call returns MCL_ERR_TIMEOUT / MCL_ERR_HIP, and mcl_comm_create must run again (on every rank: their waits run out too).
-// Nothing here re-executes a process; recovery that needs a new process is the host's (a fresh child, never an exec of a
-// process that has touched the GPU).
-static void comm_abort(mcl_engine_t *h, const char *why)
-{
-    mcl_comm *c = h->comm;
-    if (!c) return;
-    RcclApi &api = rccl_api();
-    if (c->comm) {
-        if (api.CommAbort) (void)api.CommAbort(c->comm);
-        // (without ncclCommAbort in the library the communicator is leaked rather than destroyed: ncclCommDestroy waits for peers)
-        c->comm = nullptr;
-    }
-    c->dead = true;
-    comm_forget(c);
-    (void)hipStreamSynchronize(h->stream);          // the aborted kernels and whatever else was enqueued drain
-    (void)why;
-}
-
-#define NCCLCHK(h, call)                                                                                          \
-    do {                                                                                                          \
-        ncclResult_t r_ = (call);                                                                                 \
-        if (r_ != ncclSuccess) {                                                                                  \
-            const std::string m_ = std::string(#call) + ": " + rccl_api().GetErrorString(r_) + " (communicator aborted: mcl_comm_create again)"; \
-            comm_abort(h, "collective call failed");                                                              \
-            return fail(h, MCL_ERR_HIP, m_);                                                                      \
-        }                                                                                                         \
-    } while (0)
-
-// the host wait of a sharded update, bounded: MCL_OK when the engine's stream has drained, else the communicator is aborted
-static int comm_wait(mcl_engine_t *h)
-{
-    mcl_comm *c = h->comm;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(h->stream);
-        if (e == hipSuccess) { c->host_waits += 1; return MCL_OK; }
-        if (e != hipErrorNotReady) {
-            const std::string m = std::string("hipStreamQuery: ") + hipGetErrorString(e);
-            comm_abort(h, "stream error");
-            return fail(h, MCL_ERR_HIP, m);
-        }
-        if ((spins & 63u) == 63u) {
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > c->timeout_ms) break;
-        }
-    }
-    comm_abort(h, "timeout");
-    return fail(h, MCL_ERR_TIMEOUT, "a collective of the sharded update did not finish within MCL_COMM_TIMEOUT_MS (a peer failed or never arrived): "
-                                    "communicator aborted, mcl_comm_create again");
-}
-
-int mcl_comm_available(const char **why)
-{
-    RcclApi &api = rccl_api();
-    if (why) *why = api.lib ? "" : api.why.c_str();
-    return api.lib ? MCL_OK : MCL_ERR_UNSUPPORTED;
-}
-
-int mcl_comm_unique_id(unsigned char id[128])
-{
-    RcclApi &api = rccl_api();
-    if (!id) return MCL_ERR_INVALID_ARG;
-    if (!api.lib) return MCL_ERR_UNSUPPORTED;
-    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
-    ncclUniqueId u;
-    if (api.GetUniqueId(&u) != ncclSuccess) return MCL_ERR_HIP;
-    std::memcpy(id, &u, 128);
-    return MCL_OK;
-}
-
-int mcl_comm_create(mcl_engine_t *h, const unsigned char id[128], int32_t n_ranks, int32_t rank)
-{
-    if (!h || !id || n_ranks <= 0 || n_ranks > mcl::kMaxShards || rank < 0 || rank >= n_ranks) return MCL_ERR_INVALID_ARG;
-    RcclApi &api = rccl_api();
-    if (!api.lib) return fail(h, MCL_ERR_UNSUPPORTED, api.why);
-    if (h->cfg.weight_mode != MCL_WEIGHT_LOG)
-        return fail(h, MCL_ERR_UNSUPPORTED, "a sharded set needs weight_mode LOG");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (h->comm) { comm_free(h->comm); h->comm = nullptr; }
-    mcl_comm *c = new mcl_comm();
-    c->n_ranks = n_ranks; c->rank = rank;
-    if (const char *e = getenv("MCL_COMM_TIMEOUT_MS")) { const double v = atof(e); if (v > 0.0) c->timeout_ms = v; }
-    if (const char *e = getenv("MCL_COMM_FAIL")) {                    // "<rank>:<update>:<stage>", stage = resample | rays | weights | stall
-        int fr = -1; long long fu = -1; char st[32] = {0};
-        if (std::sscanf(e, "%d:%lld:%31s", &fr, &fu, st) == 3) { c->fail_rank = fr; c->fail_update = fu; c->fail_stage = st; }
-    }
-    ncclUniqueId u;
-    std::memcpy(&u, id, 128);
-    const ncclResult_t r = api.CommInitRank(&c->comm, n_ranks, u, rank);          // collective: every rank is in this call
-    if (r != ncclSuccess) { c->comm = nullptr; comm_free(c); return fail(h, MCL_ERR_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)); }
-    const size_t words = 1 + 5 + 3 * (size_t)n_ranks + 2 + 1;                     // MAX | summed vector | error word
-    if (hipMalloc(&c->d_red, words * 8) != hipSuccess || hipHostMalloc(&c->h_red, words * 8) != hipSuccess) {
-        comm_free(c);
-        return fail(h, MCL_ERR_HIP, "mcl_comm_create: allocation failed");
-    }
-    h->comm = c;
-    return MCL_OK;
-}
-
-// The three collectives of an update on known data, before any particle depends on them: all-reduce MAX of the rank, all-reduce
-// SUM of ones, all-gather of one 64-byte chunk per rank.  COLLECTIVE.  A host that finds a rank failing here keeps its other
-// exchange (dist.py: torch's collectives) instead of learning it in the first update.
-int mcl_comm_selftest(mcl_engine_t *h)
-{
-    if (!h) return MCL_ERR_INVALID_ARG;
-    mcl_comm *c = h->comm;
-    if (!c) return fail(h, MCL_ERR_NOT_READY, "mcl_comm_create first");
-    if (c->dead) return fail(h, MCL_ERR_NOT_READY, "the communicator was aborted: mcl_comm_create again");
-    RcclApi &api = rccl_api();
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    const int G = c->n_ranks;
-    unsigned char *d_buf = nullptr;
-    HIPCHK(h, hipMalloc(&d_buf, 64 * (size_t)(G + 1)));
-    unsigned char mine[64];
-    for (int i = 0; i < 64; ++i) mine[i] = (unsigned char)(c->rank * 7 + i);
-    double two[2] = {(double)c->rank, 1.0};
-    auto run = [&]() -> int {
-        HIPCHK(h, hipMemcpyAsync(d_buf, mine, 64, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(c->d_red, two, 16, hipMemcpyHostToDevice, h->stream));
-        NCCLCHK(h, api.AllReduce(c->d_red, c->d_red, 1, ncclDouble, ncclMax, c->comm, h->stream));
-        NCCLCHK(h, api.AllReduce(c->d_red + 1, c->d_red + 1, 1, ncclDouble, ncclSum, c->comm, h->stream));
-        NCCLCHK(h, api.AllGather(d_buf, d_buf + 64, 64, ncclChar, c->comm, h->stream));
-        std::vector<unsigned char> all(64 * (size_t)G);
-        HIPCHK(h, hipMemcpyAsync(c->h_red, c->d_red, 16, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(all.data(), d_buf + 64, all.size(), hipMemcpyDeviceToHost, h->stream));
-        const int rw = comm_wait(h);
-        if (rw) return rw;
-        if (c->h_red[0] != (double)(G - 1) || c->h_red[1] != (double)G) return fail(h, MCL_ERR_HIP, "mcl_comm_selftest: an all-reduce returned a wrong value");
-        for (int r = 0; r < G; ++r)
-            for (int i = 0; i < 64; ++i)
-                if (all[(size_t)r * 64 + i] != (unsigned char)(r * 7 + i)) return fail(h, MCL_ERR_HIP, "mcl_comm_selftest: the all-gather returned wrong bytes");
-        return MCL_OK;
-    };
-    const int rc = run();
-    (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(d_buf);
-    return rc;
-}
-
-int mcl_comm_destroy(mcl_engine_t *h)
-{
-    if (!h) return MCL_ERR_INVALID_ARG;
-    if (h->comm) {
-        (void)hipSetDevice(h->cfg.device);
-        (void)hipStreamSynchronize(h->stream);
-        comm_free(h->comm);
-        h->comm = nullptr;
-    }
-    return MCL_OK;
-}
-
-// What a rank found wrong locally during one sharded update (the first thing): its local work stops, its collectives go on.
-struct CommLocal {
-    int code = MCL_OK;
-    std::string msg;
-    bool bad() const { return code != MCL_OK; }
-    void note(mcl_engine_t *h, int rc) { if (rc != MCL_OK && code == MCL_OK) { code = rc; msg = h->err; } }
-};
-
-// MCL_COMM_FAIL: does this rank fail (or stall) before `stage` of this update?
-static bool comm_injected(const mcl_comm *c, const char *stage)
-{
-    return c->fail_rank == c->rank && c->fail_update == (long long)c->updates && c->fail_stage == stage;
-}
-
-// rays -> local max -> all-reduce MAX -> weights, scan, list -> this shard's part of the sums -> all-reduce SUM (with the error
-// word) -> pinned host.  Returns a HARD failure, or MCL_OK with *failed_ranks = the summed error word (0: the sums are good).
-static int comm_rays_to_sums(mcl_engine_t *h, const float *obs, int32_t n_beams, bool sync_rays, CommLocal &loc, double *failed_ranks)
-{
-    mcl_comm *c = h->comm;
-    RcclApi &api = rccl_api();
-    const size_t k = 5 + 3 * (size_t)c->n_ranks + 2;
-    if (!loc.bad() && comm_injected(c, "rays")) loc.note(h, fail(h, MCL_ERR_HIP, "injected failure before the ray stage (MCL_COMM_FAIL)"));
-    if (!loc.bad()) loc.note(h, stage_rays_launch(h, obs, n_beams, false, sync_rays ? nullptr : c->d_red));
-    if (!loc.bad() && sync_rays) {        // after an overflow: wait, let the synchronous stage fall back to the self-contained kernel
-        loc.note(h, stage_rays_finish(h, obs, n_beams));
-        c->host_waits += 1;
-        if (!loc.bad()) hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, h->stream, h->d_scalars, c->d_red);
-    }
-    if (loc.bad()) hipLaunchKernelGGL(mcl::k_set_double, dim3(1), dim3(1), 0, h->stream, c->d_red, -INFINITY);      // (any finite-or-not value will do: the update is void)
-    NCCLCHK(h, api.AllReduce(c->d_red, c->d_red, 1, ncclDouble, ncclMax, c->comm, h->stream));
-    if (!loc.bad() && comm_injected(c, "weights")) loc.note(h, fail(h, MCL_ERR_HIP, "injected failure before the weights stage (MCL_COMM_FAIL)"));
-    if (!loc.bad()) loc.note(h, stage_weights_launch(h, 0.0, c->d_red));
-    if (!loc.bad()) {
-        hipLaunchKernelGGL(mcl::k_stage_pack, dim3(1), dim3(64), 0, h->stream, h->d_result, c->d_red + 1, c->n_ranks, c->rank, h->compact_pending ? 1 : 0,
-                           (unsigned long long)h->compact_cap);
-        if (hipGetLastError() != hipSuccess) loc.note(h, fail(h, MCL_ERR_HIP, "k_stage_pack launch failed"));
-    }
-    if (loc.bad() && hipMemsetAsync(c->d_red + 1, 0, k * 8, h->stream) != hipSuccess) { comm_abort(h, "memset"); return fail(h, MCL_ERR_HIP, "hipMemsetAsync failed (communicator aborted)"); }
-    if (comm_injected(c, "stall"))        // test switch: this rank's stream is busy for ~3 x the bound before the last collective (a peer that does not arrive)
-        hipLaunchKernelGGL(mcl::k_spin_ms, dim3(1), dim3(64), 0, h->stream, std::min(3.0 * c->timeout_ms, 2000.0));
-    hipLaunchKernelGGL(mcl::k_set_double, dim3(1), dim3(1), 0, h->stream, c->d_red + 1 + k, loc.bad() ? 1.0 : 0.0);
-    NCCLCHK(h, api.AllReduce(c->d_red + 1, c->d_red + 1, k + 1, ncclDouble, ncclSum, c->comm, h->stream));
-    if (hipMemcpyAsync(c->h_red, c->d_red, (1 + k + 1) * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { comm_abort(h, "memcpy"); return fail(h, MCL_ERR_HIP, "hipMemcpyAsync failed (communicator aborted)"); }
-    const int rw = comm_wait(h);                                      // THE host wait of the update
-    if (rw) return rw;
-    *failed_ranks = c->h_red[1 + k];
-    if (*failed_ranks != 0.0 || loc.bad()) return MCL_OK;
-    unpack_result(h);
-    stage_rays_note(h);
-    h->timings[4] = elapsed(h->ev[EV_RAYS], h->ev[EV_SENSOR]);
-    loc.note(h, layout_adopt(h, h->N));                               // (after the last collective: a failure here is this rank's alone)
-    return MCL_OK;
-}
-
-// export of this shard's list + all-gather of the chunks, on the engine's stream
-static int comm_gather_lists(mcl_engine_t *h, const int64_t *counts, CommLocal &loc)
-{
-    mcl_comm *c = h->comm;
-    RcclApi &api = rccl_api();
-    const int G = c->n_ranks;
-    int64_t longest = 0, listed = 0;
-    for (int r = 0; r < G; ++r) { longest = std::max(longest, counts[r]); listed += counts[r]; }
-    const int64_t entries = std::max<int64_t>(64, (longest + 63) & ~(int64_t)63);
-    c->gathered = false;
-    if ((size_t)entries > c->chunk_capacity) {
-        // (without buffers of the agreed size this rank cannot take part in the all-gather: a hard failure)
-        bool ok = hipStreamSynchronize(h->stream) == hipSuccess;
-        if (c->d_chunk_local) (void)hipFree(c->d_chunk_local);
-        if (c->d_chunk_all) (void)hipFree(c->d_chunk_all);
-        c->d_chunk_local = c->d_chunk_all = nullptr; c->chunk_capacity = 0;
-        const size_t cap = (size_t)entries + (size_t)entries / 4;            // lists breathe from update to update
-        ok = ok && hipMalloc(&c->d_chunk_local, cap * 44) == hipSuccess && hipMalloc(&c->d_chunk_all, cap * 44 * (size_t)G) == hipSuccess;
-        if (!ok) { comm_abort(h, "alloc"); return fail(h, MCL_ERR_HIP, "mcl_comm_update: no memory for the list exchange (communicator aborted)"); }
-        c->chunk_capacity = cap;
-    }
-    if (!loc.bad()) loc.note(h, export_compact_launch(h, c->d_chunk_local, entries, h->cfg.device, h->stream));
-    NCCLCHK(h, api.AllGather(c->d_chunk_local, c->d_chunk_all, (size_t)entries * 44, ncclChar, c->comm, h->stream));
-    c->bytes_received = (uint64_t)entries * 44u * (uint64_t)(G - 1);
-    c->bytes_payload = (uint64_t)(listed - counts[c->rank]) * 44u;
-    c->gathered = !loc.bad(); c->gathered_epoch = h->list_epoch; c->gathered_entries = entries;
-    for (int r = 0; r < G; ++r) c->gathered_counts[r] = counts[r];
-    return MCL_OK;
-}
-
-// the shards' list lengths and weight totals out of a summed vector
-static void comm_note_lists(mcl_comm *c, const double *vec)
-{
-    const int G = c->n_ranks;
-    for (int r = 0; r < G; ++r) {
-        c->counts[r] = (int64_t)vec[5 + 3 * r] - 1;
-        c->totals[r] = ((uint64_t)vec[6 + 3 * r] + ((uint64_t)vec[7 + 3 * r] << 32));      // exact: halves < 2^32
-    }
-    c->lists_known = true;
-}
-
-int mcl_comm_set_lists(mcl_engine_t *h, const int64_t *counts, const uint64_t *totals)
-{
-    if (!h || !h->comm || !counts || !totals) return MCL_ERR_INVALID_ARG;
-    mcl_comm *c = h->comm;
-    for (int r = 0; r < c->n_ranks; ++r) { c->counts[r] = counts[r]; c->totals[r] = totals[r]; }
-    c->lists_known = true;
-    return MCL_OK;
-}
-
-// An update without lists (the first after the particles were set or initialised, or a shard whose list outgrew its arrays):
-// every shard's fixed-point weights and packed records are gathered whole (8 + 32 B per particle of the other shards), every
-// rank scans the same global CDF and draws its own children from it -- the same thresholds as every other path.
-// (A set without any weight is noted as this rank's failure -- on every rank, they read the same total -- and the update goes
-//  on through its collectives like any other void update.)
-static int comm_resample_dense(mcl_engine_t *h, const double action[3], CommLocal &loc)
-{
-    mcl_comm *c = h->comm;
-    RcclApi &api = rccl_api();
-    const int G = c->n_ranks;
-    const int64_t n = h->N, nt = n * G;
-    if ((size_t)nt > c->dense_capacity) {
-        bool ok = hipStreamSynchronize(h->stream) == hipSuccess;
-        if (c->d_qall) (void)hipFree(c->d_qall);
-        if (c->d_cdfall) (void)hipFree(c->d_cdfall);
-        if (c->d_recall) (void)hipFree(c->d_recall);
-        c->d_qall = c->d_cdfall = nullptr; c->d_recall = nullptr; c->dense_capacity = 0;
-        ok = ok && hipMalloc(&c->d_qall, (size_t)nt * 8) == hipSuccess && hipMalloc(&c->d_cdfall, (size_t)nt * 8) == hipSuccess &&
-             hipMalloc(&c->d_recall, (size_t)nt * sizeof(double4)) == hipSuccess;
-        if (!ok) { comm_abort(h, "alloc"); return fail(h, MCL_ERR_HIP, "mcl_comm_update: no memory for the dense exchange (communicator aborted)"); }
-        c->dense_capacity = (size_t)nt;
-    }
-    if (!loc.bad() && (size_t)nt / mcl::kScanTile + 2 > h->blocktot_capacity) {          // spine scratch of the scan, sized for one shard so far
-        graph_reset(h);
-        bool ok = hipStreamSynchronize(h->stream) == hipSuccess;
-        dfree(h->d_blocktot);
-        h->blocktot_capacity = 0;
-        ok = ok && hipMalloc(&h->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8) == hipSuccess;
-        if (ok) h->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;
-        else loc.note(h, fail(h, MCL_ERR_HIP, "mcl_comm_update: no memory for the scan of the whole set"));
-    }
-    const int cur = h->cur;
-    if (!loc.bad() && !h->pack_valid[cur]) {
-        hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_x[cur], h->d_y[cur], h->d_th[cur], n,
-                           h->d_pack[cur]);
-        h->pack_valid[cur] = true;
-    }
-    NCCLCHK(h, api.AllGather(h->d_q, c->d_qall, (size_t)n, ncclUint64, c->comm, h->stream));
-    NCCLCHK(h, api.AllGather(h->d_pack[cur], c->d_recall, (size_t)n * sizeof(double4), ncclChar, c->comm, h->stream));
-    if (!loc.bad()) loc.note(h, scan_weights(h, c->d_qall, c->d_cdfall, nt, 0, nullptr));
-    // the draw needs the global fixed-point total on the host (a launch argument): one more wait, in an update that has no lists
-    uint64_t q_total = 0;
-    if (!loc.bad() && hipMemcpyAsync(&c->h_red[0], c->d_cdfall + (nt - 1), 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
-        loc.note(h, fail(h, MCL_ERR_HIP, "hipMemcpyAsync of the weight total failed"));
-    const int rw = comm_wait(h);
-    if (rw) return rw;
-    if (loc.bad()) return MCL_OK;
-    std::memcpy(&q_total, &c->h_red[0], 8);
-    if (q_total == 0) { loc.note(h, fail(h, MCL_ERR_NOT_READY, "the particle set carries no weight")); return MCL_OK; }
-    ParentSource src;
-    src.records = c->d_recall;
-    c->last_dense = true;
-    c->dense_weights_bytes = (uint64_t)n * 8u * (uint64_t)(G - 1);
-    c->dense_records_bytes = (uint64_t)n * 32u * (uint64_t)(G - 1);
-    if (comm_injected(c, "resample")) { loc.note(h, fail(h, MCL_ERR_HIP, "injected failure before the resampling stage (MCL_COMM_FAIL)")); return MCL_OK; }
-    loc.note(h, stage_resample_launch(h, src, c->d_cdfall, nt, q_total, (int64_t)c->rank * n, nt, action));
-    return MCL_OK;
-}
-
-int mcl_comm_update(mcl_engine_t *h, const double action[3], const float *obs, int32_t n_beams, double pose_out[3])
-{
-    if (!h || !action || !obs || !pose_out) return MCL_ERR_INVALID_ARG;
-    mcl_comm *c = h->comm;
-    // (the checks up to here must come out the same on every rank -- a host that calls with different arguments on different
-    //  ranks has a bug no protocol repairs; what CAN differ between ranks goes through CommLocal below)
-    if (!c) return fail(h, MCL_ERR_NOT_READY, "mcl_comm_create first");
-    if (c->dead) return fail(h, MCL_ERR_NOT_READY, "the communicator was aborted: mcl_comm_create again");
-    if (n_beams != h->B) return fail(h, MCL_ERR_INVALID_ARG, "bad observation");
-    const int G = c->n_ranks;
-    const int64_t n_per_shard = h->N;
-    if (n_per_shard * G >= MCL_MAX_TOTAL_PARTICLES) return fail(h, MCL_ERR_INVALID_ARG, "particle total must stay below 2^27");
-    const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    c->host_waits = 0;
-    c->last_dense = false;
-    c->updates += 1;
-    CommLocal loc;
-    // "particles not set on this rank" is a local condition: it goes through the protocol like any other
-    if (!ready(h, true)) loc.note(h, fail(h, MCL_ERR_NOT_READY, "map, beam angles and particles must be set first"));
-    const int64_t *counts = c->counts;
-    const uint64_t *totals = c->totals;
-    // Lists or not is decided from what EVERY rank knows alike (the previous update's summed vector): all ranks take the same branch.
-    bool lists = c->lists_known && !h->env_comm_no_lists;
-    uint64_t weight = 0;
-    for (int r = 0; r < G && lists; ++r) {
-        lists = counts[r] >= 0;
-        weight += counts[r] > 0 ? totals[r] : 0ull;
-    }
-    lists = lists && weight != 0;
-    int rc;
-    // Adaptive resampling (E9): the set is kept when the effective sample size of the WHOLE set (the previous update's summed
-    // vector: every rank has the same numbers) is at least r / 1000 of it -- no exchange at all then
-    bool keep = false;
-    if (h->cfg.resample_neff_permille > 0 && c->vec_valid && h->carry_valid) {
-        const double sw = c->vec[0], sww = c->vec[5 + 3 * G + 1];
-        keep = sww > 0.0 && sw * sw >= ((double)h->cfg.resample_neff_permille / 1000.0) * (double)(n_per_shard * G) * sww;
-    }
-    c->last_kept = keep;
-    if (keep) {
-        c->gathered = false;
-        c->lists_known = false;
-        if (!loc.bad()) loc.note(h, mcl_stage_keep(h, (int64_t)c->rank * n_per_shard, n_per_shard * G, action));
-    } else if (lists) {
-        if (!loc.bad() && counts[c->rank] != h->compact_n)
-            loc.note(h, fail(h, MCL_ERR_NOT_READY, "this engine's list is not the one the last exchange described (state changed on one rank only?)"));
-        // (1) the lists: already here when the previous update gathered them (same lists, same lengths), else now.  Whether they
-        // were pre-gathered is the same on every rank: every rank gathers after a good update and forgets after a void one.
-        bool have = c->gathered_entries > 0 && c->gathered_epoch_all == c->updates - 1;
-        for (int r = 0; r < G && have; ++r) have = c->gathered_counts[r] == counts[r];
-        if (have && !(c->gathered && c->gathered_epoch == h->list_epoch) && !loc.bad())
-            loc.note(h, fail(h, MCL_ERR_NOT_READY, "the gathered lists are stale on this rank (particle state changed on one rank only?)"));
-        if (!have) { rc = comm_gather_lists(h, counts, loc); if (rc) return rc; }
-        const int64_t entries = c->gathered_entries;
-        c->gathered = false;
-        c->lists_known = false;                // (known again once this update's vector is here)
-        if (!loc.bad() && comm_injected(c, "resample")) loc.note(h, fail(h, MCL_ERR_HIP, "injected failure before the resampling stage (MCL_COMM_FAIL)"));
-        if (!loc.bad())
-            loc.note(h, stage_resample_compact_launch(h, c->d_chunk_all, G, entries, counts, totals, n_per_shard, c->rank, (int64_t)c->rank * n_per_shard,
-                                                      n_per_shard * G, action, nullptr));
-    } else {
-        c->gathered = false;
-        c->lists_known = false;
-        rc = comm_resample_dense(h, action, loc);
-        if (rc) return rc;
-    }
-    // (2) + (3)
-    double failed = 0.0;
-    rc = comm_rays_to_sums(h, obs, n_beams, false, loc, &failed);
-    if (rc) return rc;
-    const size_t k = 5 + 3 * (size_t)G + 2;
-    if (failed == 0.0 && !loc.bad() && c->h_red[1 + k - 2] != 0.0) {
-        // some shard's fix-up lists overflowed (debug_force_exact at size, a pathological map): every rank once more from the ray stage on
-        rc = comm_rays_to_sums(h, obs, n_beams, true, loc, &failed);
-        if (rc) return rc;
-    }
-    if (failed != 0.0 || loc.bad()) {
-        // a void update, on every rank alike: the lists and sums are forgotten, the particle set must be set or initialised again
-        comm_forget(c);
-        c->gathered_entries = 0;
-        h->have_particles = false;
-        if (loc.bad()) return fail(h, loc.code, loc.msg + " [sharded update void on every rank]");
-        char m[160];
-        std::snprintf(m, sizeof m, "%d rank(s) of the sharded set reported a failure in this update: it is void on every rank (set or initialise the particles again)", (int)failed);
-        return fail(h, MCL_ERR_PEER, m);
-    }
-    for (size_t i = 0; i < k; ++i) c->vec[i] = c->h_red[1 + i];
-    for (int i = 0; i < 5; ++i) h->global_sums[i] = c->vec[i];
-    c->vec_valid = true;
-    stage_commit_carry(h);
-    comm_note_lists(c, c->vec);
-    bool next_keeps = false;
-    if (h->cfg.resample_neff_permille > 0) {
-        const double sw = c->vec[0], sww = c->vec[5 + 3 * G + 1];
-        next_keeps = sww > 0.0 && sw * sw >= ((double)h->cfg.resample_neff_permille / 1000.0) * (double)(n_per_shard * G) * sww;
-    }
-    // the lists this update wrote are final: gather them for the next update now, beside the host's work between updates
-    // (every rank reads the same vector, so every rank takes the same decision)
-    c->gathered_entries = 0;
-    {
-        bool all = true;
-        uint64_t wsum = 0;
-        for (int r = 0; r < G; ++r) { all = all && c->counts[r] >= 0; wsum |= c->counts[r] > 0 ? c->totals[r] : 0ull; }
-        if (all && wsum != 0 && !h->env_comm_no_pregather && !next_keeps) {
-            CommLocal pre;                         // (a local failure of the export shows in the next update: `gathered` stays false here)
-            rc = comm_gather_lists(h, c->counts, pre);
-            if (rc) return rc;
-            c->gathered_epoch_all = c->updates;
-        }
-    }
-    const double sw = c->vec[0], kk = sw > 0.0 ? 1.0 / sw : 1.0;          // expected_pose (cpp:702-716) over the whole set
-    pose_out[0] = c->vec[1] * kk; pose_out[1] = c->vec[2] * kk; pose_out[2] = std::atan2(c->vec[3] * kk, c->vec[4] * kk);
-    h->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return MCL_OK;
-}
-
-int mcl_comm_get_vector(const mcl_engine_t *h, double *vec_out, int32_t n)
-{
-    if (!h || !h->comm || !vec_out || n != 5 + 3 * h->comm->n_ranks + 2) return MCL_ERR_INVALID_ARG;
-    for (int i = 0; i < n; ++i) vec_out[i] = h->comm->vec[i];
-    return MCL_OK;
-}
-
-int mcl_comm_last_exchange(const mcl_engine_t *h, int32_t *dense, uint64_t *weights_bytes, uint64_t *records_bytes)
-{
-    if (!h || !h->comm) return MCL_ERR_INVALID_ARG;
-    if (dense) *dense = h->comm->last_kept ? 2 : h->comm->last_dense ? 1 : 0;       // 0 lists, 1 dense, 2 none (the set was kept)
-    if (weights_bytes) *weights_bytes = h->comm->last_dense ? h->comm->dense_weights_bytes : 0;
-    if (records_bytes) *records_bytes = h->comm->last_dense ? h->comm->dense_records_bytes : 0;
-    return MCL_OK;
-}
-
-int mcl_comm_stats(const mcl_engine_t *h, uint64_t *list_bytes_received, uint64_t *list_payload_bytes, int32_t *host_waits)
-{
-    if (!h || !h->comm) return MCL_ERR_INVALID_ARG;
-    if (list_bytes_received) *list_bytes_received = h->comm->bytes_received;
-    if (list_payload_bytes) *list_payload_bytes = h->comm->bytes_payload;
-    if (host_waits) *host_waits = h->comm->host_waits;
-    return MCL_OK;
-}
-
 int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset)
 {
     if (!h || !d_q || !d_cdf || n <= 0) return MCL_ERR_INVALID_ARG;
@@ -3488,441 +2684,49 @@ int mcl_scan_weights(mcl_engine_t *h, const uint64_t *d_q, uint64_t *d_cdf, int6
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Several GPUs driven by ONE host process (the reference is a single ROS 2 process, cpp:1019-1025): a group owns one engine
-// per device, shards the particles contiguously and runs every update phase on all devices before the next phase starts,
-// so the devices work concurrently although one host thread issues the calls.  Per update and device:
-//   * the other shards' fixed-point weights arrive by peer copies (8 B per particle of the other shards), every device
-//     scans the same exact global CDF and draws its own children;
-//   * a child's parent record is read where it lives (peer pointer): only SELECTED parents cross a link, no record is
-//     gathered wholesale;
-//   * max log-weight and the seven sums are combined on the host (a few doubles per device).
-// Results are bit-identical to one engine holding all particles (exact integer CDF, exact fp64 log-weight sums, Philox
-// keyed by the global particle index), which tests/test_gpu_group.py checks with two engines on one device.
-// ---------------------------------------------------------------------------------------------
-struct mcl_group {
-    std::vector<mcl_engine *> eng;
-    std::vector<uint64_t *> d_qall, d_cdfall;      // per device: all shards' weights and their global CDF
-    std::vector<unsigned long long *> d_remote;    // per device, 4 words: children whose parent was fetched from a peer (last update) |
-                                                   // this shard's max log-weight | the maximum over the shards (doubles)
-    std::vector<unsigned char *> d_chunks;         // per device: every shard's compact parent list (grown on demand)
-    std::vector<size_t> chunks_capacity;
-    std::vector<hipEvent_t> ev_ready, ev_children, ev_rays; // per device, see mcl_group_update
-    bool compact_last = false;
-    int64_t n_per = 0, n_total = 0;
-    uint64_t q_total = 0;
-    bool have_q_total = false;
-    double sums[5] = {0, 0, 0, 0, 0};
-    double sum_ww = 0.0;                           // sum w^2 of the whole set (adaptive resampling)
-    bool kept_last = false;
-    double timings[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t bytes_weights = 0, bytes_parents = 0;
-    std::string err;
-};
-
-static int gfail(mcl_group *g, int rc, const std::string &msg)
-{
-    if (g) g->err = msg;
-    return rc;
-}
-
-static int group_sync_q_total(mcl_group *g)
-{
-    // after set_particles / init: every shard has its local fixed-point total on the host (fetch_scalars)
-    uint64_t t = 0;
-    for (auto *e : g->eng) t += e->q_total;
-    g->q_total = t;
-    g->have_q_total = true;
-    double gs[5] = {0, 0, 0, 0, 0};
-    for (auto *e : g->eng)
-        for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];
-    for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
-    for (auto *e : g->eng) mcl_stage_finish(e, gs);
-    return MCL_OK;
-}
-
-const char *mcl_group_last_error(const mcl_group_t *g) { return g ? g->err.c_str() : g_create_error.c_str(); }
-
-void mcl_group_destroy(mcl_group_t *g)
-{
-    if (!g) return;
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        if (!g->eng[d]) continue;
-        (void)hipSetDevice(g->eng[d]->cfg.device);
-        if (d < g->d_qall.size() && g->d_qall[d]) (void)hipFree(g->d_qall[d]);
-        if (d < g->d_cdfall.size() && g->d_cdfall[d]) (void)hipFree(g->d_cdfall[d]);
-        if (d < g->d_remote.size() && g->d_remote[d]) (void)hipFree(g->d_remote[d]);
-        if (d < g->d_chunks.size() && g->d_chunks[d]) (void)hipFree(g->d_chunks[d]);
-        if (d < g->ev_ready.size() && g->ev_ready[d]) (void)hipEventDestroy(g->ev_ready[d]);
-        if (d < g->ev_children.size() && g->ev_children[d]) (void)hipEventDestroy(g->ev_children[d]);
-        if (d < g->ev_rays.size() && g->ev_rays[d]) (void)hipEventDestroy(g->ev_rays[d]);
-        mcl_destroy(g->eng[d]);
-    }
-    delete g;
-}
-
-int mcl_group_create(const mcl_config_t *cfg, const int32_t *devices, int32_t n_devices, mcl_group_t **out)
-{
-    g_create_error.clear();
-    if (!cfg || !devices || !out || n_devices <= 0 || n_devices > mcl::kMaxShards) { g_create_error = "bad group arguments (1..16 devices)"; return MCL_ERR_INVALID_ARG; }
-    *out = nullptr;
-    if (cfg->weight_mode != MCL_WEIGHT_LOG) {
-        g_create_error = "a device group needs weight_mode LOG";
-        return MCL_ERR_UNSUPPORTED;
-    }
-    if ((int64_t)cfg->max_particles * n_devices >= MCL_MAX_TOTAL_PARTICLES) { g_create_error = "particle total must stay below 2^27"; return MCL_ERR_INVALID_ARG; }
-    mcl_group *g = new mcl_group();
-    for (int d = 0; d < n_devices; ++d) {
-        mcl_config_t c = *cfg;
-        c.device = devices[d];
-        mcl_engine_t *e = nullptr;
-        const int rc = mcl_create(&c, &e);
-        if (rc != MCL_OK) { mcl_group_destroy(g); return rc; }
-        g->eng.push_back(e);
-    }
-    g->d_qall.assign(n_devices, nullptr); g->d_cdfall.assign(n_devices, nullptr); g->d_remote.assign(n_devices, nullptr);
-    g->d_chunks.assign(n_devices, nullptr); g->chunks_capacity.assign(n_devices, 0);
-    g->ev_ready.assign(n_devices, nullptr); g->ev_children.assign(n_devices, nullptr); g->ev_rays.assign(n_devices, nullptr);
-    const size_t cap_total = (size_t)cfg->max_particles * n_devices;
-    for (int d = 0; d < n_devices; ++d) {
-        if (hipSetDevice(devices[d]) != hipSuccess || hipMalloc(&g->d_qall[d], cap_total * 8) != hipSuccess ||
-            hipMalloc(&g->d_cdfall[d], cap_total * 8) != hipSuccess || hipMalloc(&g->d_remote[d], 32) != hipSuccess ||
-            hipEventCreateWithFlags(&g->ev_ready[d], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->ev_rays[d], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->ev_children[d], hipEventDisableTiming) != hipSuccess) {
-            g_create_error = "group buffers: hipMalloc failed";
-            mcl_group_destroy(g);
-            return MCL_ERR_HIP;
-        }
-        // parents are read where they live: peer access to every other device of the group
-        for (int o = 0; o < n_devices; ++o) {
-            if (devices[o] == devices[d]) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[d], devices[o]) != hipSuccess || !can) {
-                g_create_error = "devices of a group must have peer access to each other";
-                mcl_group_destroy(g);
-                return MCL_ERR_UNSUPPORTED;
-            }
-            const hipError_t pe = hipDeviceEnablePeerAccess(devices[o], 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { g_create_error = "hipDeviceEnablePeerAccess failed"; mcl_group_destroy(g); return MCL_ERR_HIP; }
-            (void)hipGetLastError();
-        }
-    }
-    *out = g;
-    return MCL_OK;
-}
-
-int32_t mcl_group_size(const mcl_group_t *g) { return g ? (int32_t)g->eng.size() : 0; }
-
-int mcl_group_engine(mcl_group_t *g, int32_t i, mcl_engine_t **out)
-{
-    if (!g || !out || i < 0 || i >= (int32_t)g->eng.size()) return MCL_ERR_INVALID_ARG;
-    *out = g->eng[i];
-    return MCL_OK;
-}
-
-int mcl_group_set_map(mcl_group_t *g, const int8_t *data, uint32_t width, uint32_t height, float resolution, double origin_x, double origin_y)
-{
-    if (!g) return MCL_ERR_INVALID_ARG;
-    for (auto *e : g->eng) {
-        const int rc = mcl_set_map(e, data, width, height, resolution, origin_x, origin_y);
-        if (rc) return gfail(g, rc, e->err);
-    }
-    return MCL_OK;
-}
-
-int mcl_group_set_beam_angles(mcl_group_t *g, const float *angles, int32_t n_beams)
-{
-    if (!g) return MCL_ERR_INVALID_ARG;
-    for (auto *e : g->eng) {
-        const int rc = mcl_set_beam_angles(e, angles, n_beams);
-        if (rc) return gfail(g, rc, e->err);
-    }
-    return MCL_OK;
-}
-
-static int group_check_total(mcl_group *g, int64_t n_total)
-{
-    const int64_t G = (int64_t)g->eng.size();
-    if (n_total <= 0 || n_total % G != 0 || n_total / G > g->eng[0]->cap)
-        return gfail(g, MCL_ERR_INVALID_ARG, "the particle total must be a multiple of the device count and fit max_particles per device");
-    g->n_total = n_total; g->n_per = n_total / G;
-    return MCL_OK;
-}
-
-int mcl_group_set_particles(mcl_group_t *g, const double *xyz, const double *weights, int64_t n_total)
-{
-    if (!g || !xyz || !weights) return MCL_ERR_INVALID_ARG;
-    int rc = group_check_total(g, n_total);
-    if (rc) return rc;
-    // all shards quantise their weights against the same scale: the maximum over the whole set, which is what a single
-    // engine holding all particles would use
-    double wmax = 0.0;
-    for (int64_t i = 0; i < n_total; ++i) wmax = std::max(wmax, weights[i]);
-    if (!(wmax > 0.0)) return gfail(g, MCL_ERR_INVALID_ARG, "weights must have a positive maximum");
-    std::vector<double> shard((size_t)g->n_per * 3);
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        for (int c = 0; c < 3; ++c)
-            std::memcpy(shard.data() + (size_t)c * g->n_per, xyz + (size_t)c * n_total + d * (size_t)g->n_per, (size_t)g->n_per * 8);
-        rc = set_particles_impl(g->eng[d], shard.data(), weights + d * (size_t)g->n_per, g->n_per, &wmax);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
-    return group_sync_q_total(g);
-}
-
-int mcl_group_init_particles_pose(mcl_group_t *g, const double pose[3], int64_t n_total)
-{
-    if (!g || !pose) return MCL_ERR_INVALID_ARG;
-    int rc = group_check_total(g, n_total);
-    if (rc) return rc;
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        rc = mcl_init_particles_pose(g->eng[d], pose, g->n_per, (int64_t)d * g->n_per, n_total);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
-    return group_sync_q_total(g);
-}
-
-int mcl_group_init_global(mcl_group_t *g, int64_t n_total)
-{
-    if (!g) return MCL_ERR_INVALID_ARG;
-    int rc = group_check_total(g, n_total);
-    if (rc) return rc;
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        rc = mcl_init_global(g->eng[d], g->n_per, (int64_t)d * g->n_per, n_total);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
-    return group_sync_q_total(g);
-}
-
-#define GHIP(g, call)                                                                            \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) return gfail(g, MCL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-int mcl_group_update(mcl_group_t *g, const double action[3], const float *obs, int32_t n_beams)
-{
-    if (!g || !action || !obs) return MCL_ERR_INVALID_ARG;
-    if (g->n_per <= 0 || !g->have_q_total) return gfail(g, MCL_ERR_NOT_READY, "particles not set");
-    const auto t0 = std::chrono::steady_clock::now();
-    const int G = (int)g->eng.size();
-    const int64_t n = g->n_per, nt = g->n_total;
-    // Phases are ordered by EVENTS between the devices' streams, not by host-side synchronisation: ev_ready[s] = shard s's
-    // parent data (records or compact list, weights) may be read by its peers; ev_children[d] = device d has drawn its children
-    // and no longer reads anybody's parent data.  The host waits only where it needs a value (the maxima, the sums).
-    // Exchange: when every shard has a compact parent list (the usual case after an update with many beams) the devices copy
-    // each other's LISTS (44 B per particle that carries weight); otherwise every weight (8 B per particle) and the
-    // selected parents are read where they live.
-    // Adaptive resampling (E9, cfg.resample_neff_permille > 0): the set is kept -- no exchange, no resampling -- when the effective
-    // sample size of the WHOLE set after the previous update is at least r / 1000 of it (mcl_update's rule on the group's sums)
-    bool keep = false;
-    {
-        const int r = g->eng[0]->cfg.resample_neff_permille;
-        bool carry = r > 0;
-        for (int s = 0; s < G; ++s) carry = carry && g->eng[s]->carry_valid;
-        if (carry) keep = g->sum_ww > 0.0 && g->sums[0] * g->sums[0] >= ((double)r / 1000.0) * (double)nt * g->sum_ww;
-    }
-    bool compact = g->q_total != 0 && !keep;
-    int64_t longest = 0;
-    for (int s = 0; s < G; ++s) { compact = compact && g->eng[s]->compact_n >= 0; longest = std::max(longest, g->eng[s]->compact_n); }
-    const int64_t centries = std::max<int64_t>(64, (longest + 63) & ~(int64_t)63);
-    for (int s = 0; s < G; ++s) {
-        mcl_engine *e = g->eng[s];
-        GHIP(g, hipSetDevice(e->cfg.device));
-        if (!compact && !keep && !e->pack_valid[e->cur]) {      // first update after set_particles / init: the records do not exist yet
-            hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->d_x[e->cur], e->d_y[e->cur],
-                               e->d_th[e->cur], n, e->d_pack[e->cur]);
-            e->pack_valid[e->cur] = true;
-        }
-        GHIP(g, hipEventRecord(g->ev_ready[s], e->stream));
-    }
-    const double4 *parents[mcl::kMaxShards] = {};      // the launch below flips an engine's current buffer: take the pointers first
-    for (int s = 0; s < G; ++s) parents[s] = g->eng[s]->d_pack[g->eng[s]->cur];
-    int64_t counts[mcl::kMaxShards] = {};
-    uint64_t totals[mcl::kMaxShards] = {};
-    for (int s = 0; s < G; ++s) { counts[s] = g->eng[s]->compact_n; totals[s] = g->eng[s]->q_total; }
-    for (int d = 0; d < G; ++d) {
-        mcl_engine *e = g->eng[d];
-        GHIP(g, hipSetDevice(e->cfg.device));
-        for (int s = 0; s < G; ++s)
-            if (s != d) GHIP(g, hipStreamWaitEvent(e->stream, g->ev_ready[s], 0));
-        GHIP(g, hipMemsetAsync(g->d_remote[d], 0, 8, e->stream));
-        int rc;
-        if (keep) {
-            rc = mcl_stage_keep(e, (int64_t)d * n, nt, action);
-        } else if (compact) {
-            const size_t need = (size_t)G * (size_t)centries * 44;
-            if (need > g->chunks_capacity[d]) {
-                if (g->d_chunks[d]) { GHIP(g, hipStreamSynchronize(e->stream)); (void)hipFree(g->d_chunks[d]); g->d_chunks[d] = nullptr; }
-                g->chunks_capacity[d] = 0;
-                GHIP(g, hipMalloc(&g->d_chunks[d], need));
-                g->chunks_capacity[d] = need;
-            }
-            for (int s = 0; s < G; ++s) {
-                rc = export_compact_launch(g->eng[s], g->d_chunks[d] + (size_t)s * (size_t)centries * 44, centries, e->cfg.device, e->stream);
-                if (rc) return gfail(g, rc, g->eng[s]->err);
-            }
-            rc = stage_resample_compact_launch(e, g->d_chunks[d], G, centries, counts, totals, n, d, (int64_t)d * n, nt, action, g->d_remote[d]);
-        } else {
-            for (int s = 0; s < G; ++s)
-                GHIP(g, hipMemcpyPeerAsync(g->d_qall[d] + (size_t)s * n, e->cfg.device, g->eng[s]->d_q, g->eng[s]->cfg.device, (size_t)n * 8, e->stream));
-            if ((size_t)nt / mcl::kScanTile + 2 > e->blocktot_capacity) {
-                graph_reset(e);                // a captured update graph of this engine holds the old pointer
-                GHIP(g, hipStreamSynchronize(e->stream));
-                dfree(e->d_blocktot);
-                GHIP(g, hipMalloc(&e->d_blocktot, ((size_t)nt / mcl::kScanTile + 2) * 8));
-                e->blocktot_capacity = (size_t)nt / mcl::kScanTile + 2;
-            }
-            rc = scan_weights(e, g->d_qall[d], g->d_cdfall[d], nt, 0, nullptr);
-            if (rc) return gfail(g, rc, e->err);
-            ParentSource src;
-            for (int s = 0; s < G; ++s) src.rank_records[s] = parents[s];
-            src.n_per_rank = n; src.self_rank = d; src.remote_count = g->d_remote[d];
-            rc = stage_resample_launch(e, src, g->d_cdfall[d], nt, g->q_total, (int64_t)d * n, nt, action);
-        }
-        if (rc) return gfail(g, rc, e->err);
-        GHIP(g, hipEventRecord(g->ev_children[d], e->stream));
-    }
-    // phase 2: rays + likelihood on every device; the global maximum is taken ON the devices (every device reads the peers'
-    // local maxima once their ray stages have finished: events, no host wait)
-    // phase 3: weights against the global maximum, sums.  The weights (and the compact list) of a shard are rewritten here:
-    // every device must have drawn its children first.  The host waits once, for the sums.
-    double gs[5] = {0, 0, 0, 0, 0};
-    double sww = 0.0;
-    uint64_t qt = 0;
-    unsigned long long remote = 0;
-    uint64_t listed = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool redo = pass == 1;          // only after a fix-up list overflow: the synchronous ray stage falls back by itself
-        for (int d = 0; d < G; ++d) {
-            mcl_engine *e = g->eng[d];
-            double *lmax = reinterpret_cast<double *>(g->d_remote[d] + 1);
-            int rc = stage_rays_launch(e, obs, n_beams, false, redo ? nullptr : lmax);
-            if (!rc && redo) {
-                rc = stage_rays_finish(e, obs, n_beams);             // (waits; relaunches with k_rays_skip after an overflow)
-                if (!rc) hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, e->stream, e->d_scalars, lmax);
-            }
-            if (rc) return gfail(g, rc, e->err);
-            GHIP(g, hipEventRecord(g->ev_rays[d], e->stream));
-        }
-        for (int d = 0; d < G; ++d) {
-            mcl_engine *e = g->eng[d];
-            GHIP(g, hipSetDevice(e->cfg.device));
-            mcl::GroupMaxArgs ma{};
-            for (int o = 0; o < G; ++o) {
-                if (o != d) {
-                    GHIP(g, hipStreamWaitEvent(e->stream, g->ev_rays[o], 0));
-                    GHIP(g, hipStreamWaitEvent(e->stream, g->ev_children[o], 0));
-                }
-                ma.src[o] = reinterpret_cast<const double *>(g->d_remote[o] + 1);
-            }
-            ma.n = G; ma.out = reinterpret_cast<double *>(g->d_remote[d] + 2);
-            hipLaunchKernelGGL(mcl::k_group_max, dim3(1), dim3(1), 0, e->stream, ma);
-            const int rc = stage_weights_launch(e, 0.0, ma.out);
-            if (rc) return gfail(g, rc, e->err);
-        }
-        for (int k = 0; k < 5; ++k) gs[k] = 0.0;
-        sww = 0.0;
-        qt = 0; remote = 0; listed = 0;
-        bool overflow = false;
-        for (int d = 0; d < G; ++d) {
-            mcl_engine *e = g->eng[d];
-            int rc = stage_weights_finish(e);                         // THE host wait of this device's update
-            if (rc) return gfail(g, rc, e->err);
-            stage_rays_note(e);
-            overflow = overflow || (e->last_quad && e->h_fix_count != 0);
-            for (int k = 0; k < 5; ++k) gs[k] += e->global_sums[k];      // unpack_result left the LOCAL sums there
-            sww += e->h_scalars[7];
-            qt += e->q_total;
-            unsigned long long r = 0;
-            GHIP(g, hipMemcpy(&r, g->d_remote[d], 8, hipMemcpyDeviceToHost));
-            remote += r;
-            if (compact) listed += (uint64_t)counts[d];
-        }
-        if (!overflow) break;
-        if (redo) return gfail(g, MCL_ERR_HIP, "the ray stage's work lists overflowed twice (internal)");
-    }
-    for (int k = 0; k < 5; ++k) g->sums[k] = gs[k];
-    g->sum_ww = sww;
-    g->kept_last = keep;
-    g->q_total = qt;
-    for (int d = 0; d < G; ++d) mcl_stage_finish(g->eng[d], gs);
-    // received per device: the other shards' lists / weights; parents read from peers (dense exchange only)
-    // (lists are copied entry-exact, not as padded chunks: the device that holds the shortest list receives the most)
-    uint64_t shortest = ~0ull;
-    for (int d = 0; d < G; ++d) shortest = std::min<uint64_t>(shortest, compact ? (uint64_t)counts[d] : 0u);
-    g->bytes_weights = compact ? (listed - shortest) * 44u : (uint64_t)(G - 1) * (uint64_t)n * 8u;
-    g->bytes_parents = compact ? 0u : (uint64_t)remote * 32u;         // upper bound: children of remote parents x record size
-    if (keep) { g->bytes_weights = 0; g->bytes_parents = 0; }         // nothing was exchanged
-    g->compact_last = compact;
-    for (int k = 0; k < 5; ++k) {
-        double m = 0.0;
-        for (int d = 0; d < G; ++d) m = std::max(m, g->eng[d]->timings[k]);
-        g->timings[k] = m;
-    }
-    g->timings[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return MCL_OK;
-}
-
-int mcl_group_expected_pose(mcl_group_t *g, double out[3])
-{
-    if (!g || !out) return MCL_ERR_INVALID_ARG;
-    if (g->n_per <= 0) return MCL_ERR_NOT_READY;
-    const double s = g->sums[0];
-    const double k = (s > 0.0) ? 1.0 / s : 1.0;
-    out[0] = g->sums[1] * k;
-    out[1] = g->sums[2] * k;
-    out[2] = std::atan2(g->sums[3] * k, g->sums[4] * k);
-    return MCL_OK;
-}
-
-int mcl_group_get_particles(mcl_group_t *g, double *xyz, int64_t n_total)
-{
-    if (!g || !xyz || n_total != g->n_total || g->n_per <= 0) return MCL_ERR_INVALID_ARG;
-    std::vector<double> shard((size_t)g->n_per * 3);
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        const int rc = mcl_get_particles(g->eng[d], shard.data(), g->n_per);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-        for (int c = 0; c < 3; ++c)
-            std::memcpy(xyz + (size_t)c * n_total + d * (size_t)g->n_per, shard.data() + (size_t)c * g->n_per, (size_t)g->n_per * 8);
-    }
-    return MCL_OK;
-}
-
-int mcl_group_get_weights(mcl_group_t *g, double *weights, int64_t n_total)
-{
-    if (!g || !weights || n_total != g->n_total || g->n_per <= 0) return MCL_ERR_INVALID_ARG;
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        const int rc = mcl_get_weights(g->eng[d], weights + d * (size_t)g->n_per, g->n_per);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
-    return MCL_OK;
-}
-
-int mcl_group_get_resample_indices(mcl_group_t *g, int32_t *idx, int64_t n_total)
-{
-    if (!g || !idx || n_total != g->n_total || g->n_per <= 0) return MCL_ERR_INVALID_ARG;
-    for (size_t d = 0; d < g->eng.size(); ++d) {
-        const int rc = mcl_get_resample_indices(g->eng[d], idx + d * (size_t)g->n_per, g->n_per);
-        if (rc) return gfail(g, rc, g->eng[d]->err);
-    }
-    return MCL_OK;
-}
-
-int mcl_group_get_stage_timings(const mcl_group_t *g, double ms[6])
-{
-    if (!g || !ms) return MCL_ERR_INVALID_ARG;
-    std::memcpy(ms, g->timings, sizeof(g->timings));
-    return MCL_OK;
-}
-
-int mcl_group_exchange_bytes(const mcl_group_t *g, uint64_t out[2])
-{
-    if (!g || !out) return MCL_ERR_INVALID_ARG;
-    out[0] = g->bytes_weights; out[1] = g->bytes_parents;
-    return MCL_OK;
-}
-
-int32_t mcl_group_exchanged_lists(const mcl_group_t *g) { return g && g->compact_last ? 1 : 0; }
-
 }  // extern "C"
+
+// ---- what mcl_comm.hip / mcl_group.hip reach of this translation unit (mcl_engine_internal.h)
+namespace mcl_host {
+int fail(mcl_engine *h, int code, const char *msg) { return ::fail(h, code, msg); }
+int fail(mcl_engine *h, int code, const std::string &msg) { return ::fail(h, code, msg); }
+std::string &create_error() { return g_create_error; }
+bool ready(mcl_engine *h, bool need_particles) { return ::ready(h, need_particles); }
+float elapsed(hipEvent_t a, hipEvent_t b) { return ::elapsed(a, b); }
+void graph_reset(mcl_engine *h) { ::graph_reset(h); }
+int scan_weights(mcl_engine *h, const uint64_t *d_q, uint64_t *d_cdf, int64_t n, uint64_t offset, uint64_t *d_total) { return ::scan_weights(h, d_q, d_cdf, n, offset, d_total); }
+void unpack_result(mcl_engine *h) { ::unpack_result(h); }
+int layout_adopt(mcl_engine *h, int64_t n) { return ::layout_adopt(h, n); }
+int set_particles_impl(mcl_engine_t *h, const double *xyz, const double *weights, int64_t n, const double *weight_scale) { return ::set_particles_impl(h, xyz, weights, n, weight_scale); }
+int stage_resample_launch(mcl_engine_t *h, const ParentSource &src, const uint64_t *d_cdf, int64_t n_parents, uint64_t q_total,
+                          int64_t child_first, int64_t n_children_total, const double action[3])
+{
+    return ::stage_resample_launch(h, src, d_cdf, n_parents, q_total, child_first, n_children_total, action);
+}
+int export_compact_launch(mcl_engine_t *h, void *d_chunk, int64_t chunk_entries, int dst_device, hipStream_t stream) { return ::export_compact_launch(h, d_chunk, chunk_entries, dst_device, stream); }
+int stage_resample_compact_launch(mcl_engine_t *h, const void *d_chunks, int32_t n_shards, int64_t chunk_entries, const int64_t *counts,
+                                  const uint64_t *totals, int64_t n_per_shard, int32_t self_shard, int64_t child_first,
+                                  int64_t n_children_total, const double action[3], unsigned long long *remote_count)
+{
+    return ::stage_resample_compact_launch(h, d_chunks, n_shards, chunk_entries, counts, totals, n_per_shard, self_shard, child_first, n_children_total, action, remote_count);
+}
+int stage_rays_launch(mcl_engine_t *h, const float *obs, int32_t n_beams, bool force_skip, double *d_max_out) { return ::stage_rays_launch(h, obs, n_beams, force_skip, d_max_out); }
+void stage_rays_note(mcl_engine_t *h) { ::stage_rays_note(h); }
+int stage_rays_finish(mcl_engine_t *h, const float *obs, int32_t n_beams) { return ::stage_rays_finish(h, obs, n_beams); }
+int stage_weights_launch(mcl_engine_t *h, double global_max_logw, const double *d_global_max) { return ::stage_weights_launch(h, global_max_logw, d_global_max); }
+int stage_weights_finish(mcl_engine_t *h) { return ::stage_weights_finish(h); }
+void stage_commit_carry(mcl_engine_t *h) { ::stage_commit_carry(h); }
+void launch_copy_double(hipStream_t stream, const double *src, double *dst) { hipLaunchKernelGGL(mcl::k_copy_double, dim3(1), dim3(1), 0, stream, src, dst); }
+void launch_set_double(hipStream_t stream, double *dst, double v) { hipLaunchKernelGGL(mcl::k_set_double, dim3(1), dim3(1), 0, stream, dst, v); }
+void launch_spin_ms(hipStream_t stream, double ms) { hipLaunchKernelGGL(mcl::k_spin_ms, dim3(1), dim3(64), 0, stream, ms); }
+void launch_stage_pack(hipStream_t stream, const unsigned long long *d_result, double *d_vec, int n_shards, int self, int listed, unsigned long long list_cap)
+{
+    hipLaunchKernelGGL(mcl::k_stage_pack, dim3(1), dim3(64), 0, stream, d_result, d_vec, n_shards, self, listed, list_cap);
+}
+void launch_pack_records(hipStream_t stream, const double *x, const double *y, const double *th, int64_t n, double4 *out)
+{
+    hipLaunchKernelGGL(mcl::k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, th, n, out);
+}
+void launch_group_max(hipStream_t stream, const mcl::GroupMaxArgs &a) { hipLaunchKernelGGL(mcl::k_group_max, dim3(1), dim3(1), 0, stream, a); }
+}  // namespace mcl_host
+

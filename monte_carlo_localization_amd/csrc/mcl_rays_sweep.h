@@ -788,9 +788,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 const int w0 = beam_wedge(th, a.beam_angle[0]), wl = beam_wedge(th, a.beam_angle[a.B - 1]);
                 const int m = w0 + ((kbin - w0) & (kWedges - 1));
                 if (m <= wl) {
-                    ja = m == w0 ? 0 : first_beam_in_wedge(th, a.beam_angle, a.B, m, a.beam_a0, a.beam_inv_inc);
-                    jb = m == wl ? a.B : first_beam_in_wedge(th, a.beam_angle, a.B, m + 1, a.beam_a0, a.beam_inv_inc);
-                    if (m + kWedges <= wl) ja2 = first_beam_in_wedge(th, a.beam_angle, a.B, m + kWedges, a.beam_a0, a.beam_inv_inc);
+                    ja = m == w0 ? 0 : first_beam_in_wedge<REC>(th, a.beam_angle, a.B, m, a.beam_a0, a.beam_inv_inc);
+                    jb = m == wl ? a.B : first_beam_in_wedge<REC>(th, a.beam_angle, a.B, m + 1, a.beam_a0, a.beam_inv_inc);
+                    if (m + kWedges <= wl) ja2 = first_beam_in_wedge<REC>(th, a.beam_angle, a.B, m + kWedges, a.beam_a0, a.beam_inv_inc);
                 }
             } else if (kbin == 0) {
                 jb = a.B;            // garbage heading: one range in quadrant 0 like k_particle_prep (position is NaN -> far path)

@@ -76,12 +76,17 @@ class ShardedUpdateError(EngineError):
         self.local = local
 
 
-_lib = None
+_libs = {}
+LEGACY_LIB_PATH = os.path.join(_HERE, "libmcl_hip_engine_legacy.so")
 
 
-def load_library():
-    """Loads libmcl_hip_engine.so (built by __graft_entry__.build()); raises if absent."""
-    global _lib
+def load_library(legacy=False):
+    """Loads libmcl_hip_engine.so (built by __graft_entry__.build()); raises if absent.  legacy=True: the same sources built with
+    -DMCL_LEGACY_RAY_KERNELS (libmcl_hip_engine_legacy.so), which also holds k_rays_quad / k_rays_cell -- the predecessors of the
+    windowed ray kernel, kept as two more implementations to test it against; an Engine asks for it only when its configuration
+    names one of them (ray_kernel = RAYS_QUAD / RAYS_CELL)."""
+    path = LEGACY_LIB_PATH if legacy else LIB_PATH
+    _lib = _libs.get(path)
     if _lib is None:
         # PyTorch-ROCm wheels bundle their own copies of the ROCm runtime under the same sonames as /opt/rocm's
         # (libamdhip64.so.7, libhsa-runtime64.so.1).  A process that uses both must load torch's first: if this library pulls
@@ -95,10 +100,10 @@ def load_library():
                 import torch  # noqa: F401
             except Exception:
                 pass
-        if not os.path.exists(LIB_PATH):
-            raise EngineError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        if not os.path.exists(path):
+            raise EngineError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         lib.mcl_last_error.restype = C.c_char_p
         lib.mcl_last_error.argtypes = [C.c_void_p]
         lib.mcl_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -111,7 +116,7 @@ def load_library():
         lib.mcl_group_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         lib.mcl_group_destroy.argtypes = [C.c_void_p]
         lib.mcl_group_destroy.restype = None
-        _lib = lib
+        _libs[path] = _lib = lib
     return _lib
 
 
@@ -183,11 +188,12 @@ class Engine:
     """One engine == one GPU == one particle shard."""
 
     def __init__(self, cfg: Config | None = None, **over):
-        self.lib = load_library()
         self.cfg = cfg if cfg is not None else default_config(**over)
         if cfg is not None:
             for k, v in over.items():
                 setattr(self.cfg, k, v)
+        # (the predecessors of the windowed ray kernel live in the legacy build of the library: load_library)
+        self.lib = load_library(legacy=int(self.cfg.ray_kernel) in (RAYS_QUAD, RAYS_CELL))
         h = C.c_void_p()
         rc = self.lib.mcl_create(C.byref(self.cfg), C.byref(h))
         if rc != MCL_OK:

@@ -81,3 +81,15 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert "mcl_oracle" not in txt or f.endswith("mcl_device_math.h"), f
+
+
+def test_legacy_build_exports_the_same_abi_and_the_product_refuses_its_kernels(engine_mod):
+    """libmcl_hip_engine_legacy.so (the same sources with -DMCL_LEGACY_RAY_KERNELS: k_rays_quad / k_rays_cell, test
+    infrastructure) exports the same symbols; the PRODUCT library knows the two kernel classes only as 'not built in'."""
+    leg = engine_mod.load_library(legacy=True)
+    for n in declared_functions():
+        assert hasattr(leg, n), n
+    out = subprocess.check_output(["nm", "-D", "--defined-only", engine_mod.LIB_PATH]).decode()
+    assert "k_rays_sweep" in out and "k_rays_quad" not in out and "k_rays_cell" not in out
+    out = subprocess.check_output(["nm", "-D", "--defined-only", engine_mod.LEGACY_LIB_PATH]).decode()
+    assert "k_rays_quad" in out and "k_rays_cell" in out
