@@ -132,11 +132,11 @@ def _sha16(path):
 
 # VALU instructions of k_rays_sweep's walk per ray outside the trips / per trip, by the form that ran (csrc/mcl_rays_sweep.h;
 # tools/roofline_inputs.py checks the trip against the shipped binary):
-#   fetched directions (TAB): 4 FMA + index add | table: add, mad, add                                      =  8 per ray
-#   turned directions (REC):  4 (integers) + 4 (turn) + index add | table: add, mad, add                    = 12 per ray
-#   two rays per lane (REC + PAIRS): 16 + index add | 2 add, 2 mad, add per PAIR                            = 11 per ray
-#   trip: 2 v_mad_u64_u32, address, v_min3_u32, v_sub_co_u32                                                =  5 per trip
-WALK_VALU = {"tab": (8, 5), "rec": (12, 5), "pairs": (11, 5)}
+#   fetched directions (TAB): 4 FMA + index add | table: add, mad, add                                          =  8   per ray
+#   turned directions (REC):  4 (integers) + 2 (three-term step) + 1/2 index add | table: add, mad, 1/2 add     =  9.5 per ray
+#   two rays per lane (REC + PAIRS): 8 + 4 + index add | 2 add, 2 mad, add per PAIR                              =  9   per ray
+#   trip: 2 v_mad_u64_u32, address, v_min3_u32, v_sub_co_u32                                                    =  5   per trip
+WALK_VALU = {"tab": (8.0, 5.0), "rec": (9.5, 5.0), "pairs": (9.0, 5.0)}
 
 
 def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_live=None, variant=None):

@@ -14,6 +14,10 @@ mkdir -p "$OUT" "$PROF"
 [ -x tools/ubench/valu_rates ] && [ tools/ubench/valu_rates -nt tools/ubench/valu_rates.hip ] || \
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rates.hip -o tools/ubench/valu_rates
 ./tools/ubench/valu_rates > "$PROF/${TAG}_valu_rates.txt"
+# the probe trip in its loop structure (issue cycles against the latency of the dependent chain; one ray per lane against two)
+[ -x tools/ubench/trip_rates ] && [ tools/ubench/trip_rates -nt tools/ubench/trip_rates.hip ] || \
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/ubench/trip_rates.hip -o tools/ubench/trip_rates
+./tools/ubench/trip_rates > "$PROF/${TAG}_trip_rates.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/prof" -o t -- python3 "$R/bench.py" --steps 10 --no-cpu-baseline --no-parity-check > "$R/$OUT/prof.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 6 --no-cpu-baseline --no-parity-check > "$R/$OUT/pmc_fetch.log" 2>&1
