@@ -508,6 +508,10 @@ def main():
             # who runs the collectives of an update: the engine itself (mcl_comm_*: RCCL on its own stream, one native call per
             # update: MCL_DIST_NATIVE=1) or dist.py through torch.distributed (the default)
             line["collectives"] = "engine (RCCL on the engine's stream)" if sf.native else f"torch.distributed ({args.backend})"
+            # the failure protocol's error word of the last timed update (ranks that failed: 0 = a good update on every rank; a
+            # non-zero word raises ShardedUpdateError on every rank, so a line that exists says 0) and the bound on a host wait
+            line["failure_protocol"] = {"failed_ranks_last_update": int(sf.last_failed_ranks),
+                                        "bounded_wait": "MCL_COMM_TIMEOUT_MS (30 s)" if sf.native else "process-group timeout"}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
         if checker_failed:

@@ -130,6 +130,7 @@ class ShardedFilter:
         # failure protocol: what this rank found wrong in the current update (None: nothing), the update count, the test switch
         self._err = None
         self._pending_err = None                                          # a failure while preparing the NEXT update's exchange
+        self.last_failed_ranks = 0                                        # the error word of the last update's SUM exchange (0: a good update)
         self.updates = 0
         self._fail_at = None
         spec = os.environ.get("MCL_DIST_FAIL")
@@ -212,6 +213,7 @@ class ShardedFilter:
     def _void(self, failed_ranks):
         """Every rank arrives here from the same update: forget what the exchange knew and raise."""
         err, self._err = self._err, None
+        self.last_failed_ranks = max(1, int(failed_ranks))
         self.pending_q = self.pending_list = None
         self.q_total = self.counts = self.totals = None
         self.last_sw = self.last_sww = None
@@ -430,6 +432,7 @@ class ShardedFilter:
         s = self.shard
         self._host_waits = 0
         self.updates += 1
+        self.last_failed_ranks = 0
         self._err, self._pending_err = self._pending_err, None            # (a failure while preparing this update's exchange is this update's)
         gs = None
         keep = False
