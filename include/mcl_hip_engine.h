@@ -69,16 +69,17 @@ typedef enum {
     MCL_RAYS_SKIP = 2,            /* same sample lattice, empty-space skipping on an LDS-resident
                                      distance-to-obstacle window; exactness guard falls back to MARCH  */
     MCL_RAYS_QUAD = 3,            /* SKIP with the work split by ray direction: one-byte-per-cell quadrant
-                                     windows, two workgroups per CU                                    */
+                                     windows, two workgroups per CU.  LEGACY: only in a library built with
+                                     -DMCL_LEGACY_RAY_KERNELS (the tests' libmcl_hip_engine_legacy.so); the product
+                                     library answers MCL_ERR_UNSUPPORTED                                */
     MCL_RAYS_CELL = 4,            /* QUAD on particles ordered by grid cell and heading, one particle per
-                                     lane: the lanes of a wave trace near-identical rays               */
-    MCL_RAYS_SWEEP = 5            /* CELL with work items planned on the device (runs of units x wedge groups, partial
-                                     sums kept by the owning lane instead of 16 atomics per particle), 256-cell
-                                     mirrored windows addressed by one v_perm_b32 and the probe / per-ray code
-                                     built around gfx950's 2-cycle and 4-cycle VALU classes; ranges up to 243 px.
-                                     (Longer ranges -- MAX_RANGE_PX up to 2047 -- run on MCL_RAYS_SKIP / MCL_RAYS_MARCH: the LDS
-                                     window of SKIP holds a particle's reach up to 281 px, beyond that its global-field path
-                                     traces every ray; same results, AUTO chooses.) */
+                                     lane: the lanes of a wave trace near-identical rays.  LEGACY, as QUAD */
+    MCL_RAYS_SWEEP = 5            /* cell-sorted particles, one particle per lane, work items planned on the device (runs of
+                                     units x direction wedges), 256-cell mirrored LDS windows, 64-bit fixed-point positions,
+                                     beam directions turned by the scan's increment (evenly spaced scans); ranges up to 243 px
+                                     in LDS windows, beyond that the same walk on mirrored copies of the wedge fields in global
+                                     memory (any range whose sixteen fields fit 2^32 bytes).  What AUTO runs from 65 536 particles
+                                     and 2^23 rays; below that MCL_RAYS_SKIP. */
 } mcl_ray_kernel;
 
 /* Upper bound (exclusive) on max_particles and on the particle total of a sharded set: weights are quantised to 2^-36 and

@@ -1,24 +1,27 @@
 // mcl_rays_sweep.h — K3e: k_rays_sweep, the default ray-cast + likelihood kernel from 65 536 particles (MCL_RAYS_SWEEP).
 //
-// Same algorithm and the same results as k_rays_cell (cell-sorted particles, one particle per lane, 16 wedge fields, fixed
-// point with a boundary guard, fix-up list, far flags; reference rows Q, C, E = cpp:524-650).  What is different, and why:
+// Cell-sorted particles, one particle per lane, 16 wedge fields, fixed point with a boundary guard, fix-up list, far flags;
+// reference rows Q, C, E = cpp:524-650.  What shapes the code (numbers: DESIGN.md 4.5 / 8, HISTORY.md round 5):
 //
-//   * gfx950 issues v_add/v_and/v_lshrrev/v_mov and the fp32 add/mul/fma every 2 cycles per wave64 but v_mad_*24,
-//     every three-operand integer op, v_min/v_max, shifts left, conversions, compares and all fp64 every 4
-//     (profiles/r02_op_rates.txt).  The probe trip and the per-ray code are built around that table:
-//       - positions are [cell:8][fraction:24] in a 256 x 256-cell window stored MIRRORED per quadrant (every ray of a
-//         wedge runs towards +x, +y): both direction components are unsigned 24-bit operands, the position advances by
-//         T += skip * X (no end point), and the LDS address of a cell is its two top bytes: one v_perm_b32;
-//       - the guard bias is folded into the window-relative origin, so the fraction test is two v_and (2 cycles each)
-//         and one v_min3;
-//       - the table is read as fp64 (no v_cvt_f64_f32), has 127 extra rows below "no hit" (no clamp of the samples
-//         left) and one all-zero row that undecided rays are pointed at (no select, no exec juggling);
-//       - the beam walk of the slots every live lane of the wave has is ONE asm block with its own vmcnt counting,
-//         induction variables advanced by per-lane increments (0 for a lane without rays) and undecided rays parked in
-//         two registers until the pass is over.
+//   * on gfx950 a wave64 VALU instruction occupies its SIMD for four cycles whatever its kind, and a wave's probe trip is a
+//     dependent chain (advance -> address -> LDS read -> wait -> borrow -> exec -> branch) of ~150 cycles that eight waves per SIMD
+//     only just cover.  So the walk counts instructions AND keeps its chain short:
+//       - positions are 64-bit per axis, cell in the high dword, a 32-bit fraction in the low one, in a 256 x 256-cell window
+//         stored MIRRORED per quadrant (every ray of a wedge runs towards +x, +y): both direction components are unsigned 32-bit
+//         operands, the position advances by T += skip * X with one v_mad_u64_u32 (no end point), the LDS address of a cell is
+//         row << 8 | column of the two high dwords (one v_lshl_or_b32);
+//       - the guard bias is folded into the origin, so the fraction test is one v_min3_u32 over the two low dwords, and the guard
+//         (2^-22 px) is narrow enough to be looked at once per walk, not per ray;
+//       - the beam direction is TURNED from beam to beam (an evenly spaced scan: MCL_SW_INTS_REC / MCL_SW_STEP_REC), not fetched;
+//       - the table is read as fp64 (no v_cvt_f64_f32), has 127 extra rows below "no hit" (no clamp of the samples left) and one
+//         all-zero row; the entry of a ray is requested when the ray ends and added when the next one has ended;
+//       - the beam walk of the slots every live lane of the wave has is ONE asm block with its own waitcnt counting, trips unrolled
+//         (not-taken exit branches), induction variables advanced by per-lane increments (0 for a lane without rays);
+//       - where the walk waits for memory rather than for the VALU (the global-field form, a spread cloud) a lane walks TWO rays
+//         at once (MCL_SW2_*).
 //   * A work item is (run of units, group of G wedges; G = 1 by default), planned on the device per update (k_sweep_plan).  The sum of
 //     a particle's rays in a wedge goes to its slot's accumulator with one fp64 atomic -- sixty-four lanes on 512 contiguous
-//     bytes of the sorted order, unlike k_rays_cell's atomics scattered by particle index.
+//     bytes of the sorted order.
 #pragma once
 
 namespace mcl {
@@ -26,7 +29,7 @@ namespace mcl {
 constexpr int kSwUnder = 127;            // table rows below "no hit": samples left in [-127, -1] after an over-long jump
 constexpr int kSwUnit = 1024;            // particles per scheduling unit: one pass of the 16 waves of a workgroup
 constexpr int kSwFx = 32;                // fractional bits of a position: the low dword of a 64-bit value, the cell index is the high dword
-constexpr int kSwSide = 256;             // window side = LDS row pitch: (cell y, cell x) -> address is one v_perm_b32
+constexpr int kSwSide = 256;             // window side = LDS row pitch: (cell y, cell x) -> address is row << 8 | column
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
 // fixed-point scale of a direction component: 2^32 - 3, so that |component| = 1 stays below 2^32 (the operand of v_mad_u64_u32
 // has 32 bits) with the + 1 of MCL_SW_ROTATE and its two roundings on top; the guard pays for it with 3 units (2^-32 px) per sample
