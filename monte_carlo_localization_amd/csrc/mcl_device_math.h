@@ -102,4 +102,20 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
     return v;
 }
 
+// Maximum of an int over the 64 lanes of the wave, wave-uniform, through the DPP cross-lane paths (quad permutes, row mirrors,
+// row broadcasts: VALU only).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip and a wait per step -- which is what a
+// reduction costs in a kernel whose waves are short of latency to hide (k_rays_sweep's per-chunk set-up made eighteen of them).
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    int x = v;
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));     // quad_perm [1, 0, 3, 2]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));     // quad_perm [2, 3, 0, 1]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));    // row_mirror: every lane of a row holds the row's maximum
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));    // row_bcast:15 into rows 1 and 3
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }      // (callers stay away from INT_MIN)
+
 }  // namespace mcl

@@ -857,14 +857,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // zero -- up to the common length: its rays there are walked and add 0.0.  beam_pad = beams of a full wedge (0: scan not
         // evenly spaced or too wide, no padding).
         const bool edge = a.beam_pad > 0 && (n1 + n2 > 0) && n2 == 0 && ((ja == 0) != (jb == a.B));
-        int tmax = total, tmin = (total > 0 && !edge) ? total : 0x7fffffff, temax = edge ? total : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            tmax = max(tmax, __shfl_xor(tmax, o, 64)); tmin = min(tmin, __shfl_xor(tmin, o, 64)); temax = max(temax, __shfl_xor(temax, o, 64));
-        }
-        tmax = __builtin_amdgcn_readfirstlane(tmax);
-        tmin = __builtin_amdgcn_readfirstlane(tmin);
-        temax = __builtin_amdgcn_readfirstlane(temax);
+        // (three wave-wide reductions without an LDS round trip: wave_max_i32)
+        int tmax = wave_max_i32(total), tmin = wave_min_i32((total > 0 && !edge) ? total : 0x7fffffff), temax = wave_max_i32(edge ? total : 0);
         if (temax > 0) {                      // the common length: the shortest full lane, or the longest edge lane if there is no full one
             int tstar = tmin != 0x7fffffff ? tmin : temax;
             tmin = tstar < a.beam_pad ? tstar : a.beam_pad;
