@@ -117,5 +117,35 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return __builtin_amdgcn_readlane(x, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }      // (callers stay away from INT_MIN)
+// Two maxima at once, the DPP operand folded into v_max_i32 (the builtin above costs a v_mov_dpp, the v_max and a copy per step):
+// twelve VALU instructions for both; the two chains alternate, which leaves one of the two wait states a DPP read needs after the
+// VALU write of its source to an s_nop.
+__device__ __forceinline__ void wave_max2_i32(int &a, int &b)
+{
+    int x = a, y = b;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x), "+v"(y));
+    a = __builtin_amdgcn_readlane(x, 63);
+    b = __builtin_amdgcn_readlane(y, 63);
+}
 
 }  // namespace mcl

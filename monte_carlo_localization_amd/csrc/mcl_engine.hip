@@ -472,6 +472,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
     a.beam_cs = h->d_beam_cs; a.beam_angle = h->d_angle; a.Lt = h->d_Lt;
     a.Ltr = h->d_Lt + (size_t)(h->P + 1) * h->bpad;
     a.beam_a0 = h->B > 0 ? (double)h->angles[0] : 0.0;
+    a.beam_alast = h->B > 0 ? (double)h->angles[h->B - 1] : 0.0;
     {
         const double span = h->B > 1 ? (double)h->angles[h->B - 1] - (double)h->angles[0] : 0.0;
         a.beam_inv_inc = span > 0.0 ? (double)(h->B - 1) / span : 0.0;
@@ -664,10 +665,11 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
                 hipLaunchKernelGGL(mcl::k_unit_table, dim3(1), dim3(1024), 0, h->stream, h->d_bbox, n, h->d_hist, h->d_histpart, h->d_tile_used,
                                    radix ? h->d_cut_start : (uint32_t *)nullptr, h->d_cut_end, h->d_unit_begin, h->d_nunits, (int)mu);
             }
-            if (!radix) hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
+            if (!radix && !sweep) hipLaunchKernelGGL(mcl::k_hist_clear, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_tile_used);
             if (sweep) {
+                // (... and, after a counting sort, the histogram's used tiles back to zero: k_hist_clear's work)
                 hipLaunchKernelGGL(mcl::k_unit_sums, dim3((unsigned)std::min<int64_t>(max_sweep_units(n), (n + mcl::kSwUnit - 1) / mcl::kSwUnit + 256)), dim3(256), 0, h->stream, h->d_pcs, h->d_unit_begin, h->d_nunits,
-                                   h->d_unit_sums);
+                                   h->d_unit_sums, radix ? (uint32_t *)nullptr : h->d_hist, h->d_tile_used, nparts);
             } else {
                 if ((size_t)nsl > h->slice_mean_capacity) {
                     dfree(h->d_slice_mean);
@@ -1047,7 +1049,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_cell<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #endif
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_tiny_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_sweep_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_sweep_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));

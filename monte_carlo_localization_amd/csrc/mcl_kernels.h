@@ -696,6 +696,7 @@ struct RayArgs {
     double rec_k;                  //   2 cos(inc): the three-term recurrence of the turned direction (MCL_SW_STEP_REC)
     const float *beam_angle;       // float angles (MARCH path uses theta + (double)angle)
     double beam_a0, beam_inv_inc;  // first angle and beams per radian (k_rays_cell's guess of a wedge's first beam)
+    double beam_alast;             // last angle: (double)beam_angle[B - 1]
     const float *Lt;               // (P+1) x bpad
     const float *Ltr;              // the same with the rows reversed (row P - d)
     const double *Ltd;             // k_rays_sweep: fp64 table indexed by samples left + kSwUnder (mcl_rays_sweep.h), ltd_cols columns
@@ -769,6 +770,7 @@ constexpr int kRayWaves = kRayThreads / 64;
 // direction bin (wedge, unwrapped) of beam `angle` for heading th; the quadrant index is derived from it so that
 // every kernel classifies a ray the same way
 __device__ __forceinline__ int beam_wedge(double th, float angle) { return (int)floor((th + (double)angle) * (kWedges * 0.15915494309189533577)); }
+__device__ __forceinline__ int beam_wedge_d(double th, double angle) { return (int)floor((th + angle) * (kWedges * 0.15915494309189533577)); }   // angle = (double) of the float
 __device__ __forceinline__ int beam_turns(double th, float angle) { return beam_wedge(th, angle) >> kWedgeShift; }
 
 // quadrant ranges of one particle's beams (see above); a garbage heading gets one range in quadrant 0

@@ -150,10 +150,25 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
 // Per unit of the sorted order, over its finite positions: out[2u] = (sum of pixel x, sum of pixel y, count, -) and
 // out[2u + 1] = (min x, max x, min y, max y).  A work item centres its windows on the bounding box of its units; k_sweep_plan
 // joins neighbouring units into one item while their particles still fit one window.
+// (hist / tile_used / nparts, when given: k_hist_clear's work -- the used tiles of the counting sort's histogram back to zero for the
+//  next update -- done here, after k_unit_table has read the bucket offsets: one launch less in front of the ray kernel)
 __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ pcs, const uint32_t *__restrict__ ub, const int *__restrict__ m_ptr,
-                                                  double4 *__restrict__ out)
+                                                  double4 *__restrict__ out, uint32_t *__restrict__ hist, uint32_t *__restrict__ tile_used, int nparts)
 {
     __shared__ double sm[4][7];
+    if (hist) {
+        for (int t = (int)blockIdx.x; t < nparts; t += (int)gridDim.x) {
+            if (!tile_used[t]) continue;                       // (block-uniform)
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            for (int x = 0; x < kSortXcds; ++x) {
+                uint4 *p = reinterpret_cast<uint4 *>(hist + (size_t)x * kSortKeySpace + (size_t)t * kHistTile) + threadIdx.x * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[k] = z;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) tile_used[t] = 0u;
+        }
+    }
     // (the number of units is only known on the device: a fixed grid strides over them -- one block per POSSIBLE unit was 65 000
     //  empty blocks, 10 us of a 262 144-particle update)
     for (int u = (int)blockIdx.x; u < m_ptr[0]; u += (int)gridDim.x) {
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
 constexpr int kSwRunMax = MCL_SW_RUNMAX;
 static_assert(kSwRunMax == 16, "k_sweep_plan's bounding-box pyramid has four levels above the units");
 constexpr int kPlanBlocks = 256;                 // blocks of kSwRunMax units planned per pass of the workgroup
-constexpr int kPlanLds = (kPlanBlocks * kSwRunMax * 15 / 16) * (int)sizeof(float4);     // levels 1..4 of one pass: 61 440 bytes
+constexpr int kPlanLds = (kPlanBlocks * kSwRunMax + kPlanBlocks * kSwRunMax * 15 / 16) * (int)sizeof(float4);     // the unit boxes and levels 1..4 of one pass: 126 976 bytes
 __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, const int *__restrict__ m_ptr, int ngroups, int nwg, double half_play,
                                                     int4 *__restrict__ items, int4 *runs, int *__restrict__ nitems_out)
 {
@@ -205,12 +220,15 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
     // kernel tests every particle against its window exactly), built by all threads; then one thread per block of 16 units
     // halves its candidate runs until they fit, one pyramid node per test.
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
-    float4 *pyr = reinterpret_cast<float4 *>(plan_lds);          // level l (1..4) of this pass at pyr + lvl_off[l]
+    // (the unit boxes themselves too: the planning threads read them one after the other -- from global memory that was a chain of
+    //  sixteen dependent loads per thread and most of this kernel's 18 .. 29 us)
+    constexpr int U = kPlanBlocks * kSwRunMax;                   // units per pass
+    float4 *box0 = reinterpret_cast<float4 *>(plan_lds);         // boxes of the units of this pass
+    float4 *pyr = box0 + U;                                      // level l (1..4) of this pass at pyr + lvl_off[l]
     __shared__ int wave_tot[4];
     __shared__ int carry_sh;
     const int M = m_ptr[0];                   // units of this update's sorted order (k_unit_table)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int U = kPlanBlocks * kSwRunMax;                   // units per pass
     constexpr int off1 = 0, off2 = U / 2, off3 = off2 + U / 4, off4 = off3 + U / 8;
     const float hp = (float)half_play;
     if (threadIdx.x == 0) carry_sh = 0;
@@ -226,7 +244,9 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         const int ubase = b0 * kSwRunMax;
         // (only the blocks of this pass that hold units: a 262 144-particle set is 256 units of the 4096 a pass has room for)
         const int ucnt = min(U, ((M - ubase + kSwRunMax - 1) / kSwRunMax) * kSwRunMax);
-        for (int k = threadIdx.x; k < ucnt / 2; k += 1024) pyr[off1 + k] = join(unit_box(ubase + 2 * k), unit_box(ubase + 2 * k + 1));
+        for (int k = threadIdx.x; k < ucnt; k += 1024) box0[k] = unit_box(ubase + k);
+        __syncthreads();
+        for (int k = threadIdx.x; k < ucnt / 2; k += 1024) pyr[off1 + k] = join(box0[2 * k], box0[2 * k + 1]);
         __syncthreads();
         for (int k = threadIdx.x; k < ucnt / 4; k += 1024) pyr[off2 + k] = join(pyr[off1 + 2 * k], pyr[off1 + 2 * k + 1]);
         __syncthreads();
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         __syncthreads();
         // box of the aligned run of cc units (a power of two) that starts at unit index r of this pass
         auto run_box = [&](int r, int cc) -> float4 {
-            return cc == 1 ? unit_box(ubase + r) : cc == 2 ? pyr[off1 + (r >> 1)] : cc == 4 ? pyr[off2 + (r >> 2)] : cc == 8 ? pyr[off3 + (r >> 3)] : pyr[off4 + (r >> 4)];
+            return cc == 1 ? box0[r] : cc == 2 ? pyr[off1 + (r >> 1)] : cc == 4 ? pyr[off2 + (r >> 2)] : cc == 8 ? pyr[off3 + (r >> 3)] : pyr[off4 + (r >> 4)];
         };
         const int b = b0 + (int)threadIdx.x;
         const int u0 = b * kSwRunMax, r0 = (int)threadIdx.x * kSwRunMax;
@@ -788,7 +808,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         {
             const double th = a.ths[sl];
             if (th == th && fabs(th) < 1e6) {
-                const int w0 = beam_wedge(th, a.beam_angle[0]), wl = beam_wedge(th, a.beam_angle[a.B - 1]);
+                const int w0 = beam_wedge_d(th, a.beam_a0), wl = beam_wedge_d(th, a.beam_alast);      // (the scan's first and last angle as doubles: no loads)
                 const int m = w0 + ((kbin - w0) & (kWedges - 1));
                 if (m <= wl) {
                     ja = m == w0 ? 0 : first_beam_in_wedge<REC>(th, a.beam_angle, a.B, m, a.beam_a0, a.beam_inv_inc);
@@ -828,23 +848,27 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         const bool live = total > 0;
         // position in the mirrored frame (the rays of the wedge run towards +x, +y there)
         const double dpos = 2.5;
-        const double lpx = live ? (sxp ? wpx : (double)Sx - wpx) : dpos, lpy = live ? (syp ? wpy : (double)Sy - wpy) : dpos;
-        const double p0x = lpx + kMagic, p0y = lpy + kMagic;
-        const uint32_t lox = (uint32_t)__double2loint(p0x), loy = (uint32_t)__double2loint(p0y);
-        const int cx0 = (__double2hiint(p0x) & 0xFFFFF) - kCellBase, cy0 = (__double2hiint(p0y) & 0xFFFFF) - kCellBase;
+        // (x or S - x by one FMA with wave-uniform factors: the same single rounding as the subtraction)
+        const double lpx = live ? __builtin_fma(wpx, sxp ? 1.0 : -1.0, sxp ? 0.0 : (double)Sx) : dpos;
+        const double lpy = live ? __builtin_fma(wpy, syp ? 1.0 : -1.0, syp ? 0.0 : (double)Sy) : dpos;
+        // origin in the mirrored frame in 2^-32 px, biased by the guard (see MCL_SW_TRIP), rounded to nearest by the 2^52 magic add:
+        // fraction in the low dword, cell in the high one (GLOBAL: plus the field's byte offset in the column dword).  The cell
+        // and the guard test of the origin come from the same number: an origin within the guard of a cell boundary (where the
+        // biased cell may be the neighbour's) has a low dword below twice the guard like any such sample -- its walk goes to the
+        // fix-up list whatever it read.
+        const double m0x = __builtin_fma(lpx, 4294967296.0, (double)guard_units) + 4503599627370496.0;
+        const double m0y = __builtin_fma(lpy, 4294967296.0, (double)guard_units) + 4503599627370496.0;
+        const uint32_t lox = (uint32_t)__double2loint(m0x), loy = (uint32_t)__double2loint(m0y);
+        const uint32_t cx0 = (uint32_t)__double2hiint(m0x) & 0xFFFFFu, cy0 = (uint32_t)__double2hiint(m0y) & 0xFFFFFu;
         int d0;
-        if (GLOBAL) d0 = (int)a.distg[(size_t)foff + (size_t)(uint32_t)cy0 * gpitch + (uint32_t)cx0];      // the own cell (a dead lane: cell (2, 2) of the ringed field)
+        if (GLOBAL) d0 = (int)a.distg[(size_t)foff + (size_t)cy0 * gpitch + cx0];      // the own cell (a dead lane: cell (2, 2) of the ringed field)
         else d0 = ldsb[((cy0 & (kSwSide - 1)) << 8) | (cx0 & (kSwSide - 1))];
         const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
         // no stop within range: look at sample P only (it is free: the skip says so), which ends the walk with "no hit"
         const uint32_t s0e = (uint32_t)(s0 <= a.P ? s0 : a.P);
-        const uint32_t g0 = ((lox < loy ? lox : loy) < kGuard) ? 0u : 0xFFFFFFFFu;
-        // origin in the mirrored frame in 2^-32 px, biased by the guard (see MCL_SW_TRIP), rounded to nearest by the 2^52 magic add:
-        // fraction in the low dword, cell in the high one (GLOBAL: plus the field's byte offset in the column dword)
-        const double m0x = __builtin_fma(lpx, 4294967296.0, (double)guard_units) + 4503599627370496.0;
-        const double m0y = __builtin_fma(lpy, 4294967296.0, (double)guard_units) + 4503599627370496.0;
-        const unsigned long long P0x = ((unsigned long long)(((uint32_t)__double2hiint(m0x) & 0xFFFFFu) + foff) << 32) | (uint32_t)__double2loint(m0x);
-        const unsigned long long P0y = ((unsigned long long)((uint32_t)__double2hiint(m0y) & 0xFFFFFu) << 32) | (uint32_t)__double2loint(m0y);
+        const uint32_t g0 = lox < loy ? lox : loy;
+        const unsigned long long P0x = ((unsigned long long)(cx0 + foff) << 32) | lox;
+        const unsigned long long P0y = ((unsigned long long)cy0 << 32) | loy;
         const int rem_start = live ? a.P - (int)s0e : 0;
         // direction components in the mirrored frame: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
         const double dsc = sxp ? kSwDirScale : -kSwDirScale;
@@ -857,15 +881,19 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         // zero -- up to the common length: its rays there are walked and add 0.0.  beam_pad = beams of a full wedge (0: scan not
         // evenly spaced or too wide, no padding).
         const bool edge = a.beam_pad > 0 && (n1 + n2 > 0) && n2 == 0 && ((ja == 0) != (jb == a.B));
-        // (three wave-wide reductions without an LDS round trip: wave_max_i32)
-        int tmax = wave_max_i32(total), tmin = wave_min_i32((total > 0 && !edge) ? total : 0x7fffffff), temax = wave_max_i32(edge ? total : 0);
-        if (temax > 0) {                      // the common length: the shortest full lane, or the longest edge lane if there is no full one
-            int tstar = tmin != 0x7fffffff ? tmin : temax;
+        // (wave-wide reductions without an LDS round trip: the longest lane and the shortest full one together, the longest
+        //  scan-edge lane only in the chunks that have one)
+        int tmax = total, tmin = (total > 0 && !edge) ? -total : -0x7fffffff;
+        wave_max2_i32(tmax, tmin);
+        tmin = -tmin;
+        if (__ballot(edge) != 0ull) {         // the common length: the shortest full lane, or the longest edge lane if there is no full one
+            const int temax = wave_max_i32(edge ? total : 0);
+            const int tstar = tmin != 0x7fffffff ? tmin : temax;
             tmin = tstar < a.beam_pad ? tstar : a.beam_pad;
         }
         const bool padded = edge && total < tmin;
         // a second range only exists for scans wider than three quadrants; the common case steps j by one
-        const bool wraps = __builtin_amdgcn_readfirstlane((int)(__ballot(n2 > 0 && n1 > 0) != 0ull)) != 0;
+        const bool wraps = __ballot(n2 > 0 && n1 > 0) != 0ull;
         const int jfirst = n1 > 0 ? ja : (n2 > 0 ? ja2 : 0);
         const int jwalk = padded && ja == 0 ? jb - tmin : jfirst;       // first (possibly virtual) beam of the lock-step walk
         double acc_fast = 0.0, acc = 0.0;
