@@ -710,12 +710,12 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // offsets from the grid sit in LDS behind the window: 8 bytes per table column)
         // (... as long as two workgroups still fit a CU's 160 KB: up to ~1800 table columns; more beams than that fetch their directions)
         const bool sweep_rec = sweep && h->rec_ok && h->sweep_rec_layout_ok && h->d_beam_err != nullptr &&
-                               (size_t)mcl::kSwSide * mcl::kSwSide + (size_t)h->ltd_cols * 8 <= 80 * 1024 - 64;
+                               (size_t)mcl::kSwWinBytes + (size_t)h->ltd_cols * 8 <= 80 * 1024 - 64;
         // PAIRS (two rays per lane) where the walk waits for memory: always in the global-field form; in LDS windows for a set
         // that was set / initialised since the last update (the spread cloud of a re-localisation: -11 % on its first update, where
         // the tracking cloud gains nothing and the levine stand-in loses 2 %); MCL_SWEEP_PAIRS=0 / 1 overrides
         const bool sweep_pairs = sweep_rec && (h->env_sweep_pairs >= 0 ? h->env_sweep_pairs != 0 : (sweep_glob || a.far_windowed != 0));
-        size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwSide * mcl::kSwSide) + (sweep_rec ? (size_t)h->ltd_cols * 8 : 0) : (size_t)h->qside * h->qside;
+        size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwWinBytes) + (sweep_rec ? (size_t)h->ltd_cols * 8 : 0) : (size_t)h->qside * h->qside;
         h->last_sweep_global = sweep_glob ? 1 : 0; h->last_sweep_rec = sweep_rec ? 1 : 0; h->last_sweep_pairs = (sweep_rec && (sweep_glob || sweep_pairs)) ? 1 : 0;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;

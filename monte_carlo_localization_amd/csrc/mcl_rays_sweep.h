@@ -29,7 +29,19 @@ namespace mcl {
 constexpr int kSwUnder = 127;            // table rows below "no hit": samples left in [-127, -1] after an over-long jump
 constexpr int kSwUnit = 1024;            // particles per scheduling unit: one pass of the 16 waves of a workgroup
 constexpr int kSwFx = 32;                // fractional bits of a position: the low dword of a 64-bit value, the cell index is the high dword
-constexpr int kSwSide = 256;             // window side = LDS row pitch: (cell y, cell x) -> address is row << 8 | column
+constexpr int kSwSide = 256;             // window side in cells
+// LDS row pitch of the window in bytes: (cell y, cell x) -> y * kSwPitch + x.  With 256 every row starts in the same LDS bank, and
+// the lanes of a wave sample along a ray -- a line that crosses rows: SQ_LDS_BANK_CONFLICT was a quarter of the LDS unit's busy
+// cycles.  Rounds 2-4 had no one-instruction address with another pitch (the row was a bit field of a fixed-point word); with the
+// cell in the high dword of a 64-bit position it is v_mad_u32_u24 row, pitch, column -- any pitch.
+// Ray kernel ms at 4M x 1081 with pitch 256 / 260 / 264 / 272: Spielberg 4.31 / 4.27 / 4.29 / 4.28, the levine stand-in (corridors: rays
+// along the axes) 5.72 / 5.02 / 5.03 / - (profiles/r05_experiments/window_pitch.txt); 288 no longer fits two workgroups per CU.
+#ifndef MCL_SW_PITCH
+#define MCL_SW_PITCH 260
+#endif
+constexpr int kSwPitch = MCL_SW_PITCH;
+static_assert(kSwPitch >= kSwSide && (kSwPitch % 4) == 0, "window rows are written as dwords");
+constexpr int kSwWinBytes = kSwSide * kSwPitch;  // the window in LDS
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
 // fixed-point scale of a direction component: 2^32 - 3, so that |component| = 1 stays below 2^32 (the operand of v_mad_u64_u32
 // has 32 bits) with the + 1 of MCL_SW_ROTATE and its two roundings on top; the guard pays for it with 3 units (2^-32 px) per sample
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
 #define MCL_SW_TRIP(REM, GIN, BYIN, TXIN, TYIN, TX, TY, TXLO, TXHI, TYLO, TYHI, AD, BY, GOUT, REMOUT, XX, XY, LB) \
     "v_mad_u64_u32 " TX ", vcc, " BYIN ", " XX ", " TXIN "\n\t"                                           \
     "v_mad_u64_u32 " TY ", vcc, " BYIN ", " XY ", " TYIN "\n\t"                                           \
-    "v_lshl_or_b32 " AD ", " TYHI ", 8, " TXHI "\n\t"                                                     \
+    "v_mad_u32_u24 " AD ", " TYHI ", %[wp], " TXHI "\n\t"                                                 \
     "ds_read_i8 " BY ", " AD " offset:" LB "\n\t"                                                         \
     "v_min3_u32 " GOUT ", " GIN ", " TXLO ", " TYLO "\n\t"                                                \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                            \
@@ -421,21 +433,22 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 3b\n\t"                                                                                                \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]"
-// (REC: two beams per turn of the loop: the first beam's tail leaves the loop when it was the walk's last; the table columns of
-//  the two are 8 bytes apart, the column offset moves once per turn)
-#define MCL_SW_TAIL_A                                                                                                          \
+// (REC: four beams per turn of the loop -- the table columns of the four are 8 bytes apart, immediate offsets: the column offset
+//  and the pointer to the beams' offsets move once per turn, a quarter of a VALU instruction per ray each --; a beam's tail leaves
+//  the loop when it was the walk's last)
+#define MCL_SW_TAIL_R(OFF)                                                                                                     \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
         "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
-        "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t"                                                                        \
+        "global_load_dwordx2 v[50:51], v48, %[ltb] offset:" OFF "\n\t"                                                         \
         "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
         "s_cbranch_scc1 5f\n\t"
-#define MCL_SW_TAIL_B                                                                                                          \
+#define MCL_SW_TAIL_R_LAST(OFF)                                                                                                \
         "s_waitcnt vmcnt(0)\n\t"                                                                                               \
         "v_add_f64 %[acc], %[acc], v[50:51]\n\t"                                                                               \
         "v_mad_i32_i24 v48, v57, %[st8], %[j8b]\n\t"                                                                           \
         "v_add_u32 %[j8b], %[j8b], %[ince]\n\t"                                                                                \
-        "global_load_dwordx2 v[50:51], v48, %[ltb] offset:8\n\t"                                                               \
+        "global_load_dwordx2 v[50:51], v48, %[ltb] offset:" OFF "\n\t"                                                         \
         "s_sub_u32 %[tc], %[tc], 1\n\t"                                                                                        \
         "s_cbranch_scc0 3b\n"                                                                                                  \
         "5:\n\t"                                                                                                               \
@@ -456,31 +469,40 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                               \
         : [aq] "v"(aq), [bq] "v"(bq), [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                     \
           [inc16] "v"(inc16), [inc8] "v"(inc8), [csb] "s"(a.beam_csx), [ltb] "s"(a.Ltd), [st8] "s"(st8),                        \
-          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch)                                              \
         : MCL_SW_CLOBBERS)
 
 #define MCL_SW_WALK_REC(NEGX, NEGY)                                                                                            \
     asm volatile(                                                                                                              \
-        "ds_read2_b64 v[40:43], %[je] offset1:1\n\t" /* offsets of the first two beams; the next two are read a turn ahead */  \
+        "ds_read2_b64 v[40:43], %[je] offset1:1\n\t" /* offsets of the first two beams; the next two are read two beams ahead */ \
         "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
         "global_load_dwordx2 v[50:51], v48, %[ltb]\n\t" /* 0.0 */                                                              \
         "3:\n\t"                                                                                                               \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
         MCL_SW_INTS_REC(NEGX, NEGY, "v[40:41]", "%[xa]", "%[ya]")                                                              \
         MCL_SW_TRIPS_LDS                                                                                                       \
-        MCL_SW_TAIL_A                                                                                                          \
+        MCL_SW_TAIL_R("0")                                                                                                     \
+        MCL_SW_STEP_REC("%[xa]", "%[ya]", "%[xb]", "%[yb]")                                                                    \
+        MCL_SW_INTS_REC(NEGX, NEGY, "v[42:43]", "%[xb]", "%[yb]")                                                              \
+        "ds_read2_b64 v[40:43], %[je] offset0:2 offset1:3\n\t" /* (landed by the first trip's wait) */                         \
+        MCL_SW_TRIPS_LDS                                                                                                       \
+        MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
+        MCL_SW_TAIL_R("8")                                                                                                     \
+        MCL_SW_INTS_REC(NEGX, NEGY, "v[40:41]", "%[xa]", "%[ya]")                                                              \
+        MCL_SW_TRIPS_LDS                                                                                                       \
+        MCL_SW_TAIL_R("16")                                                                                                    \
         MCL_SW_STEP_REC("%[xa]", "%[ya]", "%[xb]", "%[yb]")                                                                    \
         MCL_SW_INTS_REC(NEGX, NEGY, "v[42:43]", "%[xb]", "%[yb]")                                                              \
         "v_add_u32 %[je], %[je], %[ince]\n\t"                                                                                  \
         "ds_read2_b64 v[40:43], %[je] offset1:1\n\t"                                                                           \
         MCL_SW_TRIPS_LDS                                                                                                       \
         MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
-        MCL_SW_TAIL_B                                                                                                          \
+        MCL_SW_TAIL_R_LAST("24")                                                                                               \
         : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xa] "+v"(xa), [ya] "+v"(ya), [xb] "+v"(xb),   \
           [yb] "+v"(yb), [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                \
         : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
-          [ince] "v"(inc16), [rk] "s"(a.rec_k), [ltb] "s"(a.Ltd), [st8] "s"(st8),                                               \
-          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase)                                              \
+          [ince] "v"(inc32), [rk] "s"(a.rec_k), [ltb] "s"(a.Ltd), [st8] "s"(st8),                                               \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch)                                              \
         : MCL_SW_CLOBBERS)
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
@@ -582,8 +604,8 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_andn2_b64 exec, exec, vcc\n\t"                                                                                      \
         "s_or_b64 %[st], exec, %[mb]\n\t"                                                                                      \
         "s_cbranch_scc0 2f\n\t"
-#define MCL_SW2_READ_A_LDS "v_lshl_or_b32 v47, v57, 8, v55\n\t" "ds_read_i8 v47, v47 offset:%[lb]\n\t"
-#define MCL_SW2_READ_B_LDS "v_lshl_or_b32 v49, v61, 8, v59\n\t" "ds_read_i8 v49, v49 offset:%[lb]\n\t"
+#define MCL_SW2_READ_A_LDS "v_mad_u32_u24 v47, v57, %[wp], v55\n\t" "ds_read_i8 v47, v47 offset:%[lb]\n\t"
+#define MCL_SW2_READ_B_LDS "v_mad_u32_u24 v49, v61, %[wp], v59\n\t" "ds_read_i8 v49, v49 offset:%[lb]\n\t"
 #define MCL_SW2_READ_A_GLB "v_mad_u32_u24 v47, v57, %[pitch], v55\n\t" "global_load_sbyte v47, v47, %[gbase]\n\t"
 #define MCL_SW2_READ_B_GLB "v_mad_u32_u24 v49, v61, %[pitch], v59\n\t" "global_load_sbyte v49, v49, %[gbase]\n\t"
 // (an odd number of slots: the walk's last pair has no ray B -- its mask starts empty and its table row is the all-zero one)
@@ -645,7 +667,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         MCL_SW2_TRIPS("s_movk_i32 %[cd], 75\n\t", MCL_SW2_READ_A_LDS, MCL_SW2_READ_B_LDS, "s_waitcnt lgkmcnt(0)\n\t")           \
         MCL_SW2_EPILOGUE                                                                                                       \
         : MCL_SW2_OUTPUTS                                                                                                      \
-        : MCL_SW2_INPUTS, [lb] "n"(kQLdsBase)                                                                                  \
+        : MCL_SW2_INPUTS, [lb] "n"(kQLdsBase), [wp] "s"(wpitch)                                                                                  \
         : MCL_SW2_CLOBBERS)
 
 #define MCL_SWG2_WALK(NEGX, NEGY)                                                                                              \
@@ -693,13 +715,14 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     const uint32_t cdinit = (uint32_t)a.P + 64u;               // GLOBAL: trip countdown of the per-slot loop (a walk makes at most P trips)
     const uint32_t cdinit4 = cdinit / 4u + 1u;                 // ... and of the asm walk's loop, four trips per turn
     const uint32_t st8 = (uint32_t)__builtin_amdgcn_readfirstlane(a.ltd_cols * 8);
+    [[maybe_unused]] const uint32_t wpitch = (uint32_t)kSwPitch;      // the window's row pitch as a scalar operand of the probe trip's address
     const uint32_t zrow = (uint32_t)(a.P + 1);                 // "samples left" that selects the all-zero row
     const unsigned char *ldsb = lds_raw;
     // REC: every beam's offset from the scan's angular grid (RayArgs::beam_err, 8 bytes per table column), behind the window; the
     // walk reads it from the raw LDS offset `ebase` (published by the first barrier of the item loop, like fixn_sh)
-    constexpr uint32_t ebase = (uint32_t)kQLdsBase + (GLOBAL ? 0u : (uint32_t)(kSwSide * kSwSide));
+    constexpr uint32_t ebase = (uint32_t)kQLdsBase + (GLOBAL ? 0u : (uint32_t)kSwWinBytes);
     if (REC) {
-        double *etab = reinterpret_cast<double *>(lds_raw + (GLOBAL ? 0 : kSwSide * kSwSide));
+        double *etab = reinterpret_cast<double *>(lds_raw + (GLOBAL ? 0 : kSwWinBytes));
         for (int c = threadIdx.x; c < a.ltd_cols; c += kRayThreads) etab[c] = a.beam_err[c];
     }
     if (threadIdx.x == 0) fixn_sh = 0u;                        // published by the first barrier of the item loop
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         const int cxm = ctr.x, cym = ctr.y;
         wx0 = sxp ? cxm - back : cxm + back - S;
         wy0 = syp ? cym - back : cym + back - S;
-        uint64_t *win = reinterpret_cast<uint64_t *>(lds_raw);
+        uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw);             // rows kSwPitch bytes apart, written as dword pairs
         const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
         constexpr int wpr = S >> 3, nwords = wpr * S;
         unsigned long long dbg_w0 = 0;
@@ -771,7 +794,9 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         if (gx + k >= 0 && gx + k < a.Wp) b8 = (b8 & ~(0xFFull << (8 * k))) | ((uint64_t)rowp[gx + k] << (8 * k));
                 }
             }
-            win[wi] = sxp ? b8 : __builtin_bswap64(b8);
+            const uint64_t w8 = sxp ? b8 : __builtin_bswap64(b8);
+            uint32_t *wp = win + row * (kSwPitch / 4) + cw * 2;
+            wp[0] = (uint32_t)w8; wp[1] = (uint32_t)(w8 >> 32);
         }
         if (threadIdx.x == 0) chunk_sh = 0u;
         __syncthreads();
@@ -862,7 +887,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         const uint32_t cx0 = (uint32_t)__double2hiint(m0x) & 0xFFFFFu, cy0 = (uint32_t)__double2hiint(m0y) & 0xFFFFFu;
         int d0;
         if (GLOBAL) d0 = (int)a.distg[(size_t)foff + (size_t)cy0 * gpitch + cx0];      // the own cell (a dead lane: cell (2, 2) of the ringed field)
-        else d0 = ldsb[((cy0 & (kSwSide - 1)) << 8) | (cx0 & (kSwSide - 1))];
+        else d0 = ldsb[(cy0 & (kSwSide - 1)) * (uint32_t)kSwPitch + (cx0 & (kSwSide - 1))];
         const int s0 = (d0 > 127 || d0 < 1) ? 1 : d0;               // own cell is a stop: first sample one step away
         // no stop within range: look at sample P only (it is free: the skip says so), which ends the walk with "no hit"
         const uint32_t s0e = (uint32_t)(s0 <= a.P ? s0 : a.P);
@@ -914,6 +939,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             // table column offset, biased by kSwUnder rows so that (samples left) * row bytes + j8b is never negative
             uint32_t j8b = (uint32_t)kSwUnder * st8 + ((uint32_t)((live ? jw : a.B) + a.beam_margin) << 3);
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
+            const uint32_t inc32 = live ? 32u : 0u;                   // (REC: bytes of table columns / beam offsets per turn of the walk's loop)
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
             const uint32_t zoff = (zrow + (uint32_t)kSwUnder) * st8;      // any column of the zero row
             if constexpr (REC) {
@@ -1007,7 +1033,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         "s_mov_b64 exec, %[sv]"
                         : [g] "=&v"(g), [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
                         : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
-                          [lb] "n"(kQLdsBase)
+                          [lb] "n"(kQLdsBase), [wp] "s"(wpitch)
                         : "memory", "vcc", "scc", "v48", "v49", "v52", "v53", "v54", "v55");
                     // the countdown only expires if the window is malformed (impossible): every ray of the pass to the fix-up list
                     expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
@@ -1024,7 +1050,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         const uint32_t gm = (uint32_t)Tx < (uint32_t)Ty ? (uint32_t)Tx : (uint32_t)Ty;
                         g = g < gm ? g : gm;
                         if (GLOBAL) by = (uint32_t)(int)(int8_t)a.distg[(size_t)(uint32_t)((uint32_t)(Ty >> 32) * gpitch + (uint32_t)(Tx >> 32))];
-                        else by = (uint32_t)(int)(int8_t)ldsb[(((uint32_t)(Ty >> 32) & (kSwSide - 1)) << 8) | ((uint32_t)(Tx >> 32) & (kSwSide - 1))];
+                        else by = (uint32_t)(int)(int8_t)ldsb[((uint32_t)(Ty >> 32) & (kSwSide - 1)) * (uint32_t)kSwPitch + ((uint32_t)(Tx >> 32) & (kSwSide - 1))];
                         uint32_t nr;
                         const bool over = __builtin_usub_overflow((uint32_t)rem, by, &nr);
                         go = !over;
