@@ -211,7 +211,8 @@ int mcl_get_ray_kernel_ms(const mcl_engine_t *h, double *ms);
 /* which ray kernel the last update ran: 1 k_rays_march, 2 k_rays_skip, 3 k_rays_quad, 4 k_rays_cell, 5 k_rays_sweep */
 int mcl_get_ray_kernel_id(const mcl_engine_t *h, int32_t *kernel);
 /* The form of the windowed ray kernel the last ray stage ran (k_rays_sweep, csrc/mcl_rays_sweep.h): out = [1 if it probed the wedge
- * fields in global memory (ranges beyond 243 px), 1 if it turned the beam direction by the scan's increment instead of fetching it
+ * fields in global memory (ranges beyond 243 px), 2 if it walked in LDS windows and went on in those fields where a ray left its
+ * window (the hybrid form of such ranges: evenly spaced scans), 1 if it turned the beam direction by the scan's increment instead of fetching it
  * (evenly spaced scans), 1 if it walked two rays per lane].  A performance diagnostic (bench.py prices the instruction stream of the
  * form that ran); results do not depend on it. */
 int mcl_get_ray_kernel_variant(const mcl_engine_t *h, int32_t out[3]);

@@ -359,15 +359,31 @@ void unpack_result(mcl_engine *h)
 // upper bound on the units of n sorted particles: the plain grid plus one cut per bucket of a sparse set (mcl::k_unit_table)
 // cells the particles of one k_rays_sweep work item may spread over (per axis): what the 256-cell LDS window leaves beside a
 // ray's reach, or -- on the global wedge fields -- the span of the cell field minus the reach on both sides
-int sweep_play(const mcl_engine *h)
+// The hybrid form of k_rays_sweep (ranges beyond the LDS window: the walk leaves the window into the global wedge fields where a
+// ray is that long): for evenly spaced scans (the turned-direction walk), when both sets of fields exist.  MCL_SWEEP_HYBRID=0:
+// the global-field form alone, as in round 4.
+bool sweep_hybrid(const mcl_engine *h)
 {
+    return h->sweep_global && h->env_sweep_hybrid != 0 && h->rec_ok && h->sweep_hyb_layout_ok && h->d_beam_err != nullptr &&
+           h->d_distw != nullptr && h->d_distg != nullptr && (size_t)mcl::kSwWinBytes + (size_t)h->ltd_cols * 8 <= 80 * 1024 - 64;
+}
+
+// (... of THIS update: a set that was just initialised, or whose last update left many particles to the far pass -- the spread
+//  cloud of a re-localisation --, takes the global-field form: every lane has its own origin there, where the hybrid's windows
+//  would hand a good part of such a cloud to the far pass.  fine025 stand-in, 4M uniform: first update 39 ms against 64.)
+bool sweep_far_expected(const mcl_engine *h) { return h->far_fresh || h->h_result[15] >= mcl::kFarWindowedMin / 2; }
+bool sweep_hybrid_now(const mcl_engine *h) { return sweep_hybrid(h) && (h->env_sweep_hybrid == 2 || !sweep_far_expected(h)); }     // (MCL_SWEEP_HYBRID=2: always, the tests' setting)
+
+int sweep_play(const mcl_engine *h, bool hybrid)
+{
+    if (hybrid) return mcl::kSwSide - (mcl::kSwHybReach + 2) - 3;
     if (h->sweep_global) return 1 << 20;             // every lane has its own origin there: no window a run could outgrow
     return mcl::kSwSide - (h->P + 2) - 3;
 }
 
 int64_t max_sweep_units(int64_t n) { return (n + mcl::kSwUnit - 1) / mcl::kSwUnit + mcl::kSwMaxCuts + 2; }
 
-int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
+int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g, bool hybrid)
 {
     const int ngroups = mcl::kWedges / g;
     const size_t need = (size_t)max_sweep_units(n) * ngroups;
@@ -379,7 +395,7 @@ int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g)
         h->items_capacity = need;
     }
     if (!h->d_nitems) HIPCHK(h, hipMalloc(&h->d_nitems, sizeof(int)));
-    const int play = sweep_play(h);                                     // cells a window leaves for the particles of an item
+    const int play = sweep_play(h, hybrid);                             // cells a window leaves for the particles of an item
     // (EV_K0 = the stop event of the kernel before the ray kernel, EV_K1 = the ray kernel's own: its duration, dispatch included, at no cost)
     hipExtLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), mcl::kPlanLds, h->stream, nullptr, h->ev[EV_K0], 0, h->d_unit_sums, h->d_nunits, ngroups, nwg,
                           (double)(play / 2 - 1), h->d_items, h->d_centres, h->d_nitems);
@@ -433,7 +449,8 @@ int choose_ray_mode(const mcl_engine *h, int64_t n, bool force_skip, const char 
     const int64_t cell_min = h->env_cell_min > 0 ? h->env_cell_min : 65536;
     const bool big = n >= cell_min && n * (int64_t)h->B >= (8 << 20);
     if (big && sweep_ok) {
-        w = h->sweep_global ? "AUTO: at least 65536 particles and 2^23 rays, monotone beams; MAX_RANGE_PX > 243 (or MCL_SWEEP_GLOBAL): k_rays_sweep probes the wedge fields in global memory"
+        w = sweep_hybrid(h) ? "AUTO: at least 65536 particles and 2^23 rays, evenly spaced beams; MAX_RANGE_PX > 243 (or MCL_SWEEP_GLOBAL): k_rays_sweep walks in LDS windows and goes on in the wedge fields in global memory where a ray leaves its window"
+          : h->sweep_global ? "AUTO: at least 65536 particles and 2^23 rays, monotone beams; MAX_RANGE_PX > 243 (or MCL_SWEEP_GLOBAL): k_rays_sweep probes the wedge fields in global memory"
                             : "AUTO: at least 65536 particles and 2^23 rays, monotone beams, MAX_RANGE_PX <= 243";
         return 5;
     }
@@ -529,6 +546,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int spc = h->env_qslices_per_cu > 0 ? h->env_qslices_per_cu : 32;
         int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
         int sweep_g = 1;
+        bool sweep_hyb_now = false;                            // k_rays_sweep's hybrid form for THIS update (set with the far-pass decision)
         if (cell) {
             // k_rays_cell: a slice is a run of the sorted order; 2048 particles = two 64-particle groups per wave.  Longer
             // slices amortise the window load better, shorter ones balance the persistent workgroups better
@@ -585,7 +603,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const bool stale_layout = cell && h->layout_stale_used;      // d_bbox / d_tilemap hold the layout to order by: not remade
             if (cell && !stale_layout) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
             // the window play k_sweep_plan works with (0: no windowed kernel; -1: no cuts at all, MCL_NO_BUCKET_CUTS)
-            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? sweep_play(h) : 0);
+            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? sweep_play(h, sweep_hybrid_now(h)) : 0);
             if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
                 clr.logw_acc = nullptr; clr.far_flags = nullptr;
                 // ... and, from the second update of a configuration on, the few words that are not per particle as well
@@ -684,7 +702,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (sweep) {
             if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not allocated (internal)");
             if (!h->ltd_ready) build_ltd(h);          // a caller whose table decision was made for another particle count
-            const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g);
+            const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g, sweep_hybrid_now(h));
             if (rc_plan) return rc_plan;
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
@@ -701,11 +719,13 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             // there is reason to expect work for it: the previous ray stage flagged a fair number of slots, or the particle set
             // is fresh (set / initialised since).  A misjudgement costs time, never results: without it k_rays_far takes all.
             a.far_sorted = h->d_far_sorted;
-            a.far_windowed = (h->far_fresh || h->h_result[15] >= mcl::kFarWindowedMin / 2) ? 1 : 0;
+            sweep_hyb_now = sweep_hybrid_now(h);                 // (before far_fresh is taken down)
+            a.far_windowed = sweep_far_expected(h) ? 1 : 0;
             h->far_fresh = false;
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
         }
-        const bool sweep_glob = sweep && h->sweep_global;       // probes in global memory: no window in LDS
+        const bool sweep_hyb = sweep && sweep_hyb_now;          // LDS windows as far as they reach, the global fields beyond
+        const bool sweep_glob = sweep && h->sweep_global && !sweep_hyb;       // probes in global memory: no window in LDS
         // REC: the walk turns the beam direction by the scan's increment instead of fetching it (evenly spaced scans; the beams'
         // offsets from the grid sit in LDS behind the window: 8 bytes per table column)
         // (... as long as two workgroups still fit a CU's 160 KB: up to ~1800 table columns; more beams than that fetch their directions)
@@ -714,9 +734,9 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         // PAIRS (two rays per lane) where the walk waits for memory: always in the global-field form; in LDS windows for a set
         // that was set / initialised since the last update (the spread cloud of a re-localisation: -11 % on its first update, where
         // the tracking cloud gains nothing and the levine stand-in loses 2 %); MCL_SWEEP_PAIRS=0 / 1 overrides
-        const bool sweep_pairs = sweep_rec && (h->env_sweep_pairs >= 0 ? h->env_sweep_pairs != 0 : (sweep_glob || a.far_windowed != 0));
+        const bool sweep_pairs = sweep_rec && !sweep_hyb && (h->env_sweep_pairs >= 0 ? h->env_sweep_pairs != 0 : (sweep_glob || a.far_windowed != 0));
         size_t qlds = sweep ? (sweep_glob ? 0 : (size_t)mcl::kSwWinBytes) + (sweep_rec ? (size_t)h->ltd_cols * 8 : 0) : (size_t)h->qside * h->qside;
-        h->last_sweep_global = sweep_glob ? 1 : 0; h->last_sweep_rec = sweep_rec ? 1 : 0; h->last_sweep_pairs = (sweep_rec && (sweep_glob || sweep_pairs)) ? 1 : 0;
+        h->last_sweep_global = sweep_glob ? 1 : (sweep_hyb ? 2 : 0); h->last_sweep_rec = sweep_rec ? 1 : 0; h->last_sweep_pairs = (sweep_rec && (sweep_glob || sweep_pairs)) ? 1 : 0;
         dim3 qg((unsigned)nseg);   // persistent: 2 workgroups per CU
         unsigned long long *d_dbg = nullptr;
         const char *dbgpath = h->env_debug_wg.empty() ? nullptr : h->env_debug_wg.c_str();
@@ -726,7 +746,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int fix_split = std::max(1, std::min(16, (8 * h->num_cu) / std::max(nseg, 1)));   // ~8 workgroups of k_rays_fix per CU (2 .. 16 per segment: no difference, round 4)
         if (!sweep) HIPCHK(h, hipEventRecord(h->ev[EV_K0], h->stream));
         if (count) {
-            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            if (sweep_hyb) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec && sweep_pairs) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<true, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
@@ -741,7 +762,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL((mcl::k_rays_fix<true>), dim3(nseg * fix_split), dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((mcl::k_rays_exact<true>), dim3(2 * h->num_cu), dim3(256), 0, h->stream, a);
         } else {
-            if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            if (sweep_hyb) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
+            else if (sweep_glob && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep_glob) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec && sweep_pairs) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
             else if (sweep && sweep_rec) hipExtLaunchKernelGGL((mcl::k_rays_sweep<false, false, true>), qg, b, qlds, h->stream, nullptr, h->ev[EV_K1], 0, a);
@@ -950,6 +972,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     if (const char *e = getenv("MCL_DEBUG_WG")) h->env_debug_wg = e;
     h->env_no_bucket_cuts = getenv("MCL_NO_BUCKET_CUTS") != nullptr;
     if (const char *e = getenv("MCL_SWEEP_GLOBAL")) h->env_sweep_global = atoi(e) != 0;
+    if (const char *e = getenv("MCL_SWEEP_HYBRID")) h->env_sweep_hybrid = atoi(e);
     if (const char *e = getenv("MCL_SW_SPLIT16")) h->env_sw_split16 = atoi(e) != 0;
     if (const char *e = getenv("MCL_SWEEP_PAIRS")) h->env_sweep_pairs = atoi(e) != 0 ? 1 : 0;
     h->env_no_obs_overlap = getenv("MCL_NO_OBS_OVERLAP") != nullptr;
@@ -1055,6 +1078,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
+    CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     CRT(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 64));
     {   // The hand-written probe loops address their LDS window from a raw offset: k_rays_sweep / k_rays_cell / k_rays_quad
         // from kQLdsBase (their static LDS must end exactly there), k_rays_skip from 0 (it must have no static LDS).  A
@@ -1072,6 +1097,8 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
                 hipFuncAttributes fa{};
                 return hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes > lo && fa.sharedSizeBytes <= hi;
             };
+            h->sweep_hyb_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true, false, true>), qb) &&
+                                     static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true, false, true>), qb);
             h->sweep_rec_layout_ok = static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true>), qb) &&
                                      static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<true, false, true>), qb) &&
                                      static_lds_is(reinterpret_cast<const void *>(&mcl::k_rays_sweep<false, false, true, true>), qb) &&
@@ -1583,7 +1610,9 @@ static int next_layout_launch(mcl_engine *h, int64_t n)
     const int ntx_abs = ((h->Wp * mcl::kSortSub - 1) >> 5) + 1, nty_abs = ((h->Hp * mcl::kSortSub - 1) >> 5) + 1;
     const bool tiles_ok = (int64_t)ntx_abs * nty_abs <= mcl::kSortMaxTiles;
     const int bstride = n >= (1 << 20) ? 16 : 1;
-    const int play = h->env_no_bucket_cuts ? -1 : (choose_ray_mode(h, n, false) == 5 ? sweep_play(h) : 0);
+    // (the layout of the NEXT update, made beside this one's ray stage: whether that update takes the hybrid form is not known
+    //  yet -- its units are cut for the hybrid's windows, which costs the global-field form nothing but shorter runs)
+    const int play = h->env_no_bucket_cuts ? -1 : (choose_ray_mode(h, n, false) == 5 ? sweep_play(h, sweep_hybrid(h)) : 0);
     HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_children, 0));
     hipLaunchKernelGGL(mcl::k_bbox_init, dim3(1), dim3(64), 0, h->stream2, h->d_bbox_nx, play);
     hipLaunchKernelGGL(mcl::k_cell_bbox, dim3((unsigned)std::min<int64_t>((n / bstride + 255) / 256, 128)), dim3(256), 0, h->stream2, h->d_pc, n,

@@ -42,6 +42,11 @@ constexpr int kSwSide = 256;             // window side in cells
 constexpr int kSwPitch = MCL_SW_PITCH;
 static_assert(kSwPitch >= kSwSide && (kSwPitch % 4) == 0, "window rows are written as dwords");
 constexpr int kSwWinBytes = kSwSide * kSwPitch;  // the window in LDS
+// The HYBRID form (ranges beyond what the window holds): the window is laid out as for a range of kSwHybReach px, its last row
+// and column are EXIT cells and no skip inside leads past them; a ray that reads an exit cell goes on in the global wedge fields.
+constexpr int kSwHybPlay = 40;                   // cells of play its windows leave the particles of a work item
+constexpr int kSwHybReach = kSwSide - (kSwHybPlay + 3) - 2;      // 211: S - (reach + 2) - 3 = play
+constexpr int kSwExitByte = 0xFE;                // neither a stop (0xFF) nor a skip (1..127): -2 as the signed byte the trip reads
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
 // fixed-point scale of a direction component: 2^32 - 3, so that |component| = 1 stays below 2^32 (the operand of v_mad_u64_u32
 // has 32 bits) with the + 1 of MCL_SW_ROTATE and its two roundings on top; the guard pays for it with 3 units (2^-32 px) per sample
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch)                                              \
         : MCL_SW_CLOBBERS)
 
-#define MCL_SW_WALK_REC(NEGX, NEGY)                                                                                            \
+#define MCL_SW_WALK_REC_T(NEGX, NEGY, TRIPS, ...)                                                                                           \
     asm volatile(                                                                                                              \
         "ds_read2_b64 v[40:43], %[je] offset1:1\n\t" /* offsets of the first two beams; the next two are read two beams ahead */ \
         "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
@@ -480,30 +485,33 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "3:\n\t"                                                                                                               \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
         MCL_SW_INTS_REC(NEGX, NEGY, "v[40:41]", "%[xa]", "%[ya]")                                                              \
-        MCL_SW_TRIPS_LDS                                                                                                       \
+        TRIPS                                                                                                                  \
         MCL_SW_TAIL_R("0")                                                                                                     \
         MCL_SW_STEP_REC("%[xa]", "%[ya]", "%[xb]", "%[yb]")                                                                    \
         MCL_SW_INTS_REC(NEGX, NEGY, "v[42:43]", "%[xb]", "%[yb]")                                                              \
         "ds_read2_b64 v[40:43], %[je] offset0:2 offset1:3\n\t" /* (landed by the first trip's wait) */                         \
-        MCL_SW_TRIPS_LDS                                                                                                       \
+        TRIPS                                                                                                                  \
         MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
         MCL_SW_TAIL_R("8")                                                                                                     \
         MCL_SW_INTS_REC(NEGX, NEGY, "v[40:41]", "%[xa]", "%[ya]")                                                              \
-        MCL_SW_TRIPS_LDS                                                                                                       \
+        TRIPS                                                                                                                  \
         MCL_SW_TAIL_R("16")                                                                                                    \
         MCL_SW_STEP_REC("%[xa]", "%[ya]", "%[xb]", "%[yb]")                                                                    \
         MCL_SW_INTS_REC(NEGX, NEGY, "v[42:43]", "%[xb]", "%[yb]")                                                              \
         "v_add_u32 %[je], %[je], %[ince]\n\t"                                                                                  \
         "ds_read2_b64 v[40:43], %[je] offset1:1\n\t"                                                                           \
-        MCL_SW_TRIPS_LDS                                                                                                       \
+        TRIPS                                                                                                                  \
         MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
         MCL_SW_TAIL_R_LAST("24")                                                                                               \
         : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xa] "+v"(xa), [ya] "+v"(ya), [xb] "+v"(xb),   \
           [yb] "+v"(yb), [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                \
         : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
           [ince] "v"(inc32), [rk] "s"(a.rec_k), [ltb] "s"(a.Ltd), [st8] "s"(st8),                                               \
-          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch)                                              \
+          [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch) __VA_ARGS__                                              \
         : MCL_SW_CLOBBERS)
+
+#define MCL_SW_WALK_REC(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS)
+#define MCL_SW_WALK_HYB(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS MCL_SW_ESCAPE, , [gx] "s"(hyb_gx), [gy] "s"(hyb_gy), [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit))
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
 // holds (cpp:195 puts no bound on MAX_RANGE_PX).  The fields are read in place from copies that are MIRRORED per quadrant like
@@ -543,6 +551,29 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_mov_b32 %[expired], 1\n"                                                                                            \
         "2:\n\t"                                                                                                               \
         "s_mov_b64 exec, -1\n\t"
+
+// HYBRID: the lanes whose ray has just read an exit cell of the window (v49 = -2; the others ended at a stop or ran out of
+// range) go on in the mirrored wedge fields in global memory: samples left restored (the borrow subtracted -2), the cell dwords
+// moved from the window's frame to the ringed field's (%[gx] carries the field's byte offset as well), and a first trip that
+// advances by zero -- it reads, from global memory, the cell the ray stands in.  The usual case -- nobody left the window -- costs
+// one compare and a branch per ray.
+#define MCL_SW_ESCAPE                                                                                                          \
+        "v_cmp_eq_u32 vcc, -2, v49\n\t"                                                                                        \
+        "s_cbranch_vccz 7f\n\t"                                                                                                \
+        "s_mov_b64 exec, vcc\n\t"                                                                                              \
+        "v_add_u32 v57, -2, v57\n\t"                                                                                           \
+        "v_add_u32 v53, %[gx], v53\n\t"                                                                                        \
+        "v_add_u32 v55, %[gy], v55\n\t"                                                                                        \
+        "v_mov_b32 v49, 0\n\t"                                                                                                 \
+        "s_mov_b32 %[cd], %[cdinit]\n"                                                                                         \
+        "6:\n\t"                                                                                                               \
+        MCL_SWG_TRIP_NEXT "s_cbranch_execz 8f\n\t"                                                                              \
+        "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
+        "s_cbranch_scc0 6b\n\t"                                                                                                \
+        "s_mov_b32 %[expired], 1\n"                                                                                            \
+        "8:\n\t"                                                                                                               \
+        "s_mov_b64 exec, -1\n"                                                                                                 \
+        "7:\n\t"
 
 #define MCL_SWG_WALK_TAB(NEGA, NEGB)                                                                                           \
     asm volatile(                                                                                                              \
@@ -688,9 +719,12 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
 // -11 % on the uniform cloud of a first update (both wait for memory), +-0 on the tracking cloud in LDS windows and +2 % on the
 // levine stand-in (both bound by VALU issue by then): the host asks for PAIRS in the global-field form and for a freshly
 // initialised set.
-template <bool COUNT, bool GLOBAL = false, bool REC = false, bool PAIRS = false>
+// HYB (with REC, without GLOBAL / PAIRS): ranges beyond the window -- the walk runs in the LDS window as far as that reaches and
+// goes on in the global wedge fields where a ray leaves it (MCL_SW_ESCAPE).  At 479 px (a 0.025 m map, 12 m) most rays end inside.
+template <bool COUNT, bool GLOBAL = false, bool REC = false, bool PAIRS = false, bool HYB = false>
 __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
 {
+    static_assert(!HYB || (REC && !GLOBAL && !PAIRS), "the hybrid form is the turned-direction walk in LDS windows");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int item_sh;
     __shared__ unsigned int fixn_sh;                           // entries this workgroup appended to ITS segment of the fix-up list
@@ -758,6 +792,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
     // GLOBAL: no window.  Field kbin of RayArgs::distg is mirrored like a window would be, and a position's cell dwords are the
     // absolute row and (field offset + column) in the allocation: nothing a particle could miss but the ringed grid itself
     const uint32_t foff = GLOBAL ? (uint32_t)((size_t)kbin * a.distg_stride) : 0u;     // < 2^32: checked by mcl_set_map
+    [[maybe_unused]] uint32_t hyb_gx = 0u, hyb_gy = 0u;                  // HYB: window frame -> ringed field (set with the window's origin)
     if (GLOBAL) {
         wx0 = -2; wy0 = -2;                                                // ringed frame: column c = padded cell c - 2
         if (gw > 0) __syncthreads();                                       // every wave is done with the previous pass's chunk counter
@@ -765,11 +800,19 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         __syncthreads();
     } else {
         constexpr int S = kSwSide;
-        const int E = S - (a.P + 2) - mlo;
+        const int Pw = HYB ? kSwHybReach : a.P;                            // the range the window is laid out for
+        const int E = S - (Pw + 2) - mlo;
         const int back = E / 2 + mlo;
         const int cxm = ctr.x, cym = ctr.y;
         wx0 = sxp ? cxm - back : cxm + back - S;
         wy0 = syp ? cym - back : cym + back - S;
+        if (HYB) {
+            // column c of the mirrored window is column c + (wx0 + 2) of the mirrored ringed field where the rays run up the axis,
+            // c + (Wp - (S - 2) - wx0) where they run down (the two frames differ by whole cells: positions keep their
+            // fractions); the field's byte offset in the allocation rides in the column like in the global form
+            hyb_gx = (uint32_t)(sxp ? wx0 + 2 : a.Wp - (S - 2) - wx0) + (uint32_t)((size_t)kbin * a.distg_stride);
+            hyb_gy = (uint32_t)(syp ? wy0 + 2 : a.Hp - (S - 2) - wy0);
+        }
         uint32_t *win = reinterpret_cast<uint32_t *>(lds_raw);             // rows kSwPitch bytes apart, written as dword pairs
         const uint8_t *fieldq = a.distw + (size_t)kbin * a.distw_stride;   // only stops a wedge-kbin ray can reach bound its jumps
         constexpr int wpr = S >> 3, nwords = wpr * S;
@@ -794,7 +837,27 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         if (gx + k >= 0 && gx + k < a.Wp) b8 = (b8 & ~(0xFFull << (8 * k))) | ((uint64_t)rowp[gx + k] << (8 * k));
                 }
             }
-            const uint64_t w8 = sxp ? b8 : __builtin_bswap64(b8);
+            uint64_t w8 = sxp ? b8 : __builtin_bswap64(b8);
+            if (HYB) {
+                // no skip leads past the last row or column -- a jump of k samples moves at most k cells along either axis --, and
+                // those are exit cells where they lie inside the grid (outside it a window is stop bytes, which no ray crosses)
+                const bool row_in = gy >= 0 && gy < a.Hp;
+                const int rleft = (S - 1) - row, c0 = cw * 8;
+                if (rleft < 128 || c0 + 7 > (S - 1) - 128 || row == S - 1) {
+                    uint64_t o = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int col = c0 + k, cleft = (S - 1) - col;
+                        const int gxk = sxp ? wx0 + col : wx0 + (S - 1) - col;
+                        uint32_t b = (uint32_t)(w8 >> (8 * k)) & 0xFFu;
+                        const uint32_t lim = (uint32_t)(rleft < cleft ? rleft : cleft);
+                        if (b != 0xFFu && b > lim) b = lim;                 // (lim == 0 only in the exit row / column, set below)
+                        if ((rleft == 0 || cleft == 0) && row_in && gxk >= 0 && gxk < a.Wp) b = (uint32_t)kSwExitByte;
+                        o |= (uint64_t)b << (8 * k);
+                    }
+                    w8 = o;
+                }
+            }
             uint32_t *wp = win + row * (kSwPitch / 4) + cw * 2;
             wp[0] = (uint32_t)w8; wp[1] = (uint32_t)(w8 >> 32);
         }
@@ -853,10 +916,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             // the particle's own padded cell must exist in the field (NaN fails the comparisons)
             inwin = pci.z >= -1.0 && pci.z < (double)(a.Wp - 1) && pci.w >= -1.0 && pci.w < (double)(a.Hp - 1);
         } else {
-            const double fwd = (double)(a.P + 2), bwd = 2.0;
+            const double fwd = (double)((HYB ? kSwHybReach : a.P) + 2), bwd = 2.0;
             const bool inx = sxp ? (wpx - bwd >= 0.0 && wpx + fwd < (double)Sx) : (wpx - fwd >= 0.0 && wpx + bwd < (double)Sx);
             const bool iny = syp ? (wpy - bwd >= 0.0 && wpy + fwd < (double)Sy) : (wpy - fwd >= 0.0 && wpy + bwd < (double)Sy);
             inwin = inx && iny;
+            // (HYB: a ray may go on in the global fields, whose walk starts from a cell of the ringed grid: the particle's own padded
+            //  cell must exist there as well, like in the global-field form)
+            if (HYB) inwin = inwin && pci.z >= -1.0 && pci.z < (double)(a.Wp - 1) && pci.w >= -1.0 && pci.w < (double)(a.Hp - 1);
         }
         uint32_t i = 0xFFFFFFFFu;                                  // particle index, loaded by the rare paths that need it
         if (!inwin && n1 + n2 > 0) {                           // not in this window (or NaN): k_rays_far does this pair
@@ -952,7 +1018,8 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 (void)j16;
                 if constexpr (!PAIRS) {
                     static_assert(PAIRS || !GLOBAL || !REC, "the global-field form walks pairs when it turns the directions");
-                    if constexpr (!GLOBAL) { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
+                    if constexpr (HYB) { if (negy) MCL_SW_WALK_HYB("", "-"); else MCL_SW_WALK_HYB("-", ""); }
+                    else if constexpr (!GLOBAL) { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
                 } else {
                     // two rays per lane (MCL_SW2_*): ceil(walk_n / 2) pairs of slots
                     const uint32_t x2_even = (walk_n & 1) ? 0u : 1u;
@@ -996,7 +1063,13 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 int rem;
                 uint32_t g;
                 bool expired = false;
-                if (!COUNT && GLOBAL) {
+                // (HYB: the per-slot forms walk in the global fields from the start -- the origin moved into their frame --; the own
+                //  cell's skip came from the window, where it is at most what the field says)
+                // (a lane without rays stands in cell (2, 2) of the window -- of the ringed FIELD here: the window may lie off the grid)
+                [[maybe_unused]] const unsigned long long P0xs = !HYB ? P0x : live ? P0x + ((unsigned long long)hyb_gx << 32)
+                                                               : ((unsigned long long)(2u + (uint32_t)((size_t)kbin * a.distg_stride)) << 32) | lox;
+                [[maybe_unused]] const unsigned long long P0ys = !HYB ? P0y : live ? P0y + ((unsigned long long)hyb_gy << 32) : (2ull << 32) | loy;
+                if (!COUNT && (GLOBAL || HYB)) {
                     unsigned long long saved_exec;
                     uint32_t countdown;
                     asm volatile(
@@ -1012,7 +1085,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         "2:\n\t"
                         "s_mov_b64 exec, %[sv]"
                         : [g] "=&v"(g), [rem] "=&v"(rem), [sv] "=&s"(saved_exec), [cd] "=&s"(countdown)
-                        : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0x), [p0y] "v"(P0y),
+                        : [rem0] "v"(rem_start), [g0] "v"(g0), [s0] "v"(s0e), [xx] "v"(Xx), [xy] "v"(Xy), [p0x] "v"(P0xs), [p0y] "v"(P0ys),
                           [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit)
                         : "memory", "vcc", "scc", "v48", "v49", "v52", "v53", "v54", "v55");
                     expired = __builtin_amdgcn_readfirstlane((int)countdown) < 0;
@@ -1042,21 +1115,21 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                     int trips = 0;
                     rem = rem_start;
                     g = g0;
-                    unsigned long long Tx = P0x, Ty = P0y;
+                    unsigned long long Tx = P0xs, Ty = P0ys;
                     uint32_t by = s0e;
                     do {
                         Tx += (unsigned long long)by * Xx;
                         Ty += (unsigned long long)by * Xy;
                         const uint32_t gm = (uint32_t)Tx < (uint32_t)Ty ? (uint32_t)Tx : (uint32_t)Ty;
                         g = g < gm ? g : gm;
-                        if (GLOBAL) by = (uint32_t)(int)(int8_t)a.distg[(size_t)(uint32_t)((uint32_t)(Ty >> 32) * gpitch + (uint32_t)(Tx >> 32))];
+                        if (GLOBAL || HYB) by = (uint32_t)(int)(int8_t)a.distg[(size_t)(uint32_t)((uint32_t)(Ty >> 32) * gpitch + (uint32_t)(Tx >> 32))];
                         else by = (uint32_t)(int)(int8_t)ldsb[((uint32_t)(Ty >> 32) & (kSwSide - 1)) * (uint32_t)kSwPitch + ((uint32_t)(Tx >> 32) & (kSwSide - 1))];
                         uint32_t nr;
                         const bool over = __builtin_usub_overflow((uint32_t)rem, by, &nr);
                         go = !over;
                         rem = (int)nr;
                         cnt_probe += (go && valid) ? 1 : 0;
-                    } while (go && ++trips <= (GLOBAL ? (int)cdinit : 300));
+                    } while (go && ++trips <= ((GLOBAL || HYB) ? (int)cdinit : 300));
                     if (go) g = 0u;
                 }
                 if (COUNT && valid) ++cnt_probe;

@@ -376,10 +376,10 @@ class Engine:
         return {1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}.get(v.value, "?")
 
     def ray_kernel_variant(self):
-        """Form of k_rays_sweep the last ray stage ran: dict(global_fields, turned_directions, pairs)."""
+        """Form of k_rays_sweep the last ray stage ran: dict(global_fields, hybrid, turned_directions, pairs)."""
         v = (C.c_int32 * 3)()
         self._chk(self.lib.mcl_get_ray_kernel_variant(self._h, v), "mcl_get_ray_kernel_variant")
-        return dict(global_fields=bool(v[0]), turned_directions=bool(v[1]), pairs=bool(v[2]))
+        return dict(global_fields=v[0] == 1, hybrid=v[0] == 2, turned_directions=bool(v[1]), pairs=bool(v[2]))
 
     RAY_KERNEL_NAMES = {0: None, 1: "k_rays_march", 2: "k_rays_skip", 3: "k_rays_quad", 4: "k_rays_cell", 5: "k_rays_sweep"}
 

@@ -187,7 +187,9 @@ def test_range_beyond_the_lds_windows_takes_the_global_fields(orc, engine_mod, s
     e.sensor_update(obs)
     assert e.ray_kernel_name() == "k_rays_sweep"
     assert np.array_equal(e.log_weights(), oracle_logw(orc, om, p, ang, obs))
-    assert e.counters()["off_window_particles"] == 0
+    v = e.ray_kernel_variant()
+    assert v["hybrid"] or v["global_fields"]              # (an evenly spaced scan: the hybrid form, unless MCL_SWEEP_HYBRID=0)
+    assert e.counters()["off_window_particles"] <= (16 if v["hybrid"] else 0)
     e.close()
     e = engine_mod.Engine(max_particles=n, seed=1, ray_kernel=engine_mod.RAYS_CELL)
     e.set_map(spielberg.data, res, spielberg.origin_x, spielberg.origin_y)
