@@ -44,7 +44,10 @@ static_assert(kSwPitch >= kSwSide && (kSwPitch % 4) == 0, "window rows are writt
 constexpr int kSwWinBytes = kSwSide * kSwPitch;  // the window in LDS
 // The HYBRID form (ranges beyond what the window holds): the window is laid out as for a range of kSwHybReach px, its last row
 // and column are EXIT cells and no skip inside leads past them; a ray that reads an exit cell goes on in the global wedge fields.
-constexpr int kSwHybPlay = 40;                   // cells of play its windows leave the particles of a work item
+#ifndef MCL_SW_HYB_PLAY
+#define MCL_SW_HYB_PLAY 40
+#endif
+constexpr int kSwHybPlay = MCL_SW_HYB_PLAY;      // cells of play its windows leave the particles of a work item
 constexpr int kSwHybReach = kSwSide - (kSwHybPlay + 3) - 2;      // 211: S - (reach + 2) - 3 = play
 constexpr int kSwExitByte = 0xFE;                // neither a stop (0xFF) nor a skip (1..127): -2 as the signed byte the trip reads
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         : MCL_SW_CLOBBERS)
 
 #define MCL_SW_WALK_REC(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS)
-#define MCL_SW_WALK_HYB(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS MCL_SW_ESCAPE, , [gx] "s"(hyb_gx), [gy] "s"(hyb_gy), [pitch] "s"(gpitch), [gbase] "s"(a.distg), [cdinit] "s"(cdinit))
+#define MCL_SW_WALK_HYB(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS MCL_SW_ESCAPE, , [gx] "s"(hyb_gx), [gy] "s"(hyb_gy), [pitch] "s"(gpitch), [gbase] "s"(a.distg))
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
 // holds (cpp:195 puts no bound on MAX_RANGE_PX).  The fields are read in place from copies that are MIRRORED per quadrant like
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "v_add_u32 v53, %[gx], v53\n\t"                                                                                        \
         "v_add_u32 v55, %[gy], v55\n\t"                                                                                        \
         "v_mov_b32 v49, 0\n\t"                                                                                                 \
-        "s_mov_b32 %[cd], %[cdinit]\n"                                                                                         \
+        "s_movk_i32 %[cd], 0x7fff\n" /* (a bound for a malformed field only: the samples left end every walk) */                 \
         "6:\n\t"                                                                                                               \
         MCL_SWG_TRIP_NEXT "s_cbranch_execz 8f\n\t"                                                                              \
         "s_sub_u32 %[cd], %[cd], 1\n\t"                                                                                        \
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 const int rleft = (S - 1) - row, c0 = cw * 8;
                 if (rleft < 128 || c0 + 7 > (S - 1) - 128 || row == S - 1) {
                     uint64_t o = 0;
-#pragma unroll
+#pragma unroll 1        // (kept rolled: unrolled, its temporaries pushed seventy registers of the chunk loop into scratch)
                     for (int k = 0; k < 8; ++k) {
                         const int col = c0 + k, cleft = (S - 1) - col;
                         const int gxk = sxp ? wx0 + col : wx0 + (S - 1) - col;
