@@ -133,10 +133,11 @@ def _sha16(path):
 # VALU instructions of k_rays_sweep's walk per ray outside the trips / per trip, by the form that ran (csrc/mcl_rays_sweep.h;
 # tools/roofline_inputs.py checks the trip against the shipped binary):
 #   fetched directions (TAB): 4 FMA + index add | table: add, mad, add                                          =  8   per ray
-#   turned directions (REC):  4 (integers) + 2 (three-term step) + 1/2 index add | table: add, mad, 1/2 add     =  9.5 per ray
+#   turned directions (REC):  4 (integers) + 2 (three-term step) + 1/4 index add | table: add, mad, 1/4 add     =  8.5 per ray
 #   two rays per lane (REC + PAIRS): 8 + 4 + index add | 2 add, 2 mad, add per PAIR                              =  9   per ray
+#   hybrid (REC in LDS windows, the global fields beyond): REC + the compare for "left the window"               =  9.5 per ray
 #   trip: 2 v_mad_u64_u32, address, v_min3_u32, v_sub_co_u32                                                    =  5   per trip
-WALK_VALU = {"tab": (8.0, 5.0), "rec": (9.5, 5.0), "pairs": (9.0, 5.0)}
+WALK_VALU = {"tab": (8.0, 5.0), "rec": (8.5, 5.0), "pairs": (9.0, 5.0), "hyb": (9.5, 5.0)}
 
 
 def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_live=None, variant=None):
@@ -162,7 +163,8 @@ def roofline_block(kernel_name, k_ms, n, B, sbar, profiled_workload=True, trips_
     if variant is not None:
         block["kernel_form"] = variant
     if trips_live is not None and kernel_name == "k_rays_sweep":
-        form = "tab" if not (variant or {}).get("turned_directions") else ("pairs" if (variant or {}).get("pairs") else "rec")
+        v = variant or {}
+        form = "tab" if not v.get("turned_directions") else "hyb" if v.get("hybrid") else "pairs" if v.get("pairs") else "rec"
         per_ray, per_trip = WALK_VALU[form]
         insts_per_ray = per_ray + per_trip * trips_live
         useful_ms = n * B / 64.0 * insts_per_ray * 4.0 / (SIMDS * MAX_CLOCK_GHZ * 1e6)

@@ -97,10 +97,12 @@ for case in range(ncases):
         want2, _, _ = orc.eng_log_weights(om, np.ascontiguousarray(q[:, pick2]), ang, orc.obs_index(obs, om), L)
         ok2 = np.array_equal(got2[pick2], want2)
         c = e.counters()
+        variant = e.ray_kernel_variant() if kern == "k_rays_sweep" else {}
     finally:
         e.close()
     bad += (not ok1) + (not ok2)
-    kern += "/g" if (os.environ["MCL_SWEEP_GLOBAL"] == "1" or om.max_range_px > 243) and kern == "k_rays_sweep" else ""
+    if kern == "k_rays_sweep":           # the form of the LAST ray stage: /g global wedge fields, /h hybrid (LDS windows + the global fields beyond)
+        kern += "/h" if variant.get("hybrid") else "/g" if variant.get("global_fields") else ""
     print(f"case {case:3d} {mname:9s} range {max_range:4.1f} ({om.max_range_px:3d} px) B {B:4d} span {span:5.2f} a0 {a0:5.2f} {spacing:6s} n {n:6d} {kind:8s} "
           f"{kern:14s} off {c['off_window_particles']:6d} lvl2 {c['level2_rays']:7d} {'OK' if ok1 else 'MISMATCH(sensor)'} {'OK' if ok2 else 'MISMATCH(update)'} "
           f"{time.time() - t0:.1f}s", flush=True)

@@ -59,10 +59,11 @@ def trip_mix_from_disassembly():
     lib = os.path.join(root, "monte_carlo_localization_amd", "libmcl_hip_engine.so")
     if not os.path.exists(lib):
         return None
-    txt = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_meta.py"), lib, "--disasm", "k_rays_sweepILb0"],
+    # (the instantiation the default workload runs: <COUNT = false, GLOBAL = false, REC = true, PAIRS = false, HYB = false>)
+    txt = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_meta.py"), lib, "--disasm", "k_rays_sweepILb0ELb0ELb1ELb0ELb0E"],
                          capture_output=True, text=True).stdout
     ops = [re.sub(r"_e(32|64)$", "", l.split()[0]) for l in txt.splitlines() if l.startswith("\t")]
-    want = ["v_mad_u64_u32", "v_mad_u64_u32", "v_lshl_or_b32", "ds_read_i8", "v_min3_u32", "s_waitcnt", "v_sub_co_u32", "s_andn2_b64"]
+    want = ["v_mad_u64_u32", "v_mad_u64_u32", "v_mad_u32_u24", "ds_read_i8", "v_min3_u32", "s_waitcnt", "v_sub_co_u32", "s_andn2_b64"]
     hits = [i for i in range(len(ops) - len(want)) if ops[i:i + len(want)] == want]
     if not hits:
         return {"verified": False}
