@@ -2,7 +2,7 @@
 """Long runs of the round-5 forms of the ray kernel against each other (run on a GPU box; test infrastructure, like tests/): the same
 seeded filter through (a) the default choice (k_rays_sweep turning the beam direction, one ray per lane in LDS windows), (b)
 MCL_SWEEP_NO_REC=1 (directions fetched per ray), (c) MCL_SWEEP_PAIRS=1 (two rays per lane), (d) MCL_SWEEP_GLOBAL=1 (the wedge
-fields probed in global memory, pairs), (e) MCL_SWEEP_GLOBAL=1 + MCL_SWEEP_NO_REC=1, (f) MCL_NO_STALE_LAYOUT=1 -- particles, weights
+fields probed in global memory, pairs; MCL_SWEEP_HYBRID=0), (d') the hybrid form (MCL_SWEEP_GLOBAL=1 MCL_SWEEP_HYBRID=2), (e) MCL_SWEEP_GLOBAL=1 + MCL_SWEEP_NO_REC=1, (f) MCL_NO_STALE_LAYOUT=1 -- particles, weights
 and resample indices after N updates must be bit-identical (sha256), on the counting-sort sizes and on the radix-sort size,
 tracking and global regime, both resampling modes; then 300 updates at 4M x 1081 with an oracle spot check of the last update's
 log-weights.
@@ -24,7 +24,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 m = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
 full = np.load(os.path.join(ROOT, "tests", "golden", "scan_Spielberg_map_origin.npz"))["ranges"].astype(np.float32)
 VARIANTS = {"default": {}, "fetched-directions": {"MCL_SWEEP_NO_REC": "1"}, "pairs": {"MCL_SWEEP_PAIRS": "1"},
-            "global-fields": {"MCL_SWEEP_GLOBAL": "1"}, "global-fields-fetched": {"MCL_SWEEP_GLOBAL": "1", "MCL_SWEEP_NO_REC": "1"},
+            "global-fields": {"MCL_SWEEP_GLOBAL": "1", "MCL_SWEEP_HYBRID": "0"}, "global-fields-fetched": {"MCL_SWEEP_GLOBAL": "1", "MCL_SWEEP_NO_REC": "1"},
+            "hybrid": {"MCL_SWEEP_GLOBAL": "1", "MCL_SWEEP_HYBRID": "2"},        # LDS windows + the global fields where a ray leaves its window
             "own-layout": {"MCL_NO_STALE_LAYOUT": "1"}}
 
 
