@@ -54,3 +54,57 @@ def test_brute_force_on_a_small_map():
     dx = np.arange(p + 2)
     off = (r0[..., None, None] + dx[:, None]) * g["pitch"] + (c0[..., None, None] + dx[None, :])
     assert off.min() >= 0 and off.max() < g["stride"]
+
+
+# ---- the hybrid form's LDS window (csrc/mcl_rays_sweep.h, the window loader under HYB): ranges beyond the window -------------------
+# The rule the loader applies, restated: in a 256 x 256 window whose rays run towards +x, +y, the last row and the last column are
+# EXIT cells (0xFE) where they lie inside the grid, and every skip byte (1 .. 127; stops, 0xFF, are left alone) is clamped to
+# min(255 - row, 255 - column).  A jump of k samples moves a ray by at most k cells along either axis (a direction component is
+# at most one cell per sample), so from any cell a walk that only ever advances by the byte of the cell it stands in stays inside the
+# window until it reads a stop, an exit, or runs out of samples -- whatever the field holds.
+S, EXIT, STOP = 256, 0xFE, 0xFF
+
+
+def hybrid_window(field, in_grid):
+    """field: S x S bytes in the window's (mirrored) frame, 1 .. 127 or STOP; in_grid: which cells lie inside the map."""
+    w = field.copy()
+    rr, cc = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+    lim = np.minimum(S - 1 - rr, S - 1 - cc)
+    skip = w != STOP
+    w[skip] = np.minimum(w[skip], lim[skip])
+    edge = ((rr == S - 1) | (cc == S - 1)) & in_grid
+    w[edge] = EXIT
+    return w
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hybrid_window_no_walk_leaves_it_unnoticed(seed):
+    rng = np.random.default_rng(seed)
+    field = rng.integers(1, 128, (S, S)).astype(np.uint8)
+    field[rng.random((S, S)) < 0.002] = STOP
+    in_grid = np.ones((S, S), bool)
+    if seed & 1:                                    # the grid ends inside the window: beyond it a window is stop bytes
+        in_grid[:, 200:] = False
+        in_grid[230:, :] = False
+        field[~in_grid] = STOP
+    w = hybrid_window(field, in_grid)
+    assert (w[in_grid & (w != STOP)] != 0).all()                       # no zero skip anywhere a ray can stand
+    assert (w[-1, :][in_grid[-1, :]] == EXIT).all() and (w[:, -1][in_grid[:, -1]] == EXIT).all()
+    P = 479
+    n = 4000
+    y = rng.uniform(2.0, 44.0, n); x = rng.uniform(2.0, 44.0, n)       # origins in the play corner
+    th = rng.uniform(0.0, np.pi / 2, n)
+    dy, dx = np.sin(th), np.cos(th)                                     # both components in [0, 1]: the mirrored frame
+    left = np.full(n, P)
+    alive = np.ones(n, bool)
+    for _ in range(2 * S):
+        r, c = np.floor(y).astype(int), np.floor(x).astype(int)
+        assert (r[alive] <= S - 1).all() and (c[alive] <= S - 1).all()  # every read lies inside the window
+        b = w[np.minimum(r, S - 1), np.minimum(c, S - 1)].astype(int)
+        ended = alive & ((b == STOP) | (b == EXIT) | (b > left))
+        alive &= ~ended
+        if not alive.any():
+            break
+        y = np.where(alive, y + b * dy, y); x = np.where(alive, x + b * dx, x)
+        left = np.where(alive, left - b, left)
+    assert not alive.any()
