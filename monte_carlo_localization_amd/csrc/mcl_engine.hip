@@ -699,6 +699,8 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             a.pcs = h->d_pcs; a.ths = h->d_ths; a.perm = h->d_perm; a.slice_mean = h->d_slice_mean;
             a.distw = h->d_distw; a.distw_stride = (size_t)h->Hp * h->Wps;
         }
+        // the tables of this update's scan were built on the second stream beside the resampling and the ordering: from here on they are read
+        if (h->obs_wait_pending) { h->obs_wait_pending = false; HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_obs, 0)); }
         if (sweep) {
             if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not allocated (internal)");
             if (!h->ltd_ready) build_ltd(h);          // a caller whose table decision was made for another particle count
@@ -1849,7 +1851,9 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     }
     h->ray_ms_is_graph_tail = false;
     if (obs_early) {
-        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_obs, 0));
+        // (the ordering kernels of the ray stage do not read the tables either: the stream waits for them where the ray kernel is
+        //  launched -- launch_rays --, not here: 13 us of a 262 144-particle update)
+        h->obs_wait_pending = true;
     } else {
         rc = prepare_observation(h, obs, obs_stride);
         if (rc) return rc;
@@ -1859,6 +1863,7 @@ static int do_update(mcl_engine_t *h, const double action[3], const float *obs, 
     if (!obs_early) HIPCHK(h, hipEventRecord(h->ev[EV_QUERY], h->stream));
     h->ev_rays_bound = false;
     rc = launch_rays(h, h->d_x[h->cur], h->d_y[h->cur], h->d_th[h->cur], n);
+    if (h->obs_wait_pending) { h->obs_wait_pending = false; HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_obs, 0)); }      // (a path that launched no windowed kernel)
     if (rc) return rc;
     rc = next_layout_launch(h, n);          // (second stream; behind the ray stage in submission order, beside it on the device)
     if (rc) return rc;

@@ -36,6 +36,7 @@ struct mcl_engine {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // the per-update observation tables are built here, beside the resampling and ordering kernels
     hipEvent_t ev_obs = nullptr;        // ... and the ray stage waits for this
+    bool obs_wait_pending = false;      // ... where its first kernel that reads them is launched (launch_rays)
     hipEvent_t ev[EV_COUNT]{};
     std::string err;
 
