@@ -372,7 +372,22 @@ bool sweep_hybrid(const mcl_engine *h)
 //  cloud of a re-localisation --, takes the global-field form: every lane has its own origin there, where the hybrid's windows
 //  would hand a good part of such a cloud to the far pass.  fine025 stand-in, 4M uniform: first update 39 ms against 64.)
 bool sweep_far_expected(const mcl_engine *h) { return h->far_fresh || h->h_result[15] >= mcl::kFarWindowedMin / 2; }
-bool sweep_hybrid_now(const mcl_engine *h) { return sweep_hybrid(h) && (h->env_sweep_hybrid == 2 || !sweep_far_expected(h)); }     // (MCL_SWEEP_HYBRID=2: always, the tests' setting)
+// Decided ONCE per update (launch_rays).  A hybrid update that left many particles to the far pass -- a cloud that has not converged
+// yet -- is followed by 1, 2, 4 .. 32 updates in the global-field form before the hybrid is tried again (a global-field update
+// flags nothing, so its count says nothing about the cloud: without the back-off the two forms would alternate).
+// MCL_SWEEP_HYBRID=2: always the hybrid (the tests' setting).
+bool sweep_hybrid_decide(mcl_engine *h)
+{
+    if (!sweep_hybrid(h)) return false;
+    if (h->env_sweep_hybrid == 2) return true;
+    if (h->far_fresh) { h->hyb_backoff = 0; h->hyb_skip = 0; return false; }
+    if (h->last_sweep_global == 2) {
+        if (h->h_result[15] >= mcl::kFarWindowedMin / 2) { h->hyb_backoff = h->hyb_backoff ? std::min(32, 2 * h->hyb_backoff) : 1; h->hyb_skip = h->hyb_backoff; }
+        else h->hyb_backoff = 0;
+    }
+    if (h->hyb_skip > 0) { --h->hyb_skip; return false; }
+    return true;
+}
 
 int sweep_play(const mcl_engine *h, bool hybrid)
 {
@@ -546,7 +561,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         const int spc = h->env_qslices_per_cu > 0 ? h->env_qslices_per_cu : 32;
         int nsl = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)spc * h->num_cu, (n + 255) / 256));
         int sweep_g = 1;
-        bool sweep_hyb_now = false;                            // k_rays_sweep's hybrid form for THIS update (set with the far-pass decision)
+        const bool sweep_hyb_now = sweep && sweep_hybrid_decide(h);      // k_rays_sweep's hybrid form for THIS update
         if (cell) {
             // k_rays_cell: a slice is a run of the sorted order; 2048 particles = two 64-particle groups per wave.  Longer
             // slices amortise the window load better, shorter ones balance the persistent workgroups better
@@ -603,7 +618,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             const bool stale_layout = cell && h->layout_stale_used;      // d_bbox / d_tilemap hold the layout to order by: not remade
             if (cell && !stale_layout) clr.bbox = h->d_bbox;          // (the histogram is left all-zero by k_hist_clear of the previous sort)
             // the window play k_sweep_plan works with (0: no windowed kernel; -1: no cuts at all, MCL_NO_BUCKET_CUTS)
-            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? sweep_play(h, sweep_hybrid_now(h)) : 0);
+            clr.bbox_play = h->env_no_bucket_cuts ? -1 : (sweep ? sweep_play(h, sweep_hyb_now) : 0);
             if (cell && h->pc_ready) {         // the resampling kernel left the constants and zeroed the per-particle scratch
                 clr.logw_acc = nullptr; clr.far_flags = nullptr;
                 // ... and, from the second update of a configuration on, the few words that are not per particle as well
@@ -704,7 +719,7 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
         if (sweep) {
             if (!h->d_Ltd) return fail(h, MCL_ERR_HIP, "k_rays_sweep: table not allocated (internal)");
             if (!h->ltd_ready) build_ltd(h);          // a caller whose table decision was made for another particle count
-            const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g, sweep_hybrid_now(h));
+            const int rc_plan = launch_sweep_plan(h, n, nseg, sweep_g, sweep_hyb_now);
             if (rc_plan) return rc_plan;
             a.sweep_g = sweep_g; a.Ltd = h->d_Ltd; a.ltd_cols = h->ltd_cols;
             a.split16 = h->env_sw_split16 >= 0 ? h->env_sw_split16 : 0;
@@ -721,7 +736,6 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             // there is reason to expect work for it: the previous ray stage flagged a fair number of slots, or the particle set
             // is fresh (set / initialised since).  A misjudgement costs time, never results: without it k_rays_far takes all.
             a.far_sorted = h->d_far_sorted;
-            sweep_hyb_now = sweep_hybrid_now(h);                 // (before far_fresh is taken down)
             a.far_windowed = sweep_far_expected(h) ? 1 : 0;
             h->far_fresh = false;
             a.far_list = h->d_far_list; a.far_count = h->d_result + 15;      // word 15 of the result block, zeroed below
