@@ -9,7 +9,7 @@
 //       - positions are 64-bit per axis, cell in the high dword, a 32-bit fraction in the low one, in a 256 x 256-cell window
 //         stored MIRRORED per quadrant (every ray of a wedge runs towards +x, +y): both direction components are unsigned 32-bit
 //         operands, the position advances by T += skip * X with one v_mad_u64_u32 (no end point), the LDS address of a cell is
-//         row << 8 | column of the two high dwords (one v_lshl_or_b32);
+//         row * pitch + column of the two high dwords (one v_mad_u32_u24; pitch 260: no row starts in its neighbour's LDS bank);
 //       - the guard bias is folded into the origin, so the fraction test is one v_min3_u32 over the two low dwords, and the guard
 //         (2^-22 px) is narrow enough to be looked at once per walk, not per ray;
 //       - the beam direction is TURNED from beam to beam (an evenly spaced scan: MCL_SW_INTS_REC / MCL_SW_STEP_REC), not fetched;
@@ -18,7 +18,9 @@
 //       - the beam walk of the slots every live lane of the wave has is ONE asm block with its own waitcnt counting, trips unrolled
 //         (not-taken exit branches), induction variables advanced by per-lane increments (0 for a lane without rays);
 //       - where the walk waits for memory rather than for the VALU (the global-field form, a spread cloud) a lane walks TWO rays
-//         at once (MCL_SW2_*).
+//         at once (MCL_SW2_*);
+//       - ranges beyond the window: the HYBRID form -- the window's last row and column are exit cells, no skip leads past them,
+//         and a ray that reads one goes on in the mirrored wedge fields in global memory (MCL_SW_ESCAPE).
 //   * A work item is (run of units, group of G wedges; G = 1 by default), planned on the device per update (k_sweep_plan).  The sum of
 //     a particle's rays in a wedge goes to its slot's accumulator with one fp64 atomic -- sixty-four lanes on 512 contiguous
 //     bytes of the sorted order.
