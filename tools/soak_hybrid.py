@@ -3,10 +3,16 @@
 run on a GPU box): 1M particles x 1081 beams, N updates (default 150) -- the default choice (global fields for the freshly loaded set, the hybrid
 after), MCL_SWEEP_HYBRID=0 and MCL_SWEEP_HYBRID=2 must leave bit-identical particles, weights and resample indices; the last log-weights of the
 first run are checked against the oracle.  usage: tools/soak_hybrid.py [updates]"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from monte_carlo_localization_amd import engine, maps, synth
-from oracle import oracle as orc
+from monte_carlo_localization_amd import engine, maps, synth      # noqa: E402
+from oracle import oracle as orc                                  # noqa: E402
 sp = maps.load_npz(os.path.join(ROOT, "tests", "golden", "map_Spielberg_map.npz"))
 fine = maps.synthetic_fine025(sp)
 ang = synth.beam_angles()
