@@ -19,8 +19,8 @@
 //         (not-taken exit branches), induction variables advanced by per-lane increments (0 for a lane without rays);
 //       - where the walk waits for memory rather than for the VALU (the global-field form, a spread cloud) a lane walks TWO rays
 //         at once (MCL_SW2_*);
-//       - ranges beyond the window: the HYBRID form -- the window's last row and column are exit cells, no skip leads past them,
-//         and a ray that reads one goes on in the mirrored wedge fields in global memory (MCL_SW_ESCAPE).
+//       - ranges beyond the window: the HYBRID form -- a lane's walk has a budget of samples inside the window, and a ray that is
+//         unstopped when it is spent goes on in the mirrored wedge fields in global memory (MCL_SW_ESCAPE).
 //   * A work item is (run of units, group of G wedges; G = 1 by default), planned on the device per update (k_sweep_plan).  The sum of
 //     a particle's rays in a wedge goes to its slot's accumulator with one fp64 atomic -- sixty-four lanes on 512 contiguous
 //     bytes of the sorted order.
@@ -44,14 +44,18 @@ constexpr int kSwSide = 256;             // window side in cells
 constexpr int kSwPitch = MCL_SW_PITCH;
 static_assert(kSwPitch >= kSwSide && (kSwPitch % 4) == 0, "window rows are written as dwords");
 constexpr int kSwWinBytes = kSwSide * kSwPitch;  // the window in LDS
-// The HYBRID form (ranges beyond what the window holds): the window is laid out as for a range of kSwHybReach px, its last row
-// and column are EXIT cells and no skip inside leads past them; a ray that reads an exit cell goes on in the global wedge fields.
+// The HYBRID form (ranges beyond what the window holds): the window is laid out as for a range of kSwHybReach px; a lane's walk
+// gets a BUDGET of samples -- as many as no ray of the wedge can leave the window with, from the lane's origin and the wedge's
+// largest direction components -- and a ray that is still unstopped when the budget is spent goes on in the global wedge fields.
 #ifndef MCL_SW_HYB_PLAY
 #define MCL_SW_HYB_PLAY 40
 #endif
 constexpr int kSwHybPlay = MCL_SW_HYB_PLAY;      // cells of play its windows leave the particles of a work item
 constexpr int kSwHybReach = kSwSide - (kSwHybPlay + 3) - 2;      // 211: S - (reach + 2) - 3 = play
-constexpr int kSwExitByte = 0xFE;                // neither a stop (0xFF) nor a skip (1..127): -2 as the signed byte the trip reads
+static_assert(kWedges == 16, "the hybrid form's table of direction bounds is written for 22.5-degree wedges");
+// 1 / (largest x component) and 1 / (largest y component) of a unit step in the wedges of the mirrored frame, [0, 22.5) .. [67.5, 90) degrees
+__device__ constexpr double kSwHybInvDx[4] = {1.0, 1.0823922002923940, 1.4142135623730951, 2.6131259297527530};      // 1 / cos(0, 22.5, 45, 67.5)
+__device__ constexpr double kSwHybInvDy[4] = {2.6131259297527530, 1.4142135623730951, 1.0823922002923940, 1.0};      // 1 / sin(22.5, 45, 67.5, 90)
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
 // fixed-point scale of a direction component: 2^32 - 3, so that |component| = 1 stays below 2^32 (the operand of v_mad_u64_u32
 // has 32 bits) with the + 1 of MCL_SW_ROTATE and its two roundings on top; the guard pays for it with 3 units (2^-32 px) per sample
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch)                                              \
         : MCL_SW_CLOBBERS)
 
-#define MCL_SW_WALK_REC_T(NEGX, NEGY, TRIPS, ...)                                                                                           \
+#define MCL_SW_WALK_REC_T(NEGX, NEGY, TRIPS, XOUT, ...)                                                                                           \
     asm volatile(                                                                                                              \
         "ds_read2_b64 v[40:43], %[je] offset1:1\n\t" /* offsets of the first two beams; the next two are read two beams ahead */ \
         "v_mov_b32 v48, %[zoff]\n\t"                                                                                           \
@@ -509,14 +513,16 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         MCL_SW_STEP_REC("%[xb]", "%[yb]", "%[xa]", "%[ya]")                                                                    \
         MCL_SW_TAIL_R_LAST("24")                                                                                               \
         : [acc] "+v"(acc_fast), [je] "+v"(je), [j8b] "+v"(j8b), [g] "+v"(gwalk), [xa] "+v"(xa), [ya] "+v"(ya), [xb] "+v"(xb),   \
-          [yb] "+v"(yb), [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd)                                                \
-        : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_start), [s0] "v"(s0e),                                                 \
+          [yb] "+v"(yb), [tc] "+s"(tc), [expired] "+s"(expired), [cd] "=&s"(cd) XOUT                                           \
+        : [p0x] "v"(P0x), [p0y] "v"(P0y), [rem0] "v"(rem_walk), [s0] "v"(s0e),                                                  \
           [ince] "v"(inc32), [rk] "s"(a.rec_k), [ltb] "s"(a.Ltd), [st8] "s"(st8),                                               \
           [magic1] "s"(6755399441055745.0), [zoff] "s"(zoff), [lb] "n"(kQLdsBase), [wp] "s"(wpitch) __VA_ARGS__                                              \
         : MCL_SW_CLOBBERS)
 
-#define MCL_SW_WALK_REC(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS)
-#define MCL_SW_WALK_HYB(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS MCL_SW_ESCAPE, , [gx] "s"(hyb_gx), [gy] "s"(hyb_gy), [pitch] "s"(gpitch), [gbase] "s"(a.distg))
+#define MCL_SW_NO_XOUT
+#define MCL_SW_HYB_XOUT , [em] "=&s"(hyb_em)
+#define MCL_SW_WALK_REC(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS, MCL_SW_NO_XOUT)
+#define MCL_SW_WALK_HYB(NEGX, NEGY) MCL_SW_WALK_REC_T(NEGX, NEGY, MCL_SW_TRIPS_LDS MCL_SW_ESCAPE, MCL_SW_HYB_XOUT, , [gx] "s"(hyb_gx), [gy] "s"(hyb_gy), [pitch] "s"(gpitch), [gbase] "s"(a.distg), [dd] "v"(hyb_dd), [dm] "s"(hyb_dm))
 
 // ---- the same walk on the wedge fields in GLOBAL memory (k_rays_sweep<.., GLOBAL>): ranges beyond what a 256-cell LDS window
 // holds (cpp:195 puts no bound on MAX_RANGE_PX).  The fields are read in place from copies that are MIRRORED per quadrant like
@@ -557,16 +563,21 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "2:\n\t"                                                                                                               \
         "s_mov_b64 exec, -1\n\t"
 
-// HYBRID: the lanes whose ray has just read an exit cell of the window (v49 = -2; the others ended at a stop or ran out of
-// range) go on in the mirrored wedge fields in global memory: samples left restored (the borrow subtracted -2), the cell dwords
-// moved from the window's frame to the ringed field's (%[gx] carries the field's byte offset as well), and a first trip that
-// advances by zero -- it reads, from global memory, the cell the ray stands in.  The usual case -- nobody left the window -- costs
-// one compare and a branch per ray.
+// HYBRID: inside the window samples left count against the lane's BUDGET (the table offset of the lane carries the deficit
+// %[dd] = range - budget, so a stop inside the window finds its row without an instruction).  The lanes whose ray spent the budget
+// without a stop (samples left negative -- a skip beyond what was left -- in a lane whose budget was cut short: the mask %[dm]; the
+// others ended at a stop or ran out of RANGE) go on in the mirrored wedge fields in global memory: samples left of the true range
+// restored (the borrow undone, the deficit back), the cell dwords moved from the window's frame to the ringed field's (%[gx] carries
+// the field's byte offset as well), and a first trip that advances by zero -- it reads, from global memory, the cell the ray stands
+// in.  Back in the window's terms afterwards: a stop keeps its samples left minus the deficit, "no stop in range" becomes the row
+// just below the deficit.  The usual case -- nobody left the window -- costs one compare and a branch per ray.
 #define MCL_SW_ESCAPE                                                                                                          \
-        "v_cmp_eq_u32 vcc, -2, v49\n\t"                                                                                        \
-        "s_cbranch_vccz 7f\n\t"                                                                                                \
+        "v_cmp_gt_i32 vcc, 0, v57\n\t"                                                                                         \
+        "s_and_b64 vcc, vcc, %[dm]\n\t"                                                                                        \
+        "s_cbranch_scc0 7f\n\t"                                                                                                \
+        "s_mov_b64 %[em], vcc\n\t"                                                                                             \
         "s_mov_b64 exec, vcc\n\t"                                                                                              \
-        "v_add_u32 v57, -2, v57\n\t"                                                                                           \
+        "v_add3_u32 v57, v57, v49, %[dd]\n\t"                                                                                  \
         "v_add_u32 v53, %[gx], v53\n\t"                                                                                        \
         "v_add_u32 v55, %[gy], v55\n\t"                                                                                        \
         "v_mov_b32 v49, 0\n\t"                                                                                                 \
@@ -577,6 +588,11 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         "s_cbranch_scc0 6b\n\t"                                                                                                \
         "s_mov_b32 %[expired], 1\n"                                                                                            \
         "8:\n\t"                                                                                                               \
+        "s_mov_b64 exec, %[em]\n\t"                                                                                            \
+        "v_cmp_lt_i32 vcc, 0, v57\n\t"                                                                                         \
+        "v_sub_u32 v57, v57, %[dd]\n\t"                                                                                        \
+        "v_not_b32 v48, %[dd]\n\t"                                                                                             \
+        "v_cndmask_b32 v57, v48, v57, vcc\n\t"                                                                                 \
         "s_mov_b64 exec, -1\n"                                                                                                 \
         "7:\n\t"
 
@@ -842,27 +858,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                         if (gx + k >= 0 && gx + k < a.Wp) b8 = (b8 & ~(0xFFull << (8 * k))) | ((uint64_t)rowp[gx + k] << (8 * k));
                 }
             }
-            uint64_t w8 = sxp ? b8 : __builtin_bswap64(b8);
-            if (HYB) {
-                // no skip leads past the last row or column -- a jump of k samples moves at most k cells along either axis --, and
-                // those are exit cells where they lie inside the grid (outside it a window is stop bytes, which no ray crosses)
-                const bool row_in = gy >= 0 && gy < a.Hp;
-                const int rleft = (S - 1) - row, c0 = cw * 8;
-                if (rleft < 128 || c0 + 7 > (S - 1) - 128 || row == S - 1) {
-                    uint64_t o = 0;
-#pragma unroll 1        // (kept rolled: unrolled, its temporaries pushed seventy registers of the chunk loop into scratch)
-                    for (int k = 0; k < 8; ++k) {
-                        const int col = c0 + k, cleft = (S - 1) - col;
-                        const int gxk = sxp ? wx0 + col : wx0 + (S - 1) - col;
-                        uint32_t b = (uint32_t)(w8 >> (8 * k)) & 0xFFu;
-                        const uint32_t lim = (uint32_t)(rleft < cleft ? rleft : cleft);
-                        if (b != 0xFFu && b > lim) b = lim;                 // (lim == 0 only in the exit row / column, set below)
-                        if ((rleft == 0 || cleft == 0) && row_in && gxk >= 0 && gxk < a.Wp) b = (uint32_t)kSwExitByte;
-                        o |= (uint64_t)b << (8 * k);
-                    }
-                    w8 = o;
-                }
-            }
+            const uint64_t w8 = sxp ? b8 : __builtin_bswap64(b8);
             uint32_t *wp = win + row * (kSwPitch / 4) + cw * 2;
             wp[0] = (uint32_t)w8; wp[1] = (uint32_t)(w8 >> 32);
         }
@@ -966,6 +962,21 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
         const unsigned long long P0x = ((unsigned long long)(cx0 + foff) << 32) | lox;
         const unsigned long long P0y = ((unsigned long long)cy0 << 32) | loy;
         const int rem_start = live ? a.P - (int)s0e : 0;
+        // HYB: the budget of this lane's walk in the window -- after fewer samples than this no ray of the wedge has reached the
+        // window's last row or column: a sample moves a ray by at most dx_max / dy_max cells (the wedge's bounds in the mirrored
+        // frame; the beams' offsets from the grid and the roundings are far inside the cell of margin) -- and what it leaves of
+        // the range
+        [[maybe_unused]] int rem_walk = rem_start, hyb_dd = 0;
+        [[maybe_unused]] unsigned long long hyb_dm = 0ull;
+        if (HYB) {
+            const int wq = kbin & (kWedges / 4 - 1), wm = (q & 1) ? (kWedges / 4 - 1) - wq : wq;      // the wedge's place in the mirrored quadrant
+            const double bx = ((double)(kSwSide - 1) - lpx) * kSwHybInvDx[wm], by = ((double)(kSwSide - 1) - lpy) * kSwHybInvDy[wm];
+            const double bmin = bx < by ? bx : by;
+            const int budget = bmin >= (double)a.P ? a.P : (bmin > (double)s0e ? (int)bmin : (int)s0e);      // (inside the window a lane has kSwHybReach + 2 cells ahead: far more than a skip)
+            hyb_dd = live ? a.P - budget : 0;
+            rem_walk = live ? budget - (int)s0e : 0;
+            hyb_dm = __ballot(hyb_dd > 0);
+        }
         // direction components in the mirrored frame: Xx = aq cb - bq sb, Xy = +-(bq cb + aq sb), both >= 0
         const double dsc = sxp ? kSwDirScale : -kSwDirScale;
         const double aq = live ? pci.x * dsc : 0.0, bq = live ? pci.y * dsc : 0.0;
@@ -1009,6 +1020,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
             uint32_t j16 = live ? (uint32_t)(jw + a.beam_margin) << 4 : 0u;
             // table column offset, biased by kSwUnder rows so that (samples left) * row bytes + j8b is never negative
             uint32_t j8b = (uint32_t)kSwUnder * st8 + ((uint32_t)((live ? jw : a.B) + a.beam_margin) << 3);
+            if (HYB) j8b += (uint32_t)hyb_dd * st8;                   // samples left inside the window count against the lane's budget: rows further down by the deficit
             const uint32_t inc16 = live ? 16u : 0u, inc8 = live ? 8u : 0u;
             const uint32_t inc32 = live ? 32u : 0u;                   // (REC: bytes of table columns / beam offsets per turn of the walk's loop)
             uint32_t tc = (uint32_t)walk_n - 1u, expired = 0u, cd;
@@ -1023,7 +1035,7 @@ __global__ __launch_bounds__(kRayThreads, 8) void k_rays_sweep(RayArgs a)
                 (void)j16;
                 if constexpr (!PAIRS) {
                     static_assert(PAIRS || !GLOBAL || !REC, "the global-field form walks pairs when it turns the directions");
-                    if constexpr (HYB) { if (negy) MCL_SW_WALK_HYB("", "-"); else MCL_SW_WALK_HYB("-", ""); }
+                    if constexpr (HYB) { unsigned long long hyb_em; if (negy) MCL_SW_WALK_HYB("", "-"); else MCL_SW_WALK_HYB("-", ""); }
                     else if constexpr (!GLOBAL) { if (negy) MCL_SW_WALK_REC("", "-"); else MCL_SW_WALK_REC("-", ""); }
                 } else {
                     // two rays per lane (MCL_SW2_*): ceil(walk_n / 2) pairs of slots

@@ -56,55 +56,30 @@ def test_brute_force_on_a_small_map():
     assert off.min() >= 0 and off.max() < g["stride"]
 
 
-# ---- the hybrid form's LDS window (csrc/mcl_rays_sweep.h, the window loader under HYB): ranges beyond the window -------------------
-# The rule the loader applies, restated: in a 256 x 256 window whose rays run towards +x, +y, the last row and the last column are
-# EXIT cells (0xFE) where they lie inside the grid, and every skip byte (1 .. 127; stops, 0xFF, are left alone) is clamped to
-# min(255 - row, 255 - column).  A jump of k samples moves a ray by at most k cells along either axis (a direction component is
-# at most one cell per sample), so from any cell a walk that only ever advances by the byte of the cell it stands in stays inside the
-# window until it reads a stop, an exit, or runs out of samples -- whatever the field holds.
-S, EXIT, STOP = 256, 0xFE, 0xFF
+# ---- the hybrid form's LDS window (csrc/mcl_rays_sweep.h: the budget of a lane's walk under HYB): ranges beyond the window ----------
+# The rule, restated: in the 256 x 256 window every ray of a wedge runs towards +x, +y, and a unit step of a ray of mirrored wedge
+# wm (directions wm * 22.5 .. (wm + 1) * 22.5 degrees) moves it by at most cos(wm * 22.5) cells in x and sin((wm + 1) * 22.5) in y.
+# A lane whose origin is (x0, y0) gets budget = floor(min((255 - x0) / dx_max, (255 - y0) / dy_max)) samples (at most the range):
+# within them every sample of every ray of the wedge lies in a cell of the window, whatever the field holds; a ray that is
+# unstopped when they are spent goes on in the global fields.
+S = 256
+INV_DX = [1.0, 1.0823922002923940, 1.4142135623730951, 2.6131259297527530]
+INV_DY = [2.6131259297527530, 1.4142135623730951, 1.0823922002923940, 1.0]
 
 
-def hybrid_window(field, in_grid):
-    """field: S x S bytes in the window's (mirrored) frame, 1 .. 127 or STOP; in_grid: which cells lie inside the map."""
-    w = field.copy()
-    rr, cc = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
-    lim = np.minimum(S - 1 - rr, S - 1 - cc)
-    skip = w != STOP
-    w[skip] = np.minimum(w[skip], lim[skip])
-    edge = ((rr == S - 1) | (cc == S - 1)) & in_grid
-    w[edge] = EXIT
-    return w
-
-
-@pytest.mark.parametrize("seed", range(4))
-def test_hybrid_window_no_walk_leaves_it_unnoticed(seed):
-    rng = np.random.default_rng(seed)
-    field = rng.integers(1, 128, (S, S)).astype(np.uint8)
-    field[rng.random((S, S)) < 0.002] = STOP
-    in_grid = np.ones((S, S), bool)
-    if seed & 1:                                    # the grid ends inside the window: beyond it a window is stop bytes
-        in_grid[:, 200:] = False
-        in_grid[230:, :] = False
-        field[~in_grid] = STOP
-    w = hybrid_window(field, in_grid)
-    assert (w[in_grid & (w != STOP)] != 0).all()                       # no zero skip anywhere a ray can stand
-    assert (w[-1, :][in_grid[-1, :]] == EXIT).all() and (w[:, -1][in_grid[:, -1]] == EXIT).all()
-    P = 479
-    n = 4000
-    y = rng.uniform(2.0, 44.0, n); x = rng.uniform(2.0, 44.0, n)       # origins in the play corner
-    th = rng.uniform(0.0, np.pi / 2, n)
-    dy, dx = np.sin(th), np.cos(th)                                     # both components in [0, 1]: the mirrored frame
-    left = np.full(n, P)
-    alive = np.ones(n, bool)
-    for _ in range(2 * S):
-        r, c = np.floor(y).astype(int), np.floor(x).astype(int)
-        assert (r[alive] <= S - 1).all() and (c[alive] <= S - 1).all()  # every read lies inside the window
-        b = w[np.minimum(r, S - 1), np.minimum(c, S - 1)].astype(int)
-        ended = alive & ((b == STOP) | (b == EXIT) | (b > left))
-        alive &= ~ended
-        if not alive.any():
-            break
-        y = np.where(alive, y + b * dy, y); x = np.where(alive, x + b * dx, x)
-        left = np.where(alive, left - b, left)
-    assert not alive.any()
+@pytest.mark.parametrize("wm", range(4))
+def test_hybrid_budget_keeps_every_sample_inside_the_window(wm):
+    rng = np.random.default_rng(wm)
+    assert abs(INV_DX[wm] - 1.0 / np.cos(np.radians(22.5 * wm))) < 1e-15 * INV_DX[wm] * 4
+    assert abs(INV_DY[wm] - 1.0 / np.sin(np.radians(22.5 * (wm + 1)))) < 1e-15 * INV_DY[wm] * 4
+    n, P = 20000, 479
+    x0 = rng.uniform(2.0, 45.0, n); y0 = rng.uniform(2.0, 45.0, n)                  # origins in the play corner (40 cells + margins)
+    # directions of the wedge, and up to one beam (a quarter of a degree) beyond either end: the virtual beams of a scan-edge lane
+    psi = np.radians(rng.uniform(22.5 * wm - 0.25, 22.5 * (wm + 1) + 0.25, n))
+    dx, dy = np.abs(np.cos(psi)), np.abs(np.sin(psi))
+    budget = np.minimum(np.floor(np.minimum((S - 1 - x0) * INV_DX[wm], (S - 1 - y0) * INV_DY[wm])), P)
+    assert (budget >= 209).all()                                                     # the window is laid out for 211 px of reach
+    xe, ye = x0 + budget * dx, y0 + budget * dy                                      # the farthest sample a walk can stand on
+    assert (xe < S).all() and (ye < S).all() and (np.floor(xe) <= S - 1).all() and (np.floor(ye) <= S - 1).all()
+    inside = (psi >= np.radians(22.5 * wm)) & (psi <= np.radians(22.5 * (wm + 1)))
+    assert (xe[inside] <= S - 1 + 1e-9).all() and (ye[inside] <= S - 1 + 1e-9).all()   # real beams keep a whole cell of margin
