@@ -276,3 +276,42 @@ def test_turned_and_fetched_beam_directions_agree(orc, engine_mod, spielberg, mo
     assert np.array_equal(engines[0].log_weights()[pick], logw)
     for e in engines:
         e.close()
+
+
+@pytest.mark.lds_windows
+def test_relocalisation_on_a_long_range_map_does_not_alternate_between_the_forms(orc, engine_mod, maps_mod, spielberg, _global_fields):
+    """A global re-localisation on the 479-px map through AUTO (default settings: this test overrides the module's MCL_SWEEP_HYBRID).
+    The freshly initialised set takes the global-field form; a hybrid update that leaves many particles to the far pass (the cloud has
+    not converged) is followed by an update in the global-field form -- a back-off, so the two cannot alternate forever --; every
+    update's log-weights (sampled) equal the oracle's on the particles the engine produced."""
+    if _global_fields != "hybrid":
+        pytest.skip("one run: the default decision")
+    import os as _os
+    from monte_carlo_localization_amd import synth
+    _os.environ.pop("MCL_SWEEP_HYBRID", None)
+    fine = maps_mod.synthetic_fine025(spielberg)
+    om = orc.OracleMap(fine.data, fine.resolution, fine.origin_x, fine.origin_y)
+    ang = synth.beam_angles()
+    n = 262144
+    e = make_engine(engine_mod, fine, ang, n, seed=11)
+    scan = synth.scan_from_pose(e, fine, ang, (0.0, 0.0, 0.0))
+    e.init_global(n)
+    L = orc.eng_log_table(orc.sensor_table(om.max_range_px))
+    oi = orc.obs_index(scan, om)
+    rng = np.random.default_rng(4)
+    hist = []
+    for k in range(8):
+        e.update((0.05, 0.0, 0.01), scan)
+        v, c = e.ray_kernel_variant(), e.counters()
+        hist.append(("hybrid" if v["hybrid"] else "global" if v["global_fields"] else "lds", c["off_window_particles"]))
+        parts, lw = e.get_particles(), e.log_weights()
+        pick = rng.choice(n, 512, replace=False)
+        logw, _, _ = orc.eng_log_weights(om, np.ascontiguousarray(parts[:, pick]), ang, oi, L)
+        assert np.array_equal(lw[pick], logw), (k, hist)
+    e.close()
+    assert hist[0][0] == "global", hist                         # a freshly initialised set
+    assert all(f in ("hybrid", "global") for f, _ in hist), hist
+    for (f0, off0), (f1, _) in zip(hist, hist[1:]):
+        if f0 == "hybrid" and off0 >= 1024:
+            assert f1 == "global", hist                         # the back-off
+    assert any(f == "hybrid" for f, _ in hist), hist            # ... and the hybrid is tried
