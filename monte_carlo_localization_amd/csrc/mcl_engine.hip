@@ -413,7 +413,7 @@ int launch_sweep_plan(mcl_engine *h, int64_t n, int nwg, int g, bool hybrid)
     const int play = sweep_play(h, hybrid);                             // cells a window leaves for the particles of an item
     // (EV_K0 = the stop event of the kernel before the ray kernel, EV_K1 = the ray kernel's own: its duration, dispatch included, at no cost)
     hipExtLaunchKernelGGL(mcl::k_sweep_plan, dim3(1), dim3(1024), mcl::kPlanLds, h->stream, nullptr, h->ev[EV_K0], 0, h->d_unit_sums, h->d_nunits, ngroups, nwg,
-                          (double)(play / 2 - 1), h->d_items, h->d_centres, h->d_nitems);
+                          (double)(play / 2 - 1), h->env_sw_guide > 0 ? h->env_sw_guide : (h->sweep_global ? 3 : 2), h->d_items, h->d_centres, h->d_nitems);
     HIPCHK(h, hipGetLastError());
     return MCL_OK;
 }
@@ -989,6 +989,7 @@ int mcl_create(const mcl_config_t *cfg, mcl_engine_t **out)
     h->env_no_bucket_cuts = getenv("MCL_NO_BUCKET_CUTS") != nullptr;
     if (const char *e = getenv("MCL_SWEEP_GLOBAL")) h->env_sweep_global = atoi(e) != 0;
     if (const char *e = getenv("MCL_SWEEP_HYBRID")) h->env_sweep_hybrid = atoi(e);
+    if (const char *e = getenv("MCL_SW_GUIDE")) h->env_sw_guide = atoi(e);
     if (const char *e = getenv("MCL_SW_SPLIT16")) h->env_sw_split16 = atoi(e) != 0;
     if (const char *e = getenv("MCL_SWEEP_PAIRS")) h->env_sweep_pairs = atoi(e) != 0 ? 1 : 0;
     h->env_no_obs_overlap = getenv("MCL_NO_OBS_OVERLAP") != nullptr;

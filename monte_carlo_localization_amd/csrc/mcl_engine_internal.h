@@ -81,6 +81,7 @@ struct mcl_engine {
     bool sweep_layout_ok = false;       // k_rays_sweep's static LDS ends where its raw window offset (kQLdsBase) assumes
     bool sweep_hyb_layout_ok = false;   // ... and of its hybrid form
     int env_sweep_hybrid = 1;           // MCL_SWEEP_HYBRID=0: ranges beyond the window take the global-field form alone; 2: the hybrid also for a fresh / spread set
+    int env_sw_guide = 0;               // MCL_SW_GUIDE=<n>: the guide of k_sweep_plan's run lengths (default 2; 3 for the forms of ranges beyond the LDS window)
     int hyb_backoff = 0, hyb_skip = 0;  // updates in the global-field form after a hybrid update that flagged many particles (sweep_hybrid_decide)
     int last_sweep_global = 0, last_sweep_rec = 0, last_sweep_pairs = 0;    // the form of k_rays_sweep the last ray stage ran
     int env_sweep_pairs = -1;           // MCL_SWEEP_PAIRS: -1 the engine decides, 0 / 1 forced (A/B measurements)

@@ -225,12 +225,16 @@ __global__ __launch_bounds__(256) void k_unit_sums(const double4 *__restrict__ p
 
 // Work items of k_rays_sweep: (first unit, units, wedge group).  One thread looks at an aligned block of kSwRunMax units:
 // the run length the guided schedule wants there (long runs while plenty of work is left -- fewer window loads and fewer
-// workgroup barriers per particle --, single units for the last third, so that the persistent workgroups finish within
+// workgroup barriers per particle --, single units towards the end, so that the persistent workgroups finish within
 // one small item of each other) is halved until the particles of every run fit one window (`half_play` cells either side of
 // the centre of the run's bounding box, both axes; a sparse cloud or a long range thus gets shorter runs instead of off-window
 // particles).  Every run is listed once per wedge group.  One workgroup; items come out in unit order.
+// (the guide: a run is as long as remaining items / (guide x workgroups) allows; `guide` comes from the host, MCL_SW_GUIDE=<n> overrides
+//  it.  Ray kernel ms at 4M / 1M / 262 144 x 1081 with 1: 4.40 / 1.26 / 0.47, 2: 4.24 / 1.22 / 0.41, 3 -- rounds 3-4, tuned on a
+//  kernel a third slower --: 4.34 / 1.26 / 0.42, 4: 4.38 / 1.29 / 0.44; on the 479-px map the hybrid form 2: 5.98, 3: 5.72, 4: 5.77 and the global-field form 2: 12.21, 3: 12.02 (their
+//  chunks vary more: a probe served from L2 costs several times one from LDS); profiles/r05_experiments/guide.txt)
 #ifndef MCL_SW_GUIDE
-#define MCL_SW_GUIDE 3
+#define MCL_SW_GUIDE 2
 #endif
 #ifndef MCL_SW_RUNMAX
 #define MCL_SW_RUNMAX 16
@@ -240,7 +244,7 @@ static_assert(kSwRunMax == 16, "k_sweep_plan's bounding-box pyramid has four lev
 constexpr int kPlanBlocks = 256;                 // blocks of kSwRunMax units planned per pass of the workgroup
 constexpr int kPlanLds = (kPlanBlocks * kSwRunMax + kPlanBlocks * kSwRunMax * 15 / 16) * (int)sizeof(float4);     // the unit boxes and levels 1..4 of one pass: 126 976 bytes
 __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__ unit_stats, const int *__restrict__ m_ptr, int ngroups, int nwg, double half_play,
-                                                    int4 *__restrict__ items, int4 *runs, int *__restrict__ nitems_out)
+                                                    int guide, int4 *__restrict__ items, int4 *runs, int *__restrict__ nitems_out)
 {
     // Bounding boxes of the aligned runs of 2, 4, 8 and 16 units as a pyramid in LDS (floats: the plan is a heuristic, the ray
     // kernel tests every particle against its window exactly), built by all threads; then one thread per block of 16 units
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_sweep_plan(const double4 *__restrict__
         unsigned int starts = 0u;                 // bit k: a run starts at unit k of the block (it ends where the next one starts)
         int nruns = 0;
         if (mine) {
-            long long want = ((long long)(M - u0) * ngroups) / ((long long)MCL_SW_GUIDE * (nwg > 0 ? nwg : 1));
+            long long want = ((long long)(M - u0) * ngroups) / ((long long)(guide > 0 ? guide : MCL_SW_GUIDE) * (nwg > 0 ? nwg : 1));
             int c = 1;                            // (a floor of 2 or 4 units per run costs 0.5 / 2.5 %: the tail of the launch)
             while (c * 2 <= kSwRunMax && c * 2 <= want) c *= 2;
             // runs of c units, each halved until it fits
