@@ -52,10 +52,21 @@ constexpr int kSwWinBytes = kSwSide * kSwPitch;  // the window in LDS
 #endif
 constexpr int kSwHybPlay = MCL_SW_HYB_PLAY;      // cells of play its windows leave the particles of a work item
 constexpr int kSwHybReach = kSwSide - (kSwHybPlay + 3) - 2;      // 211: S - (reach + 2) - 3 = play
-static_assert(kWedges == 16, "the hybrid form's table of direction bounds is written for 22.5-degree wedges");
-// 1 / (largest x component) and 1 / (largest y component) of a unit step in the wedges of the mirrored frame, [0, 22.5) .. [67.5, 90) degrees
-__device__ constexpr double kSwHybInvDx[4] = {1.0, 1.0823922002923940, 1.4142135623730951, 2.6131259297527530};      // 1 / cos(0, 22.5, 45, 67.5)
-__device__ constexpr double kSwHybInvDy[4] = {2.6131259297527530, 1.4142135623730951, 1.0823922002923940, 1.0};      // 1 / sin(22.5, 45, 67.5, 90)
+// 1 / (largest x component) and 1 / (largest y component) of a unit step in the wedges of the mirrored frame (wedge w of the quadrant:
+// directions w .. w + 1 times 90 / (kWedges / 4) degrees): 1 / cos(lower bound), 1 / sin(upper bound)
+#if MCL_KWEDGES == 8
+__device__ constexpr double kSwHybInvDx[2] = {1.0, 1.414213562373095};
+__device__ constexpr double kSwHybInvDy[2] = {1.4142135623730951, 1.0};
+#elif MCL_KWEDGES == 16
+__device__ constexpr double kSwHybInvDx[4] = {1.0, 1.082392200292394, 1.414213562373095, 2.6131259297527527};
+__device__ constexpr double kSwHybInvDy[4] = {2.613125929752753, 1.4142135623730951, 1.082392200292394, 1.0};
+#elif MCL_KWEDGES == 32
+__device__ constexpr double kSwHybInvDx[8] = {1.0, 1.0195911582083184, 1.082392200292394, 1.2026897738700906, 1.414213562373095, 1.7999524462728311, 2.6131259297527527, 5.125830895483011};
+__device__ constexpr double kSwHybInvDy[8] = {5.125830895483013, 2.613125929752753, 1.7999524462728316, 1.4142135623730951, 1.2026897738700906, 1.082392200292394, 1.0195911582083184, 1.0};
+#elif MCL_KWEDGES == 64
+__device__ constexpr double kSwHybInvDx[16] = {1.0, 1.0048385723763114, 1.0195911582083184, 1.0449972298793777, 1.082392200292394, 1.1338880696327154, 1.2026897738700906, 1.2936435667199802, 1.414213562373095, 1.5763092469025004, 1.7999524462728311, 2.121355371980695, 2.6131259297527527, 3.4448941964766684, 5.125830895483011, 10.202297237378334};
+__device__ constexpr double kSwHybInvDy[16] = {10.202297237378328, 5.125830895483013, 3.4448941964766684, 2.613125929752753, 2.121355371980695, 1.7999524462728316, 1.5763092469025004, 1.4142135623730951, 1.2936435667199802, 1.2026897738700906, 1.1338880696327154, 1.082392200292394, 1.0449972298793777, 1.0195911582083184, 1.0048385723763114, 1.0};
+#endif
 constexpr int kSwMinExtent = 8;          // cells of play a window must leave for the particles of a work item (P <= 243)
 // fixed-point scale of a direction component: 2^32 - 3, so that |component| = 1 stays below 2^32 (the operand of v_mad_u64_u32
 // has 32 bits) with the + 1 of MCL_SW_ROTATE and its two roundings on top; the guard pays for it with 3 units (2^-32 px) per sample
