@@ -678,7 +678,6 @@ int launch_rays(mcl_engine *h, const double *x, const double *y, const double *t
             hipLaunchKernelGGL(mcl::k_sort_hist, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->Wp, h->Hp, h->d_bbox, h->d_hist,
                                h->d_skey, h->d_srank, h->d_tile_used, h->d_tilemap, ntx_abs);
             hipLaunchKernelGGL(mcl::k_hist_partials, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
-            hipLaunchKernelGGL(mcl::k_hist_spine, dim3(1), dim3(1024), 0, h->stream, h->d_histpart, nparts);
             hipLaunchKernelGGL(mcl::k_hist_final, dim3(nparts), dim3(256), 0, h->stream, h->d_hist, h->d_histpart, h->d_tile_used);
             hipLaunchKernelGGL(mcl::k_sort_scatter, dim3(nb256), dim3(256), 0, h->stream, h->d_pc, th, n, h->d_skey, h->d_srank,
                                h->d_hist, h->d_pcs, h->d_ths, h->d_perm);

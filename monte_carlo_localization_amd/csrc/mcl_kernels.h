@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ p
     if (r == 0u) tile_used[key / kHistTile] = 1u;
 }
 
-// totals of kHistTile buckets (over all XCD copies) per workgroup
+// totals of kHistTile buckets (over all XCD copies) per workgroup: part[t], zero for a tile nobody fell into
 __global__ __launch_bounds__(256) void k_hist_partials(const uint32_t *__restrict__ hist, uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_used)
 {
     __shared__ uint32_t ws[4];
@@ -1526,37 +1526,19 @@ __global__ __launch_bounds__(256) void k_hist_partials(const uint32_t *__restric
     if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// exclusive scan of the kSortKeySpace / kHistTile workgroup totals, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_hist_spine(uint32_t *__restrict__ part, int nparts)
-{
-    __shared__ uint32_t ws[16];
-    __shared__ uint32_t carry_s;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nparts; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const uint32_t v = i < nparts ? part[i] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) ws[w] = inc;
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (int k = 0; k < w; ++k) off += ws[k];
-        if (i < nparts) part[i] = off + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + inc;
-        __syncthreads();
-    }
-}
-
 // in place: counter (bucket b, xcd x) -> first slot of that group in the order bucket-major, xcd-minor
 __global__ __launch_bounds__(256) void k_hist_final(uint32_t *__restrict__ hist, const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_used)
 {
-    __shared__ uint32_t ws[4];
+    __shared__ uint32_t ws[4], ps[4];
     if (!tile_used[blockIdx.x]) return;           // no particle in these buckets: nobody reads their offsets
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // slots in front of this tile: the totals of the tiles before it, summed here (at most 1023 words out of L2, by the used
+    // tiles only) instead of scanned by a one-workgroup launch in between
+    uint32_t pre = 0;
+    for (int t = (int)threadIdx.x; t < (int)blockIdx.x; t += 256) pre += part[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    if (lane == 0) ps[w] = pre;
     const size_t b0 = (size_t)blockIdx.x * kHistTile + (size_t)threadIdx.x * 16;    // 16 consecutive buckets per thread
     uint4 v[kSortXcds][4];
     uint32_t s = 0;
@@ -1571,7 +1553,7 @@ __global__ __launch_bounds__(256) void k_hist_final(uint32_t *__restrict__ hist,
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     if (lane == 63) ws[w] = inc;
     __syncthreads();
-    uint32_t run = part[blockIdx.x] + inc - s;
+    uint32_t run = ps[0] + ps[1] + ps[2] + ps[3] + inc - s;
     for (int k = 0; k < w; ++k) run += ws[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -106,7 +106,7 @@ __global__ void k_build_ltd(const float *__restrict__ L, const int32_t *__restri
 // well: the particles of a unit then lie within ONE bucket, which the play of a window covers, where a unit that straddles
 // two (64 x 32 cells or worse) loses its minority side to the far pass.  Any other set gets the plain grid of kSwUnit slots.
 // Where a bucket starts: counting sort -- hist, the bucket offsets k_hist_final left (copy of XCD 0 = the first slot of a key),
-// and part, the exclusive prefix of the histogram tiles' totals (the offset of every key of a tile nobody fell into); radix
+// and part, the histogram tiles' totals (their exclusive prefix, formed here, is the offset of every key of a tile nobody fell into); radix
 // sort -- cut_start / cut_end, written by k_sort_gather where the sorted keys change bucket (zeroed here for the next update).
 // One workgroup.
 __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbox, int64_t n, const uint32_t *__restrict__ hist,
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     __shared__ uint32_t ws[16];
     __shared__ uint32_t carry_sh, nbig_sh;
     __shared__ uint4 big_sh[1024];
+    __shared__ uint32_t part_ex[1024];
     const SortLayout L = sort_layout(bbox, n);
     const int shift = L.cut_shift();
     const bool cut = L.cuts();
@@ -130,11 +131,24 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     const int ntl = (int)L.cut_groups();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) { carry_sh = 0u; nbig_sh = 0u; }
+    if (!cut_start) {
+        // counting sort: the histogram tiles' totals (k_hist_partials) -> the slots in front of every tile
+        static_assert(kSortKeySpace / kHistTile == 1024, "one total per thread");
+        const uint32_t v = part[threadIdx.x];
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        uint32_t off = inc - v;
+        for (int k = 0; k < wv; ++k) off += ws[k];
+        part_ex[threadIdx.x] = off;
+    }
     __syncthreads();
     auto start_of = [&](int t) -> uint32_t {               // counting sort: first slot of bucket t's first key
         if (t >= ntl) return (uint32_t)n;
         const uint32_t key0 = (uint32_t)t << shift;
-        return tile_used[key0 >> 12] ? hist[key0] : part[key0 >> 12];
+        return tile_used[key0 >> 12] ? hist[key0] : part_ex[key0 >> 12];
     };
     for (int t0 = 0; t0 < ntl; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
