@@ -1296,7 +1296,15 @@ __global__ __launch_bounds__(256) void k_wedge_field(const int32_t *__restrict__
 // returns is the particle's rank inside (bucket, xcd); the scan orders the counters bucket-major, xcd-minor.  The
 // rank order varies from run to run — harmless: the order only decides which rays share a wave, every log-weight
 // is an exact sum.
-constexpr int kSortKeyLog2 = 22;
+// (22 key bits and half cells.  24 bits / quarter cells and 26 bits / eighths were built and measured at the end of round 5: the ray
+//  kernel of the bench workload issues the same number of instructions launch for launch with all three -- the density gate of
+//  sort_layout, not the key space, ends the split there, so the order is the same -- and yet runs 1 % faster or slower: with where
+//  the buffers lie (the histogram allocation is 128 MB / 512 MB / 2 GB), which is all that is left to differ:
+//  profiles/r05_experiments/sort_key_bits.txt.  Not taken.)
+#ifndef MCL_SORT_KEY_LOG2
+#define MCL_SORT_KEY_LOG2 22
+#endif
+constexpr int kSortKeyLog2 = MCL_SORT_KEY_LOG2;
 constexpr uint32_t kSortKeySpace = 1u << kSortKeyLog2;
 #ifndef MCL_SORT_MAX_SUB
 #define MCL_SORT_MAX_SUB 1
@@ -1482,7 +1490,7 @@ __device__ __forceinline__ uint32_t sort_key(const int *__restrict__ bbox, const
     uint32_t tq = (f >= 0.0 && f < 1.0) ? (uint32_t)(f * (double)(1u << tb)) : 0u;
     if (tq >> tb) tq = (1u << tb) - 1u;
     key = (key << tb) | tq;
-    return key < kSortKeySpace ? (uint32_t)key : kSortKeySpace - 1u;    // a bounding box beyond 2^22 tiles: unsorted tail
+    return key < kSortKeySpace ? (uint32_t)key : kSortKeySpace - 1u;    // a bounding box beyond the key space: unsorted tail
 }
 
 __global__ __launch_bounds__(256) void k_sort_hist(const double4 *__restrict__ pc, const double *__restrict__ th, int64_t n, int Wp, int Hp,

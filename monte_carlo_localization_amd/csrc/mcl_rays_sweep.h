@@ -117,7 +117,9 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     __shared__ uint32_t ws[16];
     __shared__ uint32_t carry_sh, nbig_sh;
     __shared__ uint4 big_sh[1024];
-    __shared__ uint32_t part_ex[1024];
+    constexpr int kHistParts = (int)(kSortKeySpace / kHistTile);
+    static_assert(kHistParts % 1024 == 0, "the scan of the tiles' totals below takes 1024 at a time");
+    __shared__ uint32_t part_ex[kHistParts];
     const SortLayout L = sort_layout(bbox, n);
     const int shift = L.cut_shift();
     const bool cut = L.cuts();
@@ -133,16 +135,21 @@ __global__ __launch_bounds__(1024) void k_unit_table(const int *__restrict__ bbo
     if (threadIdx.x == 0) { carry_sh = 0u; nbig_sh = 0u; }
     if (!cut_start) {
         // counting sort: the histogram tiles' totals (k_hist_partials) -> the slots in front of every tile
-        static_assert(kSortKeySpace / kHistTile == 1024, "one total per thread");
-        const uint32_t v = part[threadIdx.x];
-        uint32_t inc = v;
+        for (int t0 = 0; t0 < kHistParts; t0 += 1024) {
+            const uint32_t v = part[t0 + threadIdx.x];
+            uint32_t inc = v;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) ws[wv] = inc;
-        __syncthreads();
-        uint32_t off = inc - v;
-        for (int k = 0; k < wv; ++k) off += ws[k];
-        part_ex[threadIdx.x] = off;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            if (lane == 63) ws[wv] = inc;
+            __syncthreads();
+            uint32_t off = carry_sh + inc - v;
+            for (int k = 0; k < wv; ++k) off += ws[k];
+            part_ex[t0 + threadIdx.x] = off;
+            __syncthreads();
+            if (threadIdx.x == 1023) carry_sh = off + v;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) carry_sh = 0u;
     }
     __syncthreads();
     auto start_of = [&](int t) -> uint32_t {               // counting sort: first slot of bucket t's first key
