@@ -1393,6 +1393,10 @@ __global__ __launch_bounds__(1024) void k_tile_compact(int *__restrict__ bbox, i
     if (threadIdx.x == 0) { bbox[4] = T; bbox[5] = 1; }
 }
 
+#ifndef MCL_SORT_SUB_GATE
+#define MCL_SORT_SUB_GATE 32.0
+#endif
+constexpr double kSortSubGate = MCL_SORT_SUB_GATE;  // particles a bucket must hold (an eighth of its heading bins taken as occupied) to be split in four
 constexpr int kSortMaxSub = MCL_SORT_MAX_SUB;        // sub-cell bits per axis a dense set may get (0: none)
 // How the key bits are split for this update's set: a pure function of the bounding box / occupied-tile count and n, so that
 // every particle -- and k_unit_table, which needs to know where a tile's keys start -- derives the same layout.
@@ -1463,7 +1467,7 @@ __device__ __forceinline__ SortLayout sort_layout(const int *__restrict__ bbox, 
         // ... as long as a bucket still holds a few waves' worth: particles per cell of the bounding box, an eighth of the
         // heading bins taken as occupied (262 144 particles on 25 cells are better off without: 43 per bucket)
         double per_bucket = cells_est > 0.0 ? (double)n / cells_est / 32.0 : 0.0;
-        while (ss < kSortMaxSub && (ncell << (tb + 2 * (ss + 1))) <= kSortKeySpace && per_bucket >= 4.0 * 8.0) { ++ss; per_bucket *= 0.25; }
+        while (ss < kSortMaxSub && (ncell << (tb + 2 * (ss + 1))) <= kSortKeySpace && per_bucket >= kSortSubGate) { ++ss; per_bucket *= 0.25; }
     }
     L.cs = cs; L.tb = tb; L.inner = inner; L.ss = ss;
     return L;
